@@ -1,0 +1,661 @@
+// libdmad_hip.so — C ABI (include/dmad.h) and host-side engine: weight packing into MFMA/LDS
+// layouts, device workspace (allocated once in dmad_create), kernel sequencing on the caller's stream.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dmad.h"
+#include "dmad_common.h"
+#include "elementwise.h"
+#include "gemm_f32.h"
+#include "wn_bf16.h"
+
+using namespace dmad;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t _e = (x);                                                                        \
+        if (_e != hipSuccess) return fail(DMAD_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define CHK(x)                 \
+    do {                       \
+        int _r = (x);          \
+        if (_r != 0) return _r; \
+    } while (0)
+
+uint16_t f2bf(float f) {   // round-to-nearest-even, NaN stays NaN
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+const int kVggCfg[] = {64, 64, -1, 128, 128, -1, 256, 256, 256, 256, -1, 512, 512, 512, 512, -1, 512, 512, 512, 512, -1};
+const int kVggCfgLen = sizeof(kVggCfg) / sizeof(int);
+constexpr int kMelLd = 1040;      // 1025 rFFT bins padded to a multiple of 16
+constexpr int kDftM = 2050;       // 1025 cos rows + 1025 sin rows
+constexpr int kDftLd = 2052;
+
+struct HostW {
+    std::vector<float> v;
+    std::vector<int64_t> shape;
+};
+
+}  // namespace
+
+struct dmad_engine {
+    dmad_config cfg{};
+    int L = 0, LP = 0, NL = 0, maxB = 0, LPm = 0;
+    bool bf16 = true, wn_final = false, cls_final = false;
+    std::map<std::string, HostW> hw;
+    std::vector<void*> allocs;
+    int64_t bytes = 0;
+    int emb_t = -1;
+
+    // WaveNet small fp32 params
+    float *init_w = nullptr, *init_b = nullptr, *fc1w = nullptr, *fc1b = nullptr, *fc2w = nullptr, *fc2b = nullptr;
+    float *fctw = nullptr, *fctb = nullptr, *emb_table = nullptr, *emb2 = nullptr;
+    float *bf0 = nullptr, *wz = nullptr;
+    float bz = 0.f;
+    // bf16 path
+    bf16_t *w1p = nullptr, *w2p = nullptr, *wsp = nullptr, *wf0p = nullptr;
+    float *b1p = nullptr, *b2 = nullptr, *bskip_sum = nullptr;
+    bf16_t *hA = nullptr, *hB = nullptr, *gstore = nullptr;
+    // fp32 path
+    float *wdil = nullptr, *bdil = nullptr, *wrs = nullptr, *brs = nullptr, *wf0 = nullptr;
+    float *hA32 = nullptr, *hB32 = nullptr, *H32 = nullptr, *g32 = nullptr, *skip32 = nullptr;
+    // common work buffers
+    float *xt = nullptr, *eps = nullptr, *x0 = nullptr, *znoise = nullptr;
+    // classifier
+    float *dftA = nullptr, *fbA = nullptr, *mel_xp = nullptr, *dftD = nullptr, *melP = nullptr, *melM = nullptr, *spec = nullptr;
+    float *vconv1w = nullptr;
+    float* vconvw[16] = {nullptr};
+    float* vscale[16] = {nullptr};
+    float* vshift[16] = {nullptr};
+    float* vfcw[3] = {nullptr};
+    float* vfcb[3] = {nullptr};
+    float *act0 = nullptr, *act1 = nullptr, *logits = nullptr;
+
+    template <typename T>
+    int alloc(T** p, size_t n, bool zero = false) {
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, n * sizeof(T));
+        if (e != hipSuccess) return fail(DMAD_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+        if (zero) {
+            e = hipMemset(d, 0, n * sizeof(T));
+            if (e != hipSuccess) return fail(DMAD_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+        }
+        allocs.push_back(d);
+        bytes += (int64_t)(n * sizeof(T));
+        *p = (T*)d;
+        return 0;
+    }
+    template <typename T>
+    int upload(T** p, const std::vector<T>& h) {
+        CHK(alloc(p, h.size()));
+        HIPCHK(hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+        return 0;
+    }
+    int upload_bf(bf16_t** p, const std::vector<uint16_t>& h) {
+        CHK(alloc(p, h.size()));
+        HIPCHK(hipMemcpy(*p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        return 0;
+    }
+    const HostW* get(const std::string& name, std::initializer_list<int64_t> shape) {
+        auto it = hw.find(name);
+        if (it == hw.end()) {
+            fail(DMAD_ERR_STATE, "weight '%s' was not loaded", name.c_str());
+            return nullptr;
+        }
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        if ((int64_t)it->second.v.size() != n) {
+            fail(DMAD_ERR_INVALID, "weight '%s' has %zu elements, expected %lld", name.c_str(), it->second.v.size(), (long long)n);
+            return nullptr;
+        }
+        return &it->second;
+    }
+};
+
+namespace {
+
+// [ksteps][rows][32] bf16 LDS image of W[row][K] (row-major, K = ksteps*32), 64-B rows, swz64 chunks
+void pack_rows(const float* W, int rows, int K, long ldw, const int* row_map, std::vector<uint16_t>& out, size_t base) {
+    const int ksteps = K / 32;
+    for (int ks = 0; ks < ksteps; ++ks)
+        for (int R = 0; R < rows; ++R) {
+            const float* src = W + (long)(row_map ? row_map[R] : R) * ldw + ks * 32;
+            for (int slot = 0; slot < 4; ++slot) {
+                const int c = slot ^ swz64(R);
+                for (int j = 0; j < 8; ++j) out[base + ((size_t)(ks * rows + R) * 32) + slot * 8 + j] = f2bf(src[c * 8 + j]);
+            }
+        }
+}
+
+int finalize_wavenet(dmad_engine* e) {
+    const int NL = e->NL;
+    const HostW* w;
+#define GETW(var, name, ...)                     \
+    w = e->get(name, {__VA_ARGS__});             \
+    if (!w) return DMAD_ERR_STATE;               \
+    const std::vector<float>& var = w->v;
+    GETW(init_w, "init.w", 256) GETW(init_b, "init.b", 256)
+    GETW(fc1w, "fc_t1.w", 512, 128) GETW(fc1b, "fc_t1.b", 512)
+    GETW(fc2w, "fc_t2.w", 512, 512) GETW(fc2b, "fc_t2.b", 512)
+    GETW(f0w, "f0.w", 256, 256) GETW(f0b, "f0.b", 256)
+    GETW(f2w, "f2.w", 256) GETW(f2b, "f2.b", 1)
+    CHK(e->upload(&e->init_w, init_w)); CHK(e->upload(&e->init_b, init_b));
+    CHK(e->upload(&e->fc1w, fc1w)); CHK(e->upload(&e->fc1b, fc1b));
+    CHK(e->upload(&e->fc2w, fc2w)); CHK(e->upload(&e->fc2b, fc2b));
+    CHK(e->upload(&e->bf0, f0b)); CHK(e->upload(&e->wz, f2w));
+    e->bz = f2b[0];
+    std::vector<float> fctw((size_t)NL * 256 * 512), fctb((size_t)NL * 256);
+    for (int n = 0; n < NL; ++n) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "fc_t.%d.w", n);
+        GETW(a, nm, 256, 512)
+        memcpy(&fctw[(size_t)n * 256 * 512], a.data(), a.size() * 4);
+        snprintf(nm, sizeof nm, "fc_t.%d.b", n);
+        GETW(bb, nm, 256)
+        memcpy(&fctb[(size_t)n * 256], bb.data(), 1024);
+    }
+    CHK(e->upload(&e->fctw, fctw)); CHK(e->upload(&e->fctb, fctb));
+    CHK(e->alloc(&e->emb_table, (size_t)NL * 256)); CHK(e->alloc(&e->emb2, 512));
+
+    if (e->bf16) {
+        int rmap[512];
+        for (int R = 0; R < 512; ++R) rmap[R] = ((R % 128) / 64) * 256 + (R / 128) * 64 + (R % 64);
+        std::vector<uint16_t> w1p((size_t)NL * 24 * 512 * 32), w2p((size_t)NL * 8 * 256 * 32), wsp((size_t)NL * 8 * 256 * 32),
+            wf0p((size_t)8 * 256 * 32);
+        std::vector<float> b1p((size_t)NL * 512), b2((size_t)NL * 256), bsum(256, 0.f), tapw((size_t)512 * 256);
+        for (int n = 0; n < NL; ++n) {
+            char nm[64];
+            snprintf(nm, sizeof nm, "dil.%d.w", n); GETW(dw, nm, 512, 256, 3)
+            snprintf(nm, sizeof nm, "dil.%d.b", n); GETW(db, nm, 512)
+            snprintf(nm, sizeof nm, "res.%d.w", n); GETW(rw, nm, 256, 256)
+            snprintf(nm, sizeof nm, "res.%d.b", n); GETW(rb, nm, 256)
+            snprintf(nm, sizeof nm, "skip.%d.w", n); GETW(sw, nm, 256, 256)
+            snprintf(nm, sizeof nm, "skip.%d.b", n); GETW(sb, nm, 256)
+            for (int tap = 0; tap < 3; ++tap) {
+                for (int oc = 0; oc < 512; ++oc)
+                    for (int ci = 0; ci < 256; ++ci) tapw[(size_t)oc * 256 + ci] = dw[((size_t)oc * 256 + ci) * 3 + tap];
+                pack_rows(tapw.data(), 512, 256, 256, rmap, w1p, ((size_t)n * 24 + tap * 8) * 512 * 32);
+            }
+            for (int R = 0; R < 512; ++R) b1p[(size_t)n * 512 + R] = db[rmap[R]];
+            pack_rows(rw.data(), 256, 256, 256, nullptr, w2p, (size_t)n * 8 * 256 * 32);
+            pack_rows(sw.data(), 256, 256, 256, nullptr, wsp, (size_t)n * 8 * 256 * 32);
+            for (int c = 0; c < 256; ++c) { b2[(size_t)n * 256 + c] = rb[c]; bsum[c] += sb[c]; }
+        }
+        pack_rows(f0w.data(), 256, 256, 256, nullptr, wf0p, 0);
+        CHK(e->upload_bf(&e->w1p, w1p)); CHK(e->upload_bf(&e->w2p, w2p)); CHK(e->upload_bf(&e->wsp, wsp));
+        CHK(e->upload_bf(&e->wf0p, wf0p));
+        CHK(e->upload(&e->b1p, b1p)); CHK(e->upload(&e->b2, b2)); CHK(e->upload(&e->bskip_sum, bsum));
+    } else {
+        std::vector<float> wdil((size_t)NL * 3 * 512 * 256), bdil((size_t)NL * 512), wrs((size_t)NL * 512 * 256), brs((size_t)NL * 512);
+        for (int n = 0; n < NL; ++n) {
+            char nm[64];
+            snprintf(nm, sizeof nm, "dil.%d.w", n); GETW(dw, nm, 512, 256, 3)
+            snprintf(nm, sizeof nm, "dil.%d.b", n); GETW(db, nm, 512)
+            snprintf(nm, sizeof nm, "res.%d.w", n); GETW(rw, nm, 256, 256)
+            snprintf(nm, sizeof nm, "res.%d.b", n); GETW(rb, nm, 256)
+            snprintf(nm, sizeof nm, "skip.%d.w", n); GETW(sw, nm, 256, 256)
+            snprintf(nm, sizeof nm, "skip.%d.b", n); GETW(sb, nm, 256)
+            for (int tap = 0; tap < 3; ++tap)
+                for (int oc = 0; oc < 512; ++oc)
+                    for (int ci = 0; ci < 256; ++ci)
+                        wdil[(((size_t)n * 3 + tap) * 512 + oc) * 256 + ci] = dw[((size_t)oc * 256 + ci) * 3 + tap];
+            memcpy(&bdil[(size_t)n * 512], db.data(), 2048);
+            memcpy(&wrs[(size_t)n * 512 * 256], rw.data(), 256 * 256 * 4);
+            memcpy(&wrs[(size_t)n * 512 * 256 + 256 * 256], sw.data(), 256 * 256 * 4);
+            memcpy(&brs[(size_t)n * 512], rb.data(), 1024);
+            memcpy(&brs[(size_t)n * 512 + 256], sb.data(), 1024);
+        }
+        CHK(e->upload(&e->wdil, wdil)); CHK(e->upload(&e->bdil, bdil)); CHK(e->upload(&e->wrs, wrs)); CHK(e->upload(&e->brs, brs));
+        CHK(e->upload(&e->wf0, f0w));
+    }
+    return 0;
+}
+
+int init_mel_constants(dmad_engine* e) {
+    // mel constants, float64 on the host then rounded once (torchaudio MelSpectrogram semantics)
+    {
+        std::vector<float> A((size_t)kDftM * 2048);
+        std::vector<double> win(2048);
+        for (int n = 0; n < 2048; ++n) win[n] = 0.5 - 0.5 * cos(2.0 * M_PI * n / 2048.0);
+        for (int f = 0; f < 1025; ++f)
+            for (int n = 0; n < 2048; ++n) {
+                const long ph = ((long)f * n) % 2048;                 // exact argument reduction
+                const double ang = 2.0 * M_PI * (double)ph / 2048.0;
+                A[(size_t)f * 2048 + n] = (float)(win[n] * cos(ang));
+                A[(size_t)(1025 + f) * 2048 + n] = (float)(-win[n] * sin(ang));
+            }
+        CHK(e->upload(&e->dftA, A));
+        // slaney mel filterbank, [32][kMelLd]
+        auto hz2mel = [](double f) { return f >= 1000.0 ? 15.0 + log(f / 1000.0) / (log(6.4) / 27.0) : f / (200.0 / 3); };
+        auto mel2hz = [](double m) { return m >= 15.0 ? 1000.0 * exp((log(6.4) / 27.0) * (m - 15.0)) : (200.0 / 3) * m; };
+        double fpts[34];
+        const double m0 = hz2mel(0.0), m1 = hz2mel(8000.0);
+        for (int i = 0; i < 34; ++i) fpts[i] = mel2hz(m0 + (m1 - m0) * i / 33.0);
+        std::vector<float> fb((size_t)32 * kMelLd, 0.f);
+        for (int m = 0; m < 32; ++m) {
+            const double enorm = 2.0 / (fpts[m + 2] - fpts[m]);
+            for (int f = 0; f < 1025; ++f) {
+                const double fr = 8000.0 * f / 1024.0;
+                const double down = (fr - fpts[m]) / (fpts[m + 1] - fpts[m]);
+                const double up = (fpts[m + 2] - fr) / (fpts[m + 2] - fpts[m + 1]);
+                const double v = fmax(0.0, fmin(down, up));
+                fb[(size_t)m * kMelLd + f] = (float)(v * enorm);
+            }
+        }
+        CHK(e->upload(&e->fbA, fb));
+    }
+    return 0;
+}
+
+int finalize_classifier(dmad_engine* e) {
+    const HostW* w;
+    // VGG19_bn
+    int cin = 1, li = 0;
+    for (int i = 0; i < kVggCfgLen; ++i) {
+        const int v = kVggCfg[i];
+        if (v < 0) continue;
+        char nm[64];
+        snprintf(nm, sizeof nm, "vgg.conv%d.w", li);
+        w = e->get(nm, {v, cin, 3, 3});
+        if (!w) return DMAD_ERR_STATE;
+        const std::vector<float>& cw = w->v;
+        if (li == 0) {
+            CHK(e->upload(&e->vconv1w, cw));
+        } else {
+            std::vector<float> A((size_t)9 * v * cin);
+            for (int co = 0; co < v; ++co)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int t = 0; t < 9; ++t) A[((size_t)t * v + co) * cin + ci] = cw[((size_t)co * cin + ci) * 9 + t];
+            CHK(e->upload(&e->vconvw[li], A));
+        }
+        snprintf(nm, sizeof nm, "vgg.conv%d.scale", li);
+        w = e->get(nm, {v}); if (!w) return DMAD_ERR_STATE;
+        CHK(e->upload(&e->vscale[li], w->v));
+        snprintf(nm, sizeof nm, "vgg.conv%d.shift", li);
+        w = e->get(nm, {v}); if (!w) return DMAD_ERR_STATE;
+        CHK(e->upload(&e->vshift[li], w->v));
+        cin = v;
+        ++li;
+    }
+    const int fin[3] = {512, 4096, 4096}, fout[3] = {4096, 4096, e->cfg.num_classes};
+    for (int j = 0; j < 3; ++j) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "vgg.fc%d.w", j);
+        w = e->get(nm, {fout[j], fin[j]}); if (!w) return DMAD_ERR_STATE;
+        CHK(e->upload(&e->vfcw[j], w->v));
+        snprintf(nm, sizeof nm, "vgg.fc%d.b", j);
+        w = e->get(nm, {fout[j]}); if (!w) return DMAD_ERR_STATE;
+        CHK(e->upload(&e->vfcb[j], w->v));
+    }
+    return 0;
+}
+
+int ensure_embed(dmad_engine* e, int t, hipStream_t s) {
+    if (e->emb_t == t) return 0;
+    launch_embed_table((float)t, e->fc1w, e->fc1b, e->fc2w, e->fc2b, e->fctw, e->fctb, e->emb_table, e->emb2, e->NL, s);
+    e->emb_t = t;
+    return 0;
+}
+
+GemmF32Args plain_gemm(const float* A, const float* X, float* C, const float* scale, const float* shift, int M, int K, long N,
+                       int ldc, long ldx, int relu) {
+    GemmF32Args g{};
+    g.A = A; g.X = X; g.C = C; g.scale = scale; g.shift = shift;
+    g.M = M; g.K = K; g.taps = 1; g.ldc = ldc; g.relu = relu; g.N = N; g.mode = 0;
+    g.rows_per_batch = N > 0 ? N : 1; g.batch_stride = 0; g.row_stride = ldx; g.tap_stride = 0;
+    return g;
+}
+
+int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipStream_t s) {
+    if (!e->wn_final) return fail(DMAD_ERR_STATE, "WaveNet weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
+    if (B < 1 || B > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d]", B, e->maxB);
+    if (t < 0) return fail(DMAD_ERR_INVALID, "diffusion step %d < 0", t);
+    CHK(ensure_embed(e, t, s));
+    const int L = e->L, LP = e->LP, NL = e->NL;
+    if (e->bf16) {
+        launch_wn_init_bf16(x_t, e->init_w, e->init_b, e->emb_table, e->hA, B, L, LP, s);
+        for (int n = 0; n < NL; ++n) {
+            WnLayerArgs a{};
+            a.hin = (n & 1) ? e->hB : e->hA;
+            a.hout = (n & 1) ? e->hA : e->hB;
+            a.gout = e->gstore + (size_t)n * B * L * kC;
+            a.w1p = e->w1p + (size_t)n * 24 * 512 * 32;
+            a.w2p = e->w2p + (size_t)n * 8 * 256 * 32;
+            a.b1 = e->b1p + (size_t)n * 512;
+            a.b2 = e->b2 + (size_t)n * 256;
+            a.emb_next = e->emb_table + (size_t)((n + 1 < NL) ? n + 1 : n) * 256;
+            a.dilation = 1 << (n % e->cfg.dilation_cycle);
+            a.L = L; a.LP = LP; a.last = (n == NL - 1);
+            launch_wn_layer_bf16(a, B, s);
+        }
+        WnFinalArgs f{};
+        f.g = e->gstore; f.wsp = e->wsp; f.wf0p = e->wf0p; f.bskip_sum = e->bskip_sum; f.bf0 = e->bf0; f.wz = e->wz;
+        f.eps = eps; f.bz = e->bz; f.skip_scale = (float)sqrt(1.0 / NL); f.NL = NL; f.B = B; f.L = L;
+        launch_wn_final_bf16(f, s);
+    } else {
+        const long N = (long)B * L;
+        launch_wn_init_f32(x_t, e->init_w, e->init_b, e->emb_table, e->hA32, B, L, LP, s);
+        for (int n = 0; n < NL; ++n) {
+            float* hin = (n & 1) ? e->hB32 : e->hA32;
+            float* hout = (n & 1) ? e->hA32 : e->hB32;
+            const int d = 1 << (n % e->cfg.dilation_cycle);
+            GemmF32Args g{};
+            g.A = e->wdil + (size_t)n * 3 * 512 * 256; g.X = hin + (size_t)kPad * kC; g.C = e->H32; g.scale = nullptr;
+            g.shift = e->bdil + (size_t)n * 512; g.M = 512; g.K = 256; g.taps = 3; g.ldc = 512; g.relu = 0; g.N = N; g.mode = 0;
+            g.rows_per_batch = L; g.batch_stride = (long)LP * kC; g.row_stride = kC; g.tap_stride = (long)d * kC;
+            launch_gemm_f32(g, s);
+            launch_wn_gate_f32(e->H32, e->g32, N, s);
+            launch_gemm_f32(plain_gemm(e->wrs + (size_t)n * 512 * 256, e->g32, e->H32, nullptr, e->brs + (size_t)n * 512, 512, 256,
+                                       N, 512, 256, 0), s);
+            launch_wn_update_f32(e->H32, hin, hout, e->skip32, e->emb_table + (size_t)((n + 1 < NL) ? n + 1 : n) * 256, n == 0,
+                                 n == NL - 1, B, L, LP, s);
+        }
+        launch_scale(e->skip32, (float)sqrt(1.0 / NL), e->g32, N * 256, s);
+        launch_gemm_f32(plain_gemm(e->wf0, e->g32, e->H32, nullptr, e->bf0, 256, 256, N, 256, 256, 1), s);
+        launch_dot256(e->H32, e->wz, e->bz, eps, N, s);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int mel_db(dmad_engine* e, const float* x, int B, float* spec, hipStream_t s) {
+    if (!e->cfg.with_classifier) return fail(DMAD_ERR_STATE, "engine was created with with_classifier = 0");
+    if (B < 1 || B > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d]", B, e->maxB);
+    const long rows = (long)B * 32;
+    launch_mel_pad(x, e->mel_xp, B, e->L, e->LPm, s);
+    GemmF32Args g{};
+    g.A = e->dftA; g.X = e->mel_xp; g.C = e->dftD; g.scale = nullptr; g.shift = nullptr;
+    g.M = kDftM; g.K = 2048; g.taps = 1; g.ldc = kDftLd; g.relu = 0; g.N = rows; g.mode = 0;
+    g.rows_per_batch = 32; g.batch_stride = e->LPm; g.row_stride = 512; g.tap_stride = 0;
+    launch_gemm_f32(g, s);
+    launch_mel_power(e->dftD, e->melP, kDftLd, kMelLd, rows, s);
+    launch_gemm_f32(plain_gemm(e->fbA, e->melP, e->melM, nullptr, nullptr, 32, kMelLd, rows, 32, kMelLd, 0), s);
+    launch_mel_db(e->melM, spec, B, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int classify(dmad_engine* e, const float* spec, int B, float* logits, hipStream_t s) {
+    if (!e->cfg.with_classifier) return fail(DMAD_ERR_STATE, "engine was created with with_classifier = 0");
+    if (!e->cls_final) return fail(DMAD_ERR_STATE, "classifier weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
+    if (B < 1 || B > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d]", B, e->maxB);
+    float *cur = e->act0, *nxt = e->act1;
+    launch_vgg_conv1(spec, e->vconv1w, e->vscale[0], e->vshift[0], cur, B, s);
+    int H = 32, cin = 64, li = 1;
+    for (int i = 1; i < kVggCfgLen; ++i) {
+        const int v = kVggCfg[i];
+        if (v < 0) {
+            launch_maxpool2_nhwc(cur, nxt, B, H, H, cin, s);
+            H >>= 1;
+        } else {
+            GemmF32Args g{};
+            g.A = e->vconvw[li]; g.X = cur; g.C = nxt; g.scale = e->vscale[li]; g.shift = e->vshift[li];
+            g.M = v; g.K = cin; g.taps = 9; g.ldc = v; g.relu = 1; g.N = (long)B * H * H; g.mode = 2;
+            g.H = H; g.W = H; g.Cin = cin;
+            launch_gemm_f32(g, s);
+            cin = v;
+            ++li;
+        }
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    const int fin[3] = {512, 4096, 4096}, fout[3] = {4096, 4096, e->cfg.num_classes};
+    for (int j = 0; j < 3; ++j) {
+        float* dst = (j == 2) ? logits : nxt;
+        launch_gemm_f32(plain_gemm(e->vfcw[j], cur, dst, nullptr, e->vfcb[j], fout[j], fin[j], B, fout[j], fin[j], j < 2), s);
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dmad_last_error(void) { return g_err.c_str(); }
+const char* dmad_version(void) { return "dmad-hip 0.1 (gfx950)"; }
+
+int dmad_create(const dmad_config* cfg, dmad_engine** out) {
+    if (!cfg || !out) return fail(DMAD_ERR_INVALID, "null argument");
+    if (cfg->res_channels != 256 || cfg->skip_channels != 256)
+        return fail(DMAD_ERR_INVALID, "only res_channels = skip_channels = 256 is supported (got %d/%d)", cfg->res_channels, cfg->skip_channels);
+    if (cfg->embed_dim_in != 128 || cfg->embed_dim_mid != 512 || cfg->embed_dim_out != 512)
+        return fail(DMAD_ERR_INVALID, "only step-embedding dims 128/512/512 are supported");
+    if (cfg->num_res_layers < 1 || cfg->num_res_layers > 64) return fail(DMAD_ERR_INVALID, "num_res_layers %d outside [1,64]", cfg->num_res_layers);
+    if (cfg->dilation_cycle < 1 || cfg->dilation_cycle > 12) return fail(DMAD_ERR_INVALID, "dilation_cycle %d outside [1,12]", cfg->dilation_cycle);
+    if (cfg->clip_len < 128 || cfg->clip_len % 128) return fail(DMAD_ERR_INVALID, "clip_len %d must be a positive multiple of 128", cfg->clip_len);
+    if (cfg->with_classifier && cfg->clip_len != 16000) return fail(DMAD_ERR_INVALID, "the mel front-end needs clip_len = 16000");
+    if (cfg->max_batch < 1) return fail(DMAD_ERR_INVALID, "max_batch must be >= 1");
+    if (cfg->precision != DMAD_BF16 && cfg->precision != DMAD_FP32) return fail(DMAD_ERR_INVALID, "unknown precision %d", cfg->precision);
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(DMAD_ERR_HIP, "no HIP device visible");
+    dmad_engine* e = new dmad_engine();
+    e->cfg = *cfg;
+    e->L = cfg->clip_len; e->LP = cfg->clip_len + 2 * kPad; e->NL = cfg->num_res_layers; e->maxB = cfg->max_batch;
+    e->LPm = cfg->clip_len + 2048;
+    e->bf16 = cfg->precision == DMAD_BF16;
+    const size_t B = e->maxB, L = e->L, LP = e->LP, NL = e->NL;
+    int r = 0;
+    do {
+        if ((r = e->alloc(&e->xt, B * L))) break;
+        if ((r = e->alloc(&e->eps, B * L))) break;
+        if ((r = e->alloc(&e->x0, B * L))) break;
+        if ((r = e->alloc(&e->znoise, B * L))) break;
+        if (e->bf16) {
+            if ((r = e->alloc(&e->hA, B * LP * kC, true))) break;
+            if ((r = e->alloc(&e->hB, B * LP * kC, true))) break;
+            if ((r = e->alloc(&e->gstore, NL * B * L * kC))) break;
+            if ((r = wn_bf16_configure())) { r = fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %d", r); break; }
+        } else {
+            if ((r = e->alloc(&e->hA32, B * LP * kC, true))) break;
+            if ((r = e->alloc(&e->hB32, B * LP * kC, true))) break;
+            if ((r = e->alloc(&e->H32, B * L * 512))) break;
+            if ((r = e->alloc(&e->g32, B * L * 256))) break;
+            if ((r = e->alloc(&e->skip32, B * L * 256))) break;
+        }
+        if (cfg->with_classifier) {
+            if ((r = e->alloc(&e->mel_xp, B * e->LPm))) break;
+            if ((r = e->alloc(&e->dftD, B * 32 * kDftLd))) break;
+            if ((r = e->alloc(&e->melP, B * 32 * kMelLd))) break;
+            if ((r = e->alloc(&e->melM, B * 32 * 32))) break;
+            if ((r = e->alloc(&e->spec, B * 1024))) break;
+            if ((r = e->alloc(&e->act0, B * 1024 * 64))) break;
+            if ((r = e->alloc(&e->act1, B * 1024 * 64))) break;
+            if ((r = e->alloc(&e->logits, B * cfg->num_classes))) break;
+            if ((r = init_mel_constants(e))) break;
+        }
+    } while (0);
+    if (r) { dmad_destroy(e); return r; }
+    *out = e;
+    return 0;
+}
+
+void dmad_destroy(dmad_engine* e) {
+    if (!e) return;
+    for (void* p : e->allocs) (void)hipFree(p);
+    delete e;
+}
+
+int64_t dmad_device_bytes(const dmad_engine* e) { return e ? e->bytes : 0; }
+
+int dmad_load_weight(dmad_engine* e, const char* name, const float* host, const int64_t* shape, int32_t ndim) {
+    if (!e || !name || !host || !shape || ndim < 1 || ndim > 4) return fail(DMAD_ERR_INVALID, "bad argument to dmad_load_weight");
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 1) return fail(DMAD_ERR_INVALID, "weight '%s': non-positive dimension", name);
+        n *= shape[i];
+    }
+    HostW& h = e->hw[name];
+    h.v.assign(host, host + n);
+    h.shape.assign(shape, shape + ndim);
+    return 0;
+}
+
+int dmad_finalize_weights(dmad_engine* e) {
+    if (!e) return fail(DMAD_ERR_INVALID, "null engine");
+    // finalises whichever part (WaveNet, classifier) has its weights loaded and is not packed yet
+    bool did = false;
+    if (!e->wn_final && e->hw.count("init.w")) {
+        CHK(finalize_wavenet(e));
+        e->wn_final = true; did = true;
+    }
+    if (e->cfg.with_classifier && !e->cls_final && e->hw.count("vgg.conv0.w")) {
+        CHK(finalize_classifier(e));
+        e->cls_final = true; did = true;
+    }
+    if (!did) return fail(DMAD_ERR_STATE, "nothing to finalise: no complete weight set was loaded");
+    e->hw.clear();
+    return 0;
+}
+
+int dmad_wavenet_eps(dmad_engine* e, const float* x_t, int32_t t, int32_t B, float* eps, dmad_stream s) {
+    if (!e || !x_t || !eps) return fail(DMAD_ERR_INVALID, "null argument");
+    return wavenet_eps(e, x_t, t, B, eps, (hipStream_t)s);
+}
+
+int dmad_one_shot(dmad_engine* e, const float* x_t, int32_t t, float c_a, float c_b, int32_t B, float* x0, dmad_stream s) {
+    if (!e || !x_t || !x0) return fail(DMAD_ERR_INVALID, "null argument");
+    CHK(wavenet_eps(e, x_t, t, B, e->eps, (hipStream_t)s));
+    launch_lincomb(0, x_t, e->eps, nullptr, c_a, c_b, 0.f, x0, (long)B * e->L, (hipStream_t)s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int dmad_ddpm_step(dmad_engine* e, float* x, int32_t t, float c_eps, float c_div, float c_sig, const float* z, uint64_t seed,
+                   uint64_t sample0, int32_t B, dmad_stream s) {
+    if (!e || !x) return fail(DMAD_ERR_INVALID, "null argument");
+    CHK(wavenet_eps(e, x, t, B, e->eps, (hipStream_t)s));
+    const float* zz = nullptr;
+    if (c_sig != 0.f) {
+        zz = z;
+        if (!zz) {
+            launch_philox_normal(seed, sample0, 1u + (uint32_t)t, e->znoise, B, e->L, (hipStream_t)s);
+            zz = e->znoise;
+        }
+    }
+    launch_lincomb(2, x, e->eps, zz, c_eps, c_div, c_sig, x, (long)B * e->L, (hipStream_t)s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int dmad_diffuse(dmad_engine* e, const float* x0, float c_a, float c_b, const float* z, uint64_t seed, uint64_t sample0,
+                 int32_t B, float* x_t, dmad_stream s) {
+    if (!e || !x0 || !x_t) return fail(DMAD_ERR_INVALID, "null argument");
+    if (B < 1 || B > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d]", B, e->maxB);
+    const float* zz = z;
+    if (!zz) {
+        launch_philox_normal(seed, sample0, 0xD1FFu, e->znoise, B, e->L, (hipStream_t)s);
+        zz = e->znoise;
+    }
+    launch_lincomb(1, x0, nullptr, zz, c_a, c_b, 0.f, x_t, (long)B * e->L, (hipStream_t)s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int dmad_mel_db(dmad_engine* e, const float* x, int32_t B, float* spec, dmad_stream s) {
+    if (!e || !x || !spec) return fail(DMAD_ERR_INVALID, "null argument");
+    return mel_db(e, x, B, spec, (hipStream_t)s);
+}
+
+int dmad_classify(dmad_engine* e, const float* spec, int32_t B, float* logits, dmad_stream s) {
+    if (!e || !spec || !logits) return fail(DMAD_ERR_INVALID, "null argument");
+    return classify(e, spec, B, logits, (hipStream_t)s);
+}
+
+int dmad_vote(dmad_engine* e, const float* logits, int32_t B, int64_t* counts, dmad_stream s) {
+    if (!e || !logits || !counts || B < 1) return fail(DMAD_ERR_INVALID, "bad argument to dmad_vote");
+    launch_vote(logits, B, e->cfg.num_classes, (unsigned long long*)counts, nullptr, (hipStream_t)s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt_alpha_bar_star, int32_t t, float c_a,
+                      float c_b, int64_t n, int32_t batch, uint64_t seed, uint64_t sample0, const float* delta, int64_t* counts,
+                      float* logits_out, float* x0_out, dmad_stream s) {
+    if (!e || !clip) return fail(DMAD_ERR_INVALID, "null argument");
+    if (n < 0 || batch < 1 || batch > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d] or n < 0", batch, e->maxB);
+    if (e->cfg.with_classifier && !counts) return fail(DMAD_ERR_INVALID, "counts must not be null");
+    hipStream_t st = (hipStream_t)s;
+    const int L = e->L, C = e->cfg.num_classes;
+    for (int64_t done = 0; done < n; done += batch) {
+        const int B = (int)((n - done < batch) ? (n - done) : batch);
+        launch_mc_noise_scale(clip, delta ? delta + done * L : nullptr, sigma, sqrt_alpha_bar_star, seed, sample0 + (uint64_t)done,
+                              e->xt, B, L, st);
+        CHK(wavenet_eps(e, e->xt, t, B, e->eps, st));
+        float* x0 = x0_out ? x0_out + done * L : e->x0;
+        launch_lincomb(0, e->xt, e->eps, nullptr, c_a, c_b, 0.f, x0, (long)B * L, st);
+        if (e->cfg.with_classifier) {
+            CHK(mel_db(e, x0, B, e->spec, st));
+            float* lg = logits_out ? logits_out + done * C : e->logits;
+            CHK(classify(e, e->spec, B, lg, st));
+            launch_vote(lg, B, C, (unsigned long long*)counts, nullptr, st);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int dmad_philox_raw(dmad_engine* e, uint64_t seed, uint64_t sample, uint32_t stream, uint32_t nblocks, uint32_t* out, dmad_stream s) {
+    if (!e || !out) return fail(DMAD_ERR_INVALID, "null argument");
+    launch_philox_raw(seed, sample, stream, nblocks, out, (hipStream_t)s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int dmad_philox_normal(dmad_engine* e, uint64_t seed, uint64_t sample0, uint32_t stream, int32_t B, float* z, dmad_stream s) {
+    if (!e || !z || B < 1) return fail(DMAD_ERR_INVALID, "bad argument");
+    launch_philox_normal(seed, sample0, stream, z, B, e->L, (hipStream_t)s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int dmad_time_layer(dmad_engine* e, int32_t layer, int32_t B, int32_t iters, float* ms_per_launch, dmad_stream s) {
+    if (!e || !ms_per_launch || iters < 1) return fail(DMAD_ERR_INVALID, "bad argument");
+    if (!e->wn_final || !e->bf16) return fail(DMAD_ERR_STATE, "dmad_time_layer needs a finalised bf16 engine");
+    if (B < 1 || B > e->maxB || layer < 0 || layer >= e->NL) return fail(DMAD_ERR_STATE, "bad batch or layer");
+    hipStream_t st = (hipStream_t)s;
+    WnLayerArgs a{};
+    a.hin = e->hA; a.hout = e->hB; a.gout = e->gstore + (size_t)layer * B * e->L * kC;
+    a.w1p = e->w1p + (size_t)layer * 24 * 512 * 32; a.w2p = e->w2p + (size_t)layer * 8 * 256 * 32;
+    a.b1 = e->b1p + (size_t)layer * 512; a.b2 = e->b2 + (size_t)layer * 256; a.emb_next = e->emb_table;
+    a.dilation = 1 << (layer % e->cfg.dilation_cycle); a.L = e->L; a.LP = e->LP; a.last = 0;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    launch_wn_layer_bf16(a, B, st);
+    HIPCHK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) launch_wn_layer_bf16(a, B, st);
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_per_launch = ms / iters;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+// Shared device/host definitions for the dmad HIP engine (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dmad {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// Geometry of the DiffWave eps-network this engine is specialised for
+// (reference configs/config.json:7-17; other sizes are rejected by dmad_create).
+constexpr int kC = 256;          // res_channels == skip_channels
+constexpr int kPad = 2048;       // zero rows on each side of a clip in the residual stream (max dilation)
+constexpr int kTileT = 128;      // time positions per workgroup tile
+
+// 16-byte-chunk swizzle for 64-byte LDS rows read as MFMA 16x16x32 operands with ds_read_b128
+// (conflict-free for the four 16-lane groups of ds_read_b128, see DESIGN.md "LDS images").
+__host__ __device__ inline int swz64(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }  // {0,2,3,1}[(row>>2)&3]
+
+__device__ inline void glds16(const void* gsrc, void* lds_dst_wave_base) {
+    // async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc, (lds_ptr_t)lds_dst_wave_base, 16, 0, 0);
+}
+
+__device__ inline float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ inline float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+}  // namespace dmad

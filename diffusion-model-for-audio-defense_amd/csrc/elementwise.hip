@@ -1,0 +1,394 @@
+// Small HBM-bound kernels of the path: noise + scale (Philox), step-embedding MLP, scheduler
+// updates, fp32-mode gate/update, mel post-processing, VGG helpers, arg-max votes.
+#include "elementwise.h"
+
+namespace dmad {
+
+// ----------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator (Salmon et al. 2011).  counter = (block, sample_lo,
+// sample_hi, stream), key = (seed_lo, seed_hi): sample i's noise is a pure function of
+// (seed, i, stream) -> Monte Carlo votes do not depend on batch size or on the number of ranks.
+// ----------------------------------------------------------------------------------------------
+__host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ inline void philox_normal4(uint64_t seed, uint64_t sample, uint32_t stream, uint32_t block, float z[4]) {
+    uint32_t c[4] = {block, (uint32_t)sample, (uint32_t)(sample >> 32), stream};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    // Box-Muller on (0,1) uniforms with 24 random bits each
+    const float u0 = ((float)(c[0] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    const float u1 = ((float)(c[1] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    const float u2 = ((float)(c[2] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    const float u3 = ((float)(c[3] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+    float s0, c0, s1, c1;
+    sincosf(6.283185307179586f * u1, &s0, &c0);
+    sincosf(6.283185307179586f * u3, &s1, &c1);
+    z[0] = r0 * c0; z[1] = r0 * s0; z[2] = r1 * c1; z[3] = r1 * s1;
+}
+
+__global__ void philox_raw_kernel(uint64_t seed, uint64_t sample, uint32_t stream, uint32_t nblocks, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblocks) return;
+    uint32_t c[4] = {i, (uint32_t)sample, (uint32_t)(sample >> 32), stream};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    out[4 * i + 0] = c[0]; out[4 * i + 1] = c[1]; out[4 * i + 2] = c[2]; out[4 * i + 3] = c[3];
+}
+
+// z[b][l] ~ N(0,1), sample index = sample0 + b
+__global__ void philox_normal_kernel(uint64_t seed, uint64_t sample0, uint32_t stream, float* z, int B, int L) {
+    const int per = L / 4;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * per) return;
+    const int b = (int)(i / per), blk = (int)(i - (long)b * per);
+    float v[4];
+    philox_normal4(seed, sample0 + b, stream, blk, v);
+    *(float4*)(z + (long)b * L + blk * 4) = float4{v[0], v[1], v[2], v[3]};
+}
+
+// certified_robust.py:46-54:  x_in = x.repeat(B) + delta ; x_in = alpha_bar_star**0.5 * x_in
+// delta = host noise [B][L] (parity mode) or sigma * Philox normal (fast mode)
+__global__ void mc_noise_scale_kernel(const float* __restrict__ clip, const float* __restrict__ delta, float sigma,
+                                      float scale, uint64_t seed, uint64_t sample0, float* __restrict__ xt, int B, int L) {
+    const int per = L / 4;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * per) return;
+    const int b = (int)(i / per), blk = (int)(i - (long)b * per);
+    const float4 x = *(const float4*)(clip + blk * 4);
+    float d[4];
+    if (delta) {
+        const float4 dv = *(const float4*)(delta + (long)b * L + blk * 4);
+        d[0] = dv.x; d[1] = dv.y; d[2] = dv.z; d[3] = dv.w;
+    } else {
+        philox_normal4(seed, sample0 + b, 0u, blk, d);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = __fmul_rn(sigma, d[j]);
+    }
+    float4 o;
+    o.x = __fmul_rn(scale, __fadd_rn(x.x, d[0])); o.y = __fmul_rn(scale, __fadd_rn(x.y, d[1]));
+    o.z = __fmul_rn(scale, __fadd_rn(x.z, d[2])); o.w = __fmul_rn(scale, __fadd_rn(x.w, d[3]));
+    *(float4*)(xt + (long)b * L + blk * 4) = o;
+}
+
+// ----------------------------------------------------------------------------------------------
+// diffusion-step embedding (util.py:68-93) -> fc_t1, fc_t2 with swish (WaveNet.py:124-126) ->
+// the 36 per-layer fc_t (WaveNet.py:82-83).  t is the same for every row of the batch in every
+// inference caller, so the result is a [NL][256] bias table.  One block per layer.
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) embed_table_kernel(float t, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          const float* __restrict__ w2, const float* __restrict__ b2,
+                                                          const float* __restrict__ wt, const float* __restrict__ bt,
+                                                          float* __restrict__ table, float* __restrict__ emb2_out) {
+    __shared__ float e0[128], e1[512], e2[512];
+    const int tid = threadIdx.x, n = blockIdx.x;
+    if (tid < 64) {
+        const float f = expf((float)tid * -0.14619587892025687f);     // -ln(10000)/63 (util.py:88-89)
+        const float v = t * f;
+        e0[tid] = sinf(v);
+        e0[64 + tid] = cosf(v);
+    }
+    __syncthreads();
+    {
+        float s = 0.f;
+        for (int k = 0; k < 128; ++k) s = fmaf(w1[tid * 128 + k], e0[k], s);
+        s += b1[tid];
+        e1[tid] = s / (1.f + expf(-s));
+    }
+    __syncthreads();
+    {
+        float s = 0.f;
+        for (int k = 0; k < 512; ++k) s = fmaf(w2[tid * 512 + k], e1[k], s);
+        s += b2[tid];
+        e2[tid] = s / (1.f + expf(-s));
+    }
+    __syncthreads();
+    if (n == 0 && emb2_out) emb2_out[tid] = e2[tid];
+    if (tid < 256) {
+        const float* w = wt + ((long)n * 256 + tid) * 512;
+        float s = 0.f;
+        for (int k = 0; k < 512; ++k) s = fmaf(w[k], e2[k], s);
+        table[n * 256 + tid] = s + bt[n * 256 + tid];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// scheduler updates (diffwave_ddpm.py); op order as in the reference, no FMA contraction
+// ----------------------------------------------------------------------------------------------
+__global__ void lincomb_kernel(int op, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                               float c0, float c1, float c2, float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    switch (op) {
+        case 0:  // one-shot x0 (l.199-203): c0 * x_t - c1 * eps
+            r = __fsub_rn(__fmul_rn(c0, x[i]), __fmul_rn(c1, y[i])); break;
+        case 1:  // diffusion (l.66-67): c0 * x0 + c1 * z
+            r = __fadd_rn(__fmul_rn(c0, x[i]), __fmul_rn(c1, z[i])); break;
+        case 2:  // reverse step (l.159-160,100): mu = (x - c0 * eps) / c1 ; x = mu + c2 * z
+            r = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(c0, y[i])), c1);
+            if (z) r = __fadd_rn(r, __fmul_rn(c2, z[i]));
+            break;
+        default: r = 0.f;
+    }
+    out[i] = r;
+}
+
+// ----------------------------------------------------------------------------------------------
+// fp32 (parity) WaveNet helpers
+// ----------------------------------------------------------------------------------------------
+__global__ void wn_init_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                   const float* __restrict__ emb0, float* __restrict__ h, int L, int LP, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 (4 channels) each
+    if (idx >= total) return;
+    const int c4 = (int)(idx & 63);
+    const long pos = idx >> 6, bb = pos / L, t = pos - bb * L;
+    const float xv = x[pos];
+    float4 o;
+    float* po = &o.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c4 * 4 + j;
+        po[j] = __fadd_rn(fmaxf(__fadd_rn(__fmul_rn(w[c], xv), bias[c]), 0.f), emb0[c]);
+    }
+    *(float4*)(h + ((bb * LP + kPad + t) * kC + c4 * 4)) = o;
+}
+
+// g = tanh(H[:, :256]) * sigmoid(H[:, 256:])   (WaveNet.py:89), H is [N][512]
+__global__ void wn_gate_f32_kernel(const float* __restrict__ H, float* __restrict__ g, long total4) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total4) return;
+    const long n = idx >> 6;
+    const int c4 = (int)(idx & 63);
+    const float4 a = *(const float4*)(H + n * 512 + c4 * 4);
+    const float4 b = *(const float4*)(H + n * 512 + 256 + c4 * 4);
+    float4 o;
+    o.x = tanhf(a.x) * (1.f / (1.f + expf(-b.x))); o.y = tanhf(a.y) * (1.f / (1.f + expf(-b.y)));
+    o.z = tanhf(a.z) * (1.f / (1.f + expf(-b.z))); o.w = tanhf(a.w) * (1.f / (1.f + expf(-b.w)));
+    *(float4*)(g + n * 256 + c4 * 4) = o;
+}
+
+// h' = (h + RS[:, :256]) * sqrt(.5) + emb_next ; skip (+)= RS[:, 256:]     (WaveNet.py:97,131-133)
+__global__ void wn_update_f32_kernel(const float* __restrict__ RS, const float* __restrict__ hin, float* __restrict__ hout,
+                                     float* __restrict__ skip, const float* __restrict__ emb_next, int first, int last,
+                                     int L, int LP, long total4) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total4) return;
+    const long n = idx >> 6, bb = n / L, t = n - bb * L;
+    const int c4 = (int)(idx & 63);
+    const float4 s = *(const float4*)(RS + n * 512 + 256 + c4 * 4);
+    float4* ps = (float4*)(skip + n * 256 + c4 * 4);
+    if (first) {
+        *ps = s;
+    } else {
+        float4 o = *ps;
+        o.x = __fadd_rn(o.x, s.x); o.y = __fadd_rn(o.y, s.y); o.z = __fadd_rn(o.z, s.z); o.w = __fadd_rn(o.w, s.w);
+        *ps = o;
+    }
+    if (last) return;
+    const long hoff = (bb * LP + kPad + t) * kC + c4 * 4;
+    const float4 r = *(const float4*)(RS + n * 512 + c4 * 4);
+    const float4 h = *(const float4*)(hin + hoff);
+    const float4 e = *(const float4*)(emb_next + c4 * 4);
+    const float k = 0.70710678118654752440f;
+    float4 o;
+    o.x = __fadd_rn(__fmul_rn(__fadd_rn(h.x, r.x), k), e.x); o.y = __fadd_rn(__fmul_rn(__fadd_rn(h.y, r.y), k), e.y);
+    o.z = __fadd_rn(__fmul_rn(__fadd_rn(h.z, r.z), k), e.z); o.w = __fadd_rn(__fmul_rn(__fadd_rn(h.w, r.w), k), e.w);
+    *(float4*)(hout + hoff) = o;
+}
+
+__global__ void scale_kernel(const float* __restrict__ x, float c, float* __restrict__ y, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = ((const float4*)x)[i];
+    v.x = __fmul_rn(v.x, c); v.y = __fmul_rn(v.y, c); v.z = __fmul_rn(v.z, c); v.w = __fmul_rn(v.w, c);
+    ((float4*)y)[i] = v;
+}
+
+// eps[n] = w . f[n][:256] + b  (final_conv.2, WaveNet.py:160-162): one wave per position
+__global__ void __launch_bounds__(256) dot256_kernel(const float* __restrict__ f, const float* __restrict__ w, float bias,
+                                                     float* __restrict__ out, long N) {
+    const long n = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const float4 v = *(const float4*)(f + n * 256 + lane * 4);
+    const float4 ww = *(const float4*)(w + lane * 4);
+    float s = v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[n] = s + bias;
+}
+
+// ----------------------------------------------------------------------------------------------
+// mel front-end post-processing (torchaudio MelSpectrogram power=2 + AmplitudeToDB 'power')
+// ----------------------------------------------------------------------------------------------
+// xp[b][0:1024] = 0, xp[b][1024:1024+L] = x[b], xp[b][1024+L:] = 0       (center=True, constant pad)
+__global__ void mel_pad_kernel(const float* __restrict__ x, float* __restrict__ xp, int L, int LPm, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / LPm;
+    const int p = (int)(i - b * LPm) - 1024;
+    xp[i] = (p >= 0 && p < L) ? x[b * L + p] : 0.f;
+}
+
+// P[n][f] = re^2 + im^2, f < 1025 ; zero for the K padding up to ldp.  D is [n][ldd]: re at f, im at 1025 + f
+__global__ void mel_power_kernel(const float* __restrict__ D, float* __restrict__ P, int ldd, int ldp, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long n = i / ldp;
+    const int f = (int)(i - n * ldp);
+    float v = 0.f;
+    if (f < 1025) {
+        const float re = D[n * ldd + f], im = D[n * ldd + 1025 + f];
+        v = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+    }
+    P[i] = v;
+}
+
+// spec[b][mel][frame] = 10 * log10(max(M[b*32 + frame][mel], 1e-10))
+__global__ void mel_db_kernel(const float* __restrict__ M, float* __restrict__ spec, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long b = i >> 10;
+    const int mel = (int)((i >> 5) & 31), fr = (int)(i & 31);
+    const float v = fmaxf(M[(b * 32 + fr) * 32 + mel], 1e-10f);
+    spec[i] = 10.f * log10f(v);
+}
+
+// ----------------------------------------------------------------------------------------------
+// VGG helpers
+// ----------------------------------------------------------------------------------------------
+// first conv (Cin = 1) + folded BN + relu: in [B][32][32] -> out NHWC [B][32][32][64]
+__global__ void vgg_conv1_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, float* __restrict__ out, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one (b, y, x, co) each
+    if (i >= total) return;
+    const int co = (int)(i & 63);
+    const long p = i >> 6, b = p >> 10;
+    const int y = (int)((p >> 5) & 31), x = (int)(p & 31);
+    float s = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            if ((unsigned)yy < 32u && (unsigned)xx < 32u) s = fmaf(w[co * 9 + ky * 3 + kx], in[(b << 10) + yy * 32 + xx], s);
+        }
+    out[i] = fmaxf(s * scale[co] + shift[co], 0.f);
+}
+
+// 2x2 max pool, NHWC
+__global__ void maxpool2_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, long total4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 of output
+    if (i >= total4) return;
+    const int c4n = C >> 2, Ho = H >> 1, Wo = W >> 1;
+    const int c4 = (int)(i % c4n);
+    long p = i / c4n;
+    const int xo = (int)(p % Wo); p /= Wo;
+    const int yo = (int)(p % Ho);
+    const long b = p / Ho;
+    const float* s = in + (((b * H + 2 * yo) * W + 2 * xo) * (long)C) + c4 * 4;
+    const float4 a = *(const float4*)s, bq = *(const float4*)(s + C), c = *(const float4*)(s + (long)W * C),
+                 d = *(const float4*)(s + (long)W * C + C);
+    float4 o;
+    o.x = fmaxf(fmaxf(a.x, bq.x), fmaxf(c.x, d.x)); o.y = fmaxf(fmaxf(a.y, bq.y), fmaxf(c.y, d.y));
+    o.z = fmaxf(fmaxf(a.z, bq.z), fmaxf(c.z, d.z)); o.w = fmaxf(fmaxf(a.w, bq.w), fmaxf(c.w, d.w));
+    ((float4*)out)[i] = o;
+}
+
+// ----------------------------------------------------------------------------------------------
+// votes: arg-max (first maximum wins, like torch.max) + per-class count (certified_robust.py:59-65)
+// ----------------------------------------------------------------------------------------------
+__global__ void vote_kernel(const float* __restrict__ logits, int B, int C, unsigned long long* __restrict__ counts,
+                            int* __restrict__ pred_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int best = 0;
+    float bv = logits[(long)b * C];
+    for (int c = 1; c < C; ++c) {
+        const float v = logits[(long)b * C + c];
+        if (v > bv || (v != v && bv == bv)) { bv = v; best = c; }
+    }
+    if (pred_out) pred_out[b] = best;
+    atomicAdd(&counts[best], 1ull);
+}
+
+// ---------------------------------------------------------------------------------------------- launchers
+static inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+void launch_philox_raw(uint64_t seed, uint64_t sample, uint32_t stream, uint32_t nblocks, uint32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(philox_raw_kernel, dim3(nblk(nblocks, 256)), dim3(256), 0, s, seed, sample, stream, nblocks, out);
+}
+void launch_philox_normal(uint64_t seed, uint64_t sample0, uint32_t stream, float* z, int B, int L, hipStream_t s) {
+    hipLaunchKernelGGL(philox_normal_kernel, dim3(nblk((long)B * (L / 4), 256)), dim3(256), 0, s, seed, sample0, stream, z, B, L);
+}
+void launch_mc_noise_scale(const float* clip, const float* delta, float sigma, float scale, uint64_t seed, uint64_t sample0,
+                           float* xt, int B, int L, hipStream_t s) {
+    hipLaunchKernelGGL(mc_noise_scale_kernel, dim3(nblk((long)B * (L / 4), 256)), dim3(256), 0, s, clip, delta, sigma, scale,
+                       seed, sample0, xt, B, L);
+}
+void launch_embed_table(float t, const float* w1, const float* b1, const float* w2, const float* b2, const float* wt,
+                        const float* bt, float* table, float* emb2_out, int NL, hipStream_t s) {
+    hipLaunchKernelGGL(embed_table_kernel, dim3(NL), dim3(512), 0, s, t, w1, b1, w2, b2, wt, bt, table, emb2_out);
+}
+void launch_lincomb(int op, const float* x, const float* y, const float* z, float c0, float c1, float c2, float* out, long n,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(lincomb_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, op, x, y, z, c0, c1, c2, out, n);
+}
+void launch_wn_init_f32(const float* x, const float* w, const float* bias, const float* emb0, float* h, int B, int L, int LP,
+                        hipStream_t s) {
+    const long total = (long)B * L * 64;
+    hipLaunchKernelGGL(wn_init_f32_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, x, w, bias, emb0, h, L, LP, total);
+}
+void launch_wn_gate_f32(const float* H, float* g, long N, hipStream_t s) {
+    hipLaunchKernelGGL(wn_gate_f32_kernel, dim3(nblk(N * 64, 256)), dim3(256), 0, s, H, g, N * 64);
+}
+void launch_wn_update_f32(const float* RS, const float* hin, float* hout, float* skip, const float* emb_next, int first,
+                          int last, int B, int L, int LP, hipStream_t s) {
+    const long total = (long)B * L * 64;
+    hipLaunchKernelGGL(wn_update_f32_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, RS, hin, hout, skip, emb_next, first, last,
+                       L, LP, total);
+}
+void launch_scale(const float* x, float c, float* y, long n, hipStream_t s) {
+    hipLaunchKernelGGL(scale_kernel, dim3(nblk(n / 4, 256)), dim3(256), 0, s, x, c, y, n / 4);
+}
+void launch_dot256(const float* f, const float* w, float bias, float* out, long N, hipStream_t s) {
+    hipLaunchKernelGGL(dot256_kernel, dim3(nblk(N, 4)), dim3(256), 0, s, f, w, bias, out, N);
+}
+void launch_mel_pad(const float* x, float* xp, int B, int L, int LPm, hipStream_t s) {
+    const long total = (long)B * LPm;
+    hipLaunchKernelGGL(mel_pad_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, x, xp, L, LPm, total);
+}
+void launch_mel_power(const float* D, float* P, int ldd, int ldp, long rows, hipStream_t s) {
+    const long total = rows * ldp;
+    hipLaunchKernelGGL(mel_power_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, D, P, ldd, ldp, total);
+}
+void launch_mel_db(const float* M, float* spec, int B, hipStream_t s) {
+    const long total = (long)B * 1024;
+    hipLaunchKernelGGL(mel_db_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, M, spec, total);
+}
+void launch_vgg_conv1(const float* in, const float* w, const float* scale, const float* shift, float* out, int B, hipStream_t s) {
+    const long total = (long)B * 1024 * 64;
+    hipLaunchKernelGGL(vgg_conv1_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, in, w, scale, shift, out, total);
+}
+void launch_maxpool2_nhwc(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
+    const long total4 = (long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_nhwc_kernel, dim3(nblk(total4, 256)), dim3(256), 0, s, in, out, H, W, C, total4);
+}
+void launch_vote(const float* logits, int B, int C, unsigned long long* counts, int* pred_out, hipStream_t s) {
+    hipLaunchKernelGGL(vote_kernel, dim3(nblk(B, 64)), dim3(64), 0, s, logits, B, C, counts, pred_out);
+}
+
+void philox4x32_10_host(uint32_t c[4], uint32_t k0, uint32_t k1) { philox4x32_10(c, k0, k1); }
+
+}  // namespace dmad

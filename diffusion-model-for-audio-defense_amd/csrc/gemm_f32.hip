@@ -1,0 +1,136 @@
+// fp32 gather-GEMM on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains).
+//
+//   C[n][m] = act( scale[m] * sum_tap sum_k A[tap][m][k] * X[row(n, tap)][k] + shift[m] )
+//
+// One kernel serves every exact-fp32 GEMM-shaped op of the path:
+//   * parity-mode WaveNet: dilated Conv1d as 3 row-shifted taps over the zero-padded residual
+//     stream (WaveNet.py:23-34,86) and the 1x1 res/skip/final convs (WaveNet.py:66-72,160-162);
+//   * mel front-end: the windowed DFT of the 32 overlapping frames of a clip (row stride = hop) and
+//     the slaney filterbank product (torchaudio MelSpectrogram, certified_robustness_eval.py:85);
+//   * VGG19_bn: 3x3 convs as implicit GEMM over NHWC activations with eval-mode BatchNorm folded
+//     into scale/shift, and the three Linear layers (models/vgg.py:48-52,69-81).
+// Tile 128(M) x 128(N) x 16(K), 4 waves (2x2), register-staged double buffering, LDS k-major with a
+// 16-float pad so both the operand reads (ds_read_b32) are bank-conflict free.
+#include "gemm_f32.h"
+
+namespace dmad {
+
+namespace {
+constexpr int BM = 128, BN = 128, BK = 16, PITCH = BM + 16;
+
+__device__ __forceinline__ const float* row_ptr(const GemmF32Args& a, long n, int tap, int kc) {
+    // returns nullptr for a zero row
+    if (n >= a.N) return nullptr;
+    if (a.mode == 2) {
+        const int hw = a.H * a.W;
+        const long b = n / hw;
+        const int p = (int)(n - b * hw), y = p / a.W, x = p - y * a.W;
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if ((unsigned)yy >= (unsigned)a.H || (unsigned)xx >= (unsigned)a.W) return nullptr;
+        return a.X + ((b * a.H + yy) * a.W + xx) * (long)a.Cin + kc;
+    }
+    const long b = n / a.rows_per_batch, r = n - b * a.rows_per_batch;
+    return a.X + b * a.batch_stride + r * a.row_stride + (long)(tap - (a.taps >> 1)) * a.tap_stride + kc;
+}
+}  // namespace
+
+__global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
+    __shared__ float As[2][BK][PITCH];
+    __shared__ float Bs[2][BK][PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1, q = lane >> 4, r16 = lane & 15;
+    const long n0 = (long)blockIdx.x * BN;
+    const int m0 = blockIdx.y * BM;
+    const int ksteps_per_tap = a.K / BK, nks = a.taps * ksteps_per_tap;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[2], rb[2];
+    auto gload = [&](int ks) {
+        const int tap = ks / ksteps_per_tap, kc = (ks - tap * ksteps_per_tap) * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = i * 256 + tid, row = id >> 2, kg = id & 3;
+            const int m = m0 + row;
+            ra[i] = (m < a.M) ? *(const float4*)(a.A + ((long)tap * a.M + m) * a.K + kc + kg * 4) : float4{0, 0, 0, 0};
+            const float* p = row_ptr(a, n0 + row, tap, kc + kg * 4);
+            rb[i] = p ? *(const float4*)p : float4{0, 0, 0, 0};
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = i * 256 + tid, row = id >> 2, kg = id & 3;
+            As[buf][kg * 4 + 0][row] = ra[i].x; As[buf][kg * 4 + 1][row] = ra[i].y;
+            As[buf][kg * 4 + 2][row] = ra[i].z; As[buf][kg * 4 + 3][row] = ra[i].w;
+            Bs[buf][kg * 4 + 0][row] = rb[i].x; Bs[buf][kg * 4 + 1][row] = rb[i].y;
+            Bs[buf][kg * 4 + 2][row] = rb[i].z; Bs[buf][kg * 4 + 3][row] = rb[i].w;
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nks) gload(ks + 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = As[buf][kk * 4 + q][wm * 64 + i * 16 + r16];
+                bf[i] = Bs[buf][kk * 4 + q][wn * 64 + i * 16 + r16];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (ks + 1 < nks) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    const bool vec = ((a.ldc & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + q * 4;
+        float sc[4], sh[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[r] = (a.scale && m + r < a.M) ? a.scale[m + r] : 1.f;
+            sh[r] = (a.shift && m + r < a.M) ? a.shift[m + r] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long n = n0 + wn * 64 + j * 16 + r16;
+            if (n >= a.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = a.scale ? acc[i][j][r] * sc[r] + sh[r] : acc[i][j][r] + sh[r];
+                v[r] = a.relu ? fmaxf(t, 0.f) : t;
+            }
+            float* dst = a.C + n * a.ldc + m;
+            if (vec && m + 3 < a.M) {
+                *(float4*)dst = float4{v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < a.M) dst[r] = v[r];
+            }
+        }
+    }
+}
+
+void launch_gemm_f32(const GemmF32Args& a, hipStream_t s) {
+    dim3 grid((unsigned)((a.N + BN - 1) / BN), (unsigned)((a.M + BM - 1) / BM));
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, a);
+}
+
+}  // namespace dmad

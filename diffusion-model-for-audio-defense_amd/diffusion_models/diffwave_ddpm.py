@@ -1,0 +1,201 @@
+"""Host mirror of the reference's diffusion_models/diffwave_ddpm.py surface, backed by the MI355X
+engine (libdmad_hip.so).  Same names, argument meaning and error behaviour as the reference:
+
+  create_diffwave_model(model_path, config_path, reverse_timestep=25) -> DiffWave   (ref l.395-411)
+  DiffWave.model((audio [B,1,L], steps [B,1])) -> eps [B,1,L]                       (ref l.158,170,178)
+  DiffWave.forward / _diffusion / _reverse / compute_coefficients / compute_eps_t /
+  one_shot_denoise / two_shot_denoise / fast_reverse, .diffusion_hyperparams, .reverse_timestep
+
+Inference only: the eps-network runs in hand-written HIP kernels without autograd.  There is no CPU
+path; inputs must be CUDA tensors (the reference itself hard-codes .cuda()).
+
+Noise: the reference draws every Gaussian on the CPU default generator and copies it over
+(ref l.66,100).  `noise_source='torch_cpu'` reproduces exactly that stream (parity);
+`noise_source='device'` (default) draws counter-based Philox noise on the GPU."""
+import json
+from typing import Union
+
+import numpy as np
+import torch
+
+from dmad_hip import engine as _eng
+from .DiffWave_Unconditional.util import calc_diffusion_hyperparams
+
+
+class WaveNetHIP(torch.nn.Module):
+    """Stands in for WaveNet_Speech_Commands (DiffWave_Unconditional/WaveNet.py:138-172):
+    callable on the tuple (audio [B,1,L], diffusion_steps [B,1]); all rows must carry the same step,
+    which is what every inference caller of the reference passes (t * ones)."""
+
+    def __init__(self, engine: "_eng.Engine"):
+        super().__init__()
+        self.engine = engine
+
+    def forward(self, input_data):
+        audio, diffusion_steps = input_data
+        if torch.is_grad_enabled() and audio.requires_grad:
+            raise NotImplementedError('the HIP eps-network is inference-only (no autograd)')
+        steps = torch.as_tensor(diffusion_steps).detach().reshape(-1).float().cpu()
+        t = float(steps[0])
+        if not bool((steps == t).all()) or t != int(t):
+            raise NotImplementedError('per-row / fractional diffusion steps are not supported by the HIP engine')
+        return self.engine.wavenet_eps(audio, int(t)).unsqueeze(1)
+
+
+class DiffWave(torch.nn.Module):
+
+    def __init__(self, model, diffusion_hyperparams: dict, reverse_timestep: int = 200, grad_enable=True,
+                 noise_source: str = 'device', seed: int = 0):
+        super().__init__()
+        self.model = model
+        self.diffusion_hyperparams = diffusion_hyperparams
+        self.reverse_timestep = reverse_timestep
+        self.freeze = False
+        self.grad_enable = grad_enable
+        assert noise_source in ('device', 'torch_cpu')
+        self.noise_source = noise_source
+        self.seed = seed
+        self._draws = 0           # sample counter for device noise
+
+    # -- plumbing --------------------------------------------------------------------------------
+    @property
+    def engine(self) -> "_eng.Engine":
+        return self.model.engine
+
+    def _tables(self):
+        hp = self.diffusion_hyperparams
+        T, Alpha, Alpha_bar, Sigma = hp["T"], hp["Alpha"], hp["Alpha_bar"], hp["Sigma"]
+        assert len(Alpha) == T
+        assert len(Alpha_bar) == T
+        assert len(Sigma) == T
+        return T, Alpha, Alpha_bar, Sigma
+
+    @staticmethod
+    def _to_tensor(x):
+        return torch.from_numpy(x) if isinstance(x, np.ndarray) else x
+
+    def _noise(self, shape, device):
+        """N(0,1) like the reference's torch.normal(0, 1, size).cuda(); None = let the engine draw Philox."""
+        if self.noise_source == 'torch_cpu':
+            return torch.normal(0, 1, size=tuple(shape)).to(device)
+        return None
+
+    # -- reference API ---------------------------------------------------------------------------
+    def forward(self, waveforms: Union[torch.Tensor, np.ndarray]):
+        waveforms = self._to_tensor(waveforms)
+        output = self._diffusion(waveforms)
+        output = self._reverse(output)
+        return output
+
+    @torch.no_grad()
+    def _diffusion(self, x_0) -> torch.Tensor:
+        x_0 = self._to_tensor(x_0)
+        _, _, Alpha_bar, _ = self._tables()
+        assert x_0.ndim == 3
+        t = self.reverse_timestep - 1
+        c_a = float(torch.sqrt(Alpha_bar[t]))
+        c_b = float(torch.sqrt(1 - Alpha_bar[t]))
+        z = self._noise(x_0.shape, x_0.device)
+        out = self.engine.diffuse(x_0, c_a, c_b, z, seed=self.seed, sample0=self._draws)
+        self._draws += x_0.shape[0]
+        return out.unsqueeze(1)
+
+    @torch.no_grad()
+    def _reverse(self, x_t) -> torch.Tensor:
+        x_t = self._to_tensor(x_t)
+        _, Alpha, Alpha_bar, Sigma = self._tables()
+        assert x_t.ndim == 3
+        x = x_t.detach()[:, 0].contiguous().float().clone()
+        base = self._draws
+        for t in range(self.reverse_timestep - 1, -1, -1):
+            c_eps = float((1 - Alpha[t]) / torch.sqrt(1 - Alpha_bar[t]))
+            c_div = float(torch.sqrt(Alpha[t]))
+            c_sig = float(Sigma[t]) if t > 0 else 0.0
+            z = self._noise(x_t.shape, x_t.device) if t > 0 else None
+            self.engine.ddpm_step(x, t, c_eps, c_div, c_sig, z, seed=self.seed, sample0=base)
+        self._draws += x.shape[0]
+        return x.unsqueeze(1)
+
+    @torch.no_grad()
+    def compute_coefficients(self, x_t, t: int):
+        x_t = self._to_tensor(x_t)
+        _, Alpha, Alpha_bar, Sigma = self._tables()
+        diffusion_steps = t * torch.ones((x_t.shape[0], 1))
+        epsilon_theta = self.model((x_t, diffusion_steps))
+        c = ((1 - Alpha[t]) / torch.sqrt(1 - Alpha_bar[t])).to(x_t.device)
+        mu_theta = (x_t - c * epsilon_theta) / torch.sqrt(Alpha[t]).to(x_t.device)
+        return epsilon_theta, mu_theta, Sigma[t]
+
+    @torch.no_grad()
+    def compute_eps_t(self, x_t, t):
+        x_t = self._to_tensor(x_t)
+        return self.model((x_t, t * torch.ones((x_t.shape[0], 1))))
+
+    @torch.no_grad()
+    def one_shot_denoise(self, x_t):
+        x_t = self._to_tensor(x_t)
+        t = self.reverse_timestep - 1
+        Alpha_bar = self.diffusion_hyperparams["Alpha_bar"]
+        c_a = float((1 / Alpha_bar).sqrt()[t])
+        c_b = float((1 / Alpha_bar - 1).sqrt()[t])
+        return self.engine.one_shot(x_t, t, c_a, c_b).unsqueeze(1)
+
+    @torch.no_grad()
+    def two_shot_denoise(self, x_t):
+        x_t = self._to_tensor(x_t)
+        t = self.reverse_timestep - 1
+        hp = self.diffusion_hyperparams
+        Alpha, Alpha_bar, Beta = hp["Alpha"], hp["Alpha_bar"], hp["Beta"]
+        eps = self.model((x_t, t * torch.ones((x_t.shape[0], 1))))
+        mu = (Alpha_bar[t] / Alpha[0]).sqrt().to(x_t.device)
+        sigma = (1 - Alpha_bar[t] - (Alpha_bar[t] / Alpha[0]) * Beta[0] ** 2).sqrt().to(x_t.device)
+        x_1 = (x_t - sigma * eps) / mu
+        return self.compute_coefficients(x_1, 0)[1]
+
+    @torch.no_grad()
+    def fast_reverse(self, x_t):
+        """K = 3 strided sampler (ref l.106-141); note the reference uses Beta_tilde (not its sqrt) as sigma."""
+        x_t = self._to_tensor(x_t)
+        Alpha_bar = self.diffusion_hyperparams["Alpha_bar"]
+        K = 3
+        S = torch.round(torch.linspace(1, self.reverse_timestep, K)).int() - 1
+        beta_new, beta_tilde_new = torch.zeros(K), torch.zeros(K)
+        for i in range(K):
+            if i > 0:
+                beta_new[i] = 1 - Alpha_bar[S[i]] / Alpha_bar[S[i - 1]]
+                beta_tilde_new[i] = (1 - Alpha_bar[S[i - 1]]) / (1 - Alpha_bar[S[i]]) * beta_new[i]
+            else:
+                beta_new[i] = 1 - Alpha_bar[S[i]]
+        alpha_new = 1 - beta_new
+        alpha_bar_new = torch.cumprod(alpha_new, dim=0)
+        x = x_t
+        for t in range(K - 1, -1, -1):
+            eps = self.model((x, int(S[t]) * torch.ones((x.shape[0], 1))))
+            c = ((1 - alpha_new[t]) / torch.sqrt(1 - alpha_bar_new[t])).to(x.device)
+            mu = (x - c * eps) / torch.sqrt(alpha_new[t]).to(x.device)
+            z = self._noise(x.shape, x.device)
+            if z is None:
+                z = self.engine.philox_normal(self.seed, self._draws, 0xFA57 + t, x.shape[0]).unsqueeze(1)
+            x = mu + beta_tilde_new[t].to(x.device) * z
+        self._draws += x.shape[0]
+        return x
+
+
+def create_diffwave_model(model_path, config_path, reverse_timestep=25, state_dict=None, noise_source='device',
+                          precision=None, max_batch=None, engine=None):
+    """Reference signature (ref l.395-411) plus optional keyword-only extras.  Reads the JSON keys
+    `wavenet_config` and `diffusion_config`, loads checkpoint['model_state_dict'] (weight_g/weight_v
+    layout), folds and uploads the weights.  `state_dict` may be passed instead of
+    a checkpoint path (synthetic weights)."""
+    with open(config_path) as f:
+        cfg = json.loads(f.read())
+    wavenet_config = cfg["wavenet_config"]
+    diffusion_hyperparams = calc_diffusion_hyperparams(**cfg["diffusion_config"])
+    if state_dict is None:
+        checkpoint = torch.load(model_path, map_location='cpu')
+        state_dict = checkpoint['model_state_dict']
+    eng = engine or _eng.get_engine(wavenet_config, precision=precision, max_batch=max_batch)
+    if not eng.has_wavenet:
+        eng.load_wavenet(state_dict)
+    return DiffWave(model=WaveNetHIP(eng), diffusion_hyperparams=diffusion_hyperparams,
+                    reverse_timestep=reverse_timestep, noise_source=noise_source)

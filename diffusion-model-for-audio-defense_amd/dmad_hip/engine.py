@@ -1,0 +1,270 @@
+"""Host-side handle on one dmad_engine (one per process per GPU).
+
+PyTorch is plumbing here: device memory (torch tensors), the current HIP stream and
+torch.distributed.  All arithmetic of the hot path runs inside libdmad_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DmadConfig, DmadError, check
+
+BF16, FP32 = 0, 1
+VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _as_np(a) -> np.ndarray:
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().float().numpy()
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def fold_wavenet_state_dict(sd: Dict[str, object], num_res_layers: int) -> Dict[str, np.ndarray]:
+    """Reference checkpoint layout -> folded fp32 arrays named as in dmad.h.
+    Weight norm is folded with torch._weight_norm, the very op nn.utils.weight_norm evaluates on each
+    forward of the reference (WaveNet.py:27-28,66-72)."""
+    def T(k):
+        v = sd[k]
+        return v.detach().cpu().float() if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v, dtype=np.float32))
+
+    def fold(prefix):
+        return torch._weight_norm(T(prefix + '.weight_v'), T(prefix + '.weight_g'), 0)
+
+    out = {'init.w': fold('init_conv.0.conv').reshape(256), 'init.b': T('init_conv.0.conv.bias'),
+           'fc_t1.w': T('residual_layer.fc_t1.weight'), 'fc_t1.b': T('residual_layer.fc_t1.bias'),
+           'fc_t2.w': T('residual_layer.fc_t2.weight'), 'fc_t2.b': T('residual_layer.fc_t2.bias')}
+    for n in range(num_res_layers):
+        p = 'residual_layer.residual_blocks.%d' % n
+        out['fc_t.%d.w' % n] = T(p + '.fc_t.weight'); out['fc_t.%d.b' % n] = T(p + '.fc_t.bias')
+        out['dil.%d.w' % n] = fold(p + '.dilated_conv_layer.conv'); out['dil.%d.b' % n] = T(p + '.dilated_conv_layer.conv.bias')
+        out['res.%d.w' % n] = fold(p + '.res_conv').reshape(256, 256); out['res.%d.b' % n] = T(p + '.res_conv.bias')
+        out['skip.%d.w' % n] = fold(p + '.skip_conv').reshape(256, 256); out['skip.%d.b' % n] = T(p + '.skip_conv.bias')
+    out['f0.w'] = fold('final_conv.0.conv').reshape(256, 256); out['f0.b'] = T('final_conv.0.conv.bias')
+    out['f2.w'] = T('final_conv.2.conv.weight').reshape(256); out['f2.b'] = T('final_conv.2.conv.bias').reshape(1)
+    return {k: _as_np(v) for k, v in out.items()}
+
+
+def fold_vgg19_bn_state_dict(sd: Dict[str, object], eps: float = 1e-5) -> Dict[str, np.ndarray]:
+    """models/vgg.py vgg19_bn state dict -> conv weights + eval-mode BatchNorm folded to scale/shift
+    (float64 on the host, rounded once):  y = scale * conv(x) + shift,
+    scale = gamma / sqrt(var + eps), shift = (bias - mean) * scale + beta."""
+    def A(k):
+        v = sd[k]
+        return (v.detach().cpu().double().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, dtype=np.float64))
+    out, idx, li = {}, 0, 0
+    for v in VGG19_CFG:
+        if v == 'M':
+            idx += 1
+            continue
+        b = idx + 1
+        scale = A('features.%d.weight' % b) / np.sqrt(A('features.%d.running_var' % b) + eps)
+        shift = (A('features.%d.bias' % idx) - A('features.%d.running_mean' % b)) * scale + A('features.%d.bias' % b)
+        out['vgg.conv%d.w' % li] = A('features.%d.weight' % idx)
+        out['vgg.conv%d.scale' % li] = scale
+        out['vgg.conv%d.shift' % li] = shift
+        idx += 3
+        li += 1
+    for j, i in enumerate((0, 3, 6)):
+        out['vgg.fc%d.w' % j] = A('classifier.%d.weight' % i)
+        out['vgg.fc%d.b' % j] = A('classifier.%d.bias' % i)
+    return {k: _as_np(v) for k, v in out.items()}
+
+
+class Engine:
+    """One libdmad_hip engine bound to the current CUDA(HIP) device."""
+
+    def __init__(self, wavenet_config: Optional[dict] = None, clip_len: int = 16000, max_batch: int = 64,
+                 num_classes: int = 10, precision: int = BF16, with_classifier: bool = True):
+        if not torch.cuda.is_available():
+            raise DmadError('no MI355X/HIP device visible: the dmad engine has no CPU path')
+        self.lib = _lib.load()
+        wc = dict(res_channels=256, skip_channels=256, num_res_layers=36, dilation_cycle=12,
+                  diffusion_step_embed_dim_in=128, diffusion_step_embed_dim_mid=512, diffusion_step_embed_dim_out=512)
+        wc.update(wavenet_config or {})
+        if wc.get('in_channels', 1) != 1 or wc.get('out_channels', 1) != 1:
+            raise DmadError('only in_channels = out_channels = 1 is supported')
+        self.cfg = DmadConfig(wc['res_channels'], wc['skip_channels'], wc['num_res_layers'], wc['dilation_cycle'],
+                              wc['diffusion_step_embed_dim_in'], wc['diffusion_step_embed_dim_mid'],
+                              wc['diffusion_step_embed_dim_out'], clip_len, max_batch, num_classes, precision,
+                              1 if with_classifier else 0)
+        self.L, self.max_batch, self.num_classes, self.precision = clip_len, max_batch, num_classes, precision
+        self.num_res_layers = wc['num_res_layers']
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        h = C.c_void_p()
+        check(self.lib.dmad_create(C.byref(self.cfg), C.byref(h)))
+        self._h = h
+        self.has_wavenet = False
+        self.has_classifier = False
+
+    def close(self):
+        if getattr(self, '_h', None):
+            torch.cuda.synchronize()
+            self.lib.dmad_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def _load(self, arrays: Dict[str, np.ndarray]):
+        for name, a in arrays.items():
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            check(self.lib.dmad_load_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+        check(self.lib.dmad_finalize_weights(self._h))
+
+    def load_wavenet(self, state_dict):
+        if self.has_wavenet:
+            raise DmadError('WaveNet weights are already loaded into this engine')
+        self._load(fold_wavenet_state_dict(state_dict, self.num_res_layers))
+        self.has_wavenet = True
+
+    def load_vgg19_bn(self, state_dict):
+        if self.has_classifier:
+            raise DmadError('classifier weights are already loaded into this engine')
+        self._load(fold_vgg19_bn_state_dict(state_dict))
+        self.has_classifier = True
+
+    # ------------------------------------------------------------------ helpers
+    def _wave(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise DmadError('input must live on the GPU (the dmad engine has no CPU path)')
+        x = x.detach()
+        if x.dim() == 3:
+            assert x.shape[1] == 1, 'expected [B,1,L]'
+            x = x[:, 0]
+        assert x.dim() == 2 and x.shape[1] == self.L, 'expected [B,%d], got %s' % (self.L, tuple(x.shape))
+        return x.contiguous().float()
+
+    def _chunks(self, B):
+        for s in range(0, B, self.max_batch):
+            yield s, min(B, s + self.max_batch)
+
+    # ------------------------------------------------------------------ hot path
+    def wavenet_eps(self, x_t: torch.Tensor, t: int) -> torch.Tensor:
+        x = self._wave(x_t)
+        out = torch.empty_like(x)
+        for s, e in self._chunks(x.shape[0]):
+            check(self.lib.dmad_wavenet_eps(self._h, _ptr(x[s:e]), int(t), e - s, _ptr(out[s:e]), _stream()))
+        return out
+
+    def one_shot(self, x_t: torch.Tensor, t: int, c_a: float, c_b: float) -> torch.Tensor:
+        x = self._wave(x_t)
+        out = torch.empty_like(x)
+        for s, e in self._chunks(x.shape[0]):
+            check(self.lib.dmad_one_shot(self._h, _ptr(x[s:e]), int(t), float(c_a), float(c_b), e - s, _ptr(out[s:e]), _stream()))
+        return out
+
+    def ddpm_step(self, x: torch.Tensor, t: int, c_eps: float, c_div: float, c_sig: float, z: Optional[torch.Tensor],
+                  seed: int = 0, sample0: int = 0):
+        """in place on x ([B, L] contiguous fp32 CUDA)."""
+        assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
+        for s, e in self._chunks(x.shape[0]):
+            zz = None if z is None else self._wave(z)[s:e].contiguous()
+            check(self.lib.dmad_ddpm_step(self._h, _ptr(x[s:e]), int(t), float(c_eps), float(c_div), float(c_sig), _ptr(zz),
+                                          int(seed), int(sample0) + s, e - s, _stream()))
+        return x
+
+    def diffuse(self, x0: torch.Tensor, c_a: float, c_b: float, z: Optional[torch.Tensor], seed: int = 0, sample0: int = 0):
+        x = self._wave(x0)
+        out = torch.empty_like(x)
+        for s, e in self._chunks(x.shape[0]):
+            zz = None if z is None else self._wave(z)[s:e].contiguous()
+            check(self.lib.dmad_diffuse(self._h, _ptr(x[s:e]), float(c_a), float(c_b), _ptr(zz), int(seed), int(sample0) + s,
+                                        e - s, _ptr(out[s:e]), _stream()))
+        return out
+
+    def mel_db(self, x: torch.Tensor) -> torch.Tensor:
+        x = self._wave(x)
+        out = torch.empty((x.shape[0], 1, 32, 32), device=x.device, dtype=torch.float32)
+        for s, e in self._chunks(x.shape[0]):
+            check(self.lib.dmad_mel_db(self._h, _ptr(x[s:e]), e - s, _ptr(out[s:e]), _stream()))
+        return out
+
+    def classify(self, spec: torch.Tensor) -> torch.Tensor:
+        if not spec.is_cuda:
+            raise DmadError('input must live on the GPU (the dmad engine has no CPU path)')
+        sp = spec.detach().reshape(spec.shape[0], 32 * 32).contiguous().float()
+        out = torch.empty((sp.shape[0], self.num_classes), device=sp.device, dtype=torch.float32)
+        for s, e in self._chunks(sp.shape[0]):
+            check(self.lib.dmad_classify(self._h, _ptr(sp[s:e]), e - s, _ptr(out[s:e]), _stream()))
+        return out
+
+    def vote(self, logits: torch.Tensor, counts: torch.Tensor):
+        lg = logits.detach().contiguous().float()
+        assert lg.is_cuda and counts.is_cuda and counts.dtype == torch.int64 and lg.shape[1] == self.num_classes
+        check(self.lib.dmad_vote(self._h, _ptr(lg), lg.shape[0], _ptr(counts), _stream()))
+
+    def smooth_votes(self, clip: torch.Tensor, sigma: float, sqrt_abar_star: float, t: int, c_a: float, c_b: float,
+                     n: int, batch: Optional[int] = None, seed: int = 0, sample0: int = 0,
+                     delta: Optional[torch.Tensor] = None, want_logits: bool = False, want_x0: bool = False,
+                     counts: Optional[torch.Tensor] = None):
+        """The fused Monte Carlo loop (dmad_smooth_votes).  Returns (counts[int64, C] on device, logits|None, x0|None)."""
+        clip = clip.detach().reshape(-1).contiguous().float()
+        assert clip.is_cuda and clip.numel() == self.L
+        batch = min(batch or self.max_batch, self.max_batch)
+        if counts is None:
+            counts = torch.zeros(self.num_classes, dtype=torch.int64, device=clip.device)
+        logits = torch.empty((n, self.num_classes), device=clip.device) if want_logits else None
+        x0 = torch.empty((n, self.L), device=clip.device) if want_x0 else None
+        if delta is not None:
+            delta = delta.detach().reshape(n, self.L).contiguous().float()
+            assert delta.is_cuda
+        check(self.lib.dmad_smooth_votes(self._h, _ptr(clip), float(sigma), float(sqrt_abar_star), int(t), float(c_a), float(c_b),
+                                         int(n), int(batch), int(seed), int(sample0), _ptr(delta), _ptr(counts), _ptr(logits),
+                                         _ptr(x0), _stream()))
+        return counts, logits, x0
+
+    def philox_raw(self, seed: int, sample: int, stream: int, nblocks: int) -> torch.Tensor:
+        out = torch.empty(nblocks * 4, dtype=torch.int32, device=self.device)
+        check(self.lib.dmad_philox_raw(self._h, int(seed), int(sample), int(stream), int(nblocks), _ptr(out), _stream()))
+        return out
+
+    def philox_normal(self, seed: int, sample0: int, stream: int, B: int) -> torch.Tensor:
+        out = torch.empty((B, self.L), dtype=torch.float32, device=self.device)
+        check(self.lib.dmad_philox_normal(self._h, int(seed), int(sample0), int(stream), int(B), _ptr(out), _stream()))
+        return out
+
+    def time_layer(self, layer: int, B: int, iters: int) -> float:
+        ms = C.c_float(0)
+        check(self.lib.dmad_time_layer(self._h, int(layer), int(B), int(iters), C.byref(ms), _stream()))
+        return float(ms.value)
+
+    def device_bytes(self) -> int:
+        return int(self.lib.dmad_device_bytes(self._h))
+
+
+_ENGINES: Dict[tuple, Engine] = {}
+
+
+def get_engine(wavenet_config: Optional[dict] = None, precision: Optional[int] = None, max_batch: Optional[int] = None,
+               fresh: bool = False) -> Engine:
+    """Process-wide engine per (device, precision).  DMAD_PRECISION = bf16|fp32 and DMAD_MAX_BATCH
+    override the defaults (bf16, 64)."""
+    if precision is None:
+        precision = {'bf16': BF16, 'fp32': FP32}[os.environ.get('DMAD_PRECISION', 'bf16').lower()]
+    if max_batch is None:
+        max_batch = int(os.environ.get('DMAD_MAX_BATCH', '64'))
+    key = (torch.cuda.current_device() if torch.cuda.is_available() else -1, precision)
+    if fresh or key not in _ENGINES:
+        eng = Engine(wavenet_config, max_batch=max_batch, precision=precision)
+        if fresh:
+            return eng
+        _ENGINES[key] = eng
+    return _ENGINES[key]

@@ -1,0 +1,137 @@
+"""Seeded synthetic weights and inputs.
+
+The pretrained DiffWave / ConvNets_SpeechCommands checkpoints are not available offline
+(SURVEY F9), so every parity case runs on weights produced HERE from a seed.  The same
+generator feeds (a) the reference modules inside tests/golden/make_golden.py, (b) the CPU
+oracle and (c) the HIP engine, so all three see bit-identical fp32 parameters.
+
+Key names and shapes follow the reference checkpoints:
+  WaveNet  : diffusion_models/DiffWave_Unconditional/WaveNet.py:23-34,53-72,138-162
+  VGG19_bn : audio_models/ConvNets_SpeechCommands/models/vgg.py:31-52,69-89,190-201
+Only numpy's Generator(PCG64) is used, so the stream does not depend on torch.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+WAVENET_CONFIG = dict(in_channels=1, res_channels=256, skip_channels=256, out_channels=1,
+                      num_res_layers=36, dilation_cycle=12,
+                      diffusion_step_embed_dim_in=128,
+                      diffusion_step_embed_dim_mid=512,
+                      diffusion_step_embed_dim_out=512)
+DIFFUSION_CONFIG = dict(T=200, beta_0=0.0001, beta_T=0.02)
+
+VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M',
+             512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _wn_pair(rng, prefix, out_c, in_c, k, sd):
+    """weight-normed conv: weight_v ~ N(0, 2/fan_in), weight_g = |v| * U(0.8, 1.2)."""
+    fan_in = in_c * k
+    v = rng.standard_normal((out_c, in_c, k)) * np.sqrt(2.0 / fan_in)
+    norm = np.sqrt((v.astype(np.float32) ** 2).sum(axis=(1, 2), keepdims=True))
+    g = norm * rng.uniform(0.8, 1.2, size=(out_c, 1, 1))
+    sd[prefix + '.bias'] = _f32(rng.standard_normal(out_c) * 0.02)
+    sd[prefix + '.weight_g'] = _f32(g)
+    sd[prefix + '.weight_v'] = _f32(v)
+
+
+def _linear(rng, prefix, out_f, in_f, sd):
+    bound = 1.0 / np.sqrt(in_f)
+    sd[prefix + '.weight'] = _f32(rng.uniform(-bound, bound, size=(out_f, in_f)))
+    sd[prefix + '.bias'] = _f32(rng.uniform(-bound, bound, size=(out_f,)))
+
+
+def wavenet_state_dict(seed: int = 1234, cfg: dict | None = None) -> "OrderedDict[str, np.ndarray]":
+    """fp32 numpy state dict with the reference's 408 keys (for the default config)."""
+    cfg = dict(WAVENET_CONFIG if cfg is None else cfg)
+    C, S = cfg['res_channels'], cfg['skip_channels']
+    E_in, E_mid, E_out = (cfg['diffusion_step_embed_dim_in'], cfg['diffusion_step_embed_dim_mid'],
+                          cfg['diffusion_step_embed_dim_out'])
+    rng = np.random.default_rng(seed)
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    _wn_pair(rng, 'init_conv.0.conv', C, cfg['in_channels'], 1, sd)
+    _linear(rng, 'residual_layer.fc_t1', E_mid, E_in, sd)
+    _linear(rng, 'residual_layer.fc_t2', E_out, E_mid, sd)
+    for n in range(cfg['num_res_layers']):
+        p = 'residual_layer.residual_blocks.%d' % n
+        _linear(rng, p + '.fc_t', C, E_out, sd)
+        _wn_pair(rng, p + '.dilated_conv_layer.conv', 2 * C, C, 3, sd)
+        _wn_pair(rng, p + '.res_conv', C, C, 1, sd)
+        _wn_pair(rng, p + '.skip_conv', S, C, 1, sd)
+    _wn_pair(rng, 'final_conv.0.conv', S, S, 1, sd)
+    # the reference zero-initialises this conv (WaveNet.py:39-44): re-initialise, SURVEY F6
+    sd['final_conv.2.conv.weight'] = _f32(rng.standard_normal((cfg['out_channels'], S, 1)) * 0.05)
+    sd['final_conv.2.conv.bias'] = _f32(rng.standard_normal(cfg['out_channels']) * 0.02)
+    return sd
+
+
+def vgg19_bn_state_dict(seed: int = 4321, num_classes: int = 10, in_channels: int = 1, calibrated: bool = True):
+    """fp32 numpy state dict for models/vgg.py vgg19_bn(num_classes=10, in_channels=1).
+
+    With `calibrated` (and seed 4321) the BatchNorm running statistics come from the committed data
+    file dmad_hip/data/vgg19_bn_calib_seed4321.npz (one calibration pass over noisy synthetic clips,
+    tests/golden/make_vgg_calib.py) so that the synthetic classifier is not degenerate and the Monte
+    Carlo votes spread over several classes, like a trained checkpoint's would.
+    """
+    rng = np.random.default_rng(seed)
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    idx, cin, first = 0, in_channels, True
+    for v in VGG19_CFG:
+        if v == 'M':
+            idx += 1
+            continue
+        n = 9 * v
+        w = rng.standard_normal((v, cin, 3, 3)) * np.sqrt(2.0 / n)
+        sd['features.%d.weight' % idx] = _f32(w)
+        sd['features.%d.bias' % idx] = _f32(rng.standard_normal(v) * 0.05)
+        b = idx + 1
+        sd['features.%d.weight' % b] = _f32(rng.uniform(0.6, 1.4, size=v))
+        sd['features.%d.bias' % b] = _f32(rng.standard_normal(v) * 0.2)
+        if first:
+            # conv(1->64) of a dB image: response ~ sum(w)*mean_dB, spread ~ |w|*std_dB
+            wsum = w.reshape(v, -1).sum(1)
+            wl2 = np.sqrt((w.reshape(v, -1) ** 2).sum(1))
+            sd['features.%d.running_mean' % b] = _f32(wsum * (-20.0))
+            sd['features.%d.running_var' % b] = _f32((wl2 * 12.0) ** 2 + 1.0)
+            first = False
+        else:
+            sd['features.%d.running_mean' % b] = _f32(rng.standard_normal(v) * 0.3)
+            sd['features.%d.running_var' % b] = _f32(rng.uniform(0.5, 1.5, size=v))
+        sd['features.%d.num_batches_tracked' % b] = np.asarray(1000, dtype=np.int64)
+        idx += 3
+        cin = v
+    for i, (o, k) in zip((0, 3, 6), ((4096, 512), (4096, 4096), (num_classes, 4096))):
+        sd['classifier.%d.weight' % i] = _f32(rng.standard_normal((o, k)) * np.sqrt(2.0 / k))
+        sd['classifier.%d.bias' % i] = _f32(rng.standard_normal(o) * 0.1)
+    if calibrated and seed == 4321:
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'vgg19_bn_calib_seed4321.npz')
+        with np.load(path) as z:
+            for k in z.files:
+                assert sd[k].shape == z[k].shape
+                sd[k] = _f32(z[k])
+    return sd
+
+
+def synthetic_clip(seed: int = 0, length: int = 16000) -> np.ndarray:
+    """A 1 s 'utterance': decaying harmonic bursts + weak noise, in [-1, 1] (fp32 [1, L])."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(length) / 16000.0
+    x = np.zeros(length)
+    for _ in range(4):
+        f0 = rng.uniform(110, 420)
+        t0 = rng.uniform(0.05, 0.7)
+        dur = rng.uniform(0.08, 0.25)
+        env = np.exp(-0.5 * ((t - t0) / dur) ** 2)
+        for h in range(1, 6):
+            x += env * rng.uniform(0.2, 1.0) / h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6.28))
+    x += 0.01 * rng.standard_normal(length)
+    x = 0.5 * x / np.abs(x).max()
+    return _f32(x[None, :])

@@ -1,0 +1,28 @@
+"""The reference's Wave2Spect transform (certified_robustness_eval.py:85-87:
+torchaudio MelSpectrogram(n_fft=2048, hop_length=512, n_mels=32, norm='slaney', pad_mode='constant',
+mel_scale='slaney') followed by AmplitudeToDB(stype='power')) as one HIP-backed callable."""
+import torch
+
+from . import engine as _eng
+
+
+class MelSpectrogramDB(torch.nn.Module):
+    """[B,1,16000] fp32 CUDA -> [B,1,32,32] dB mel spectrogram (windowed DFT on the fp32 matrix cores,
+    |.|^2, slaney filterbank, 10*log10(max(.,1e-10)))."""
+
+    def __init__(self, engine=None):
+        super().__init__()
+        self._engine = engine
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = _eng.get_engine()
+        return self._engine
+
+    @torch.no_grad()
+    def forward(self, x):
+        return self.engine.mel_db(x)
+
+
+Wave2Spect = MelSpectrogramDB

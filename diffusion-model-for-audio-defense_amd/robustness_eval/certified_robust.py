@@ -1,0 +1,194 @@
+"""Host mirror of robustness_eval/certified_robust.py (RobustCertificate, ref l.6-127) on the MI355X
+engine.  Same constructor, methods, return types and assertions as the reference.
+
+What changes underneath:
+  * smooth_predict's Monte Carlo loop (ref l.33-67) runs as ONE call into libdmad_hip.so
+    (dmad_smooth_votes) when denoiser / transform / classifier are this package's HIP-backed stages:
+    noise, sqrt(alpha_bar*) scaling, one-shot DiffWave purification, mel-dB, VGG19_bn, arg-max and the
+    per-class histogram never leave the GPU and the 10 `.item()` syncs of the reference become one
+    80-byte copy.  Other classifiers / transforms (M5, ResNeXt, user modules) are called as torch
+    modules on the purified batch and only the vote count runs in HIP.
+  * The N samples shard over torch.distributed ranks (one process per GPU); the per-class counts are
+    summed with a single all_reduce (RCCL over xGMI on MI355X).  With device noise (Philox keyed by the
+    global sample index) the counts do not depend on the number of ranks.
+  * noise_source='torch_cpu' reproduces the reference's CPU torch.normal stream exactly (parity).
+  * lower_conf_bound uses scipy's Beta quantile; the reference's statsmodels call
+    proportion_confint(k, n, alpha=2*alpha, method='beta')[0] is the same Clopper-Pearson bound.
+"""
+import math
+
+import torch
+from scipy.stats import beta as _beta
+from scipy.stats import norm
+
+__all__ = ['RobustCertificate']
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+class RobustCertificate():
+
+    def __init__(self, classifier: torch.nn.Module, transform=None, denoiser=None, one_shot_rev: bool = False,
+                 num_classes=10, noise_source: str = 'device', seed: int = None, shard: bool = True) -> None:
+        self.classifier = classifier
+        self.transform = transform
+        self.denoiser = denoiser
+        self.num_classes = num_classes
+        self.one_shot_rev = one_shot_rev
+        assert noise_source in ('device', 'torch_cpu')
+        self.noise_source = noise_source
+        self.seed = seed
+        self.shard = shard
+        self._calls = 0
+
+    # ------------------------------------------------------------------------------------------
+    def _fused(self):
+        """True when every stage is HIP-backed and lives in one engine."""
+        from dmad_hip.transforms import MelSpectrogramDB
+        den, cls = self.denoiser, self.classifier
+        eng = getattr(den, 'engine', None)
+        return (eng is not None and isinstance(self.transform, MelSpectrogramDB) and getattr(cls, 'engine', None) is eng
+                and eng.has_classifier and eng.has_wavenet)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor):
+        x_in = x
+        if self.denoiser is not None:
+            x_in = self.denoiser.one_shot_denoise(x_in)
+        if self.transform is not None:
+            x_in = self.transform(x_in)
+        return self.classifier(x_in)
+
+    def _seed_for_call(self):
+        if self.seed is not None:
+            s = (int(self.seed) * 1000003 + self._calls) & 0xFFFFFFFFFFFFFFFF
+        else:                                   # governed by torch.manual_seed, identical on every rank only
+            s = int(torch.randint(0, 2 ** 62, (1,)).item())   # if the ranks seeded torch identically
+            dist, _, world = _dist()
+            if dist is not None and world > 1:
+                t = torch.tensor([s], dtype=torch.int64, device='cuda' if torch.cuda.is_available() and dist.get_backend() == 'nccl' else 'cpu')
+                dist.broadcast(t, 0)
+                s = int(t.item())
+        self._calls += 1
+        return s
+
+    @torch.no_grad()
+    def smooth_predict(self, x: torch.Tensor, num_sampling: int = 100, sigma=0.25, batch_size=64):
+        assert(x.shape[0] == 1)
+        dist, rank, world = _dist()
+        if not self.shard:
+            dist, rank, world = None, 0, 1
+        # contiguous shard of the global sample index range for this rank
+        lo = (num_sampling * rank) // world
+        hi = (num_sampling * (rank + 1)) // world
+        seed = self._seed_for_call()
+
+        coeffs = None
+        if self.denoiser is not None:
+            alpha_bar_star = 1 / (1 + sigma ** 2)
+            t_star = self.compute_t_star(alpha_bar_star)
+            self.denoiser.reverse_timestep = t_star
+            Alpha_bar = self.denoiser.diffusion_hyperparams['Alpha_bar']
+            t = t_star - 1
+            coeffs = (t, float((1 / Alpha_bar).sqrt()[t]), float((1 / Alpha_bar - 1).sqrt()[t]),
+                      float(torch.tensor(alpha_bar_star ** 0.5, dtype=torch.float32)))
+
+        if self.noise_source == 'torch_cpu':
+            # the reference's stream: one CPU draw per batch (ref l.47); the stream is batch-split
+            # invariant, so every rank draws the whole stream and keeps its own slice
+            chunks, done = [], 0
+            while done < num_sampling:
+                b = min(batch_size, num_sampling - done)
+                d = torch.normal(0, sigma, size=(b,) + tuple(x.shape))
+                a, e = max(lo, done), min(hi, done + b)
+                if e > a:
+                    chunks.append(d[a - done:e - done])
+                done += b
+            delta = torch.cat(chunks, 0).to(x.device) if chunks else None
+        else:
+            delta = None
+
+        n_local = hi - lo
+        if self._fused() and n_local > 0:
+            eng = self.denoiser.engine
+            counts, _, _ = eng.smooth_votes(x, sigma, coeffs[3], coeffs[0], coeffs[1], coeffs[2], n_local,
+                                            seed=seed, sample0=lo, delta=delta)
+        else:
+            counts = self._generic_votes(x, sigma, coeffs, lo, hi, seed, delta, batch_size)
+
+        if dist is not None and world > 1:
+            if dist.get_backend() != 'nccl':
+                counts = counts.cpu()
+            dist.all_reduce(counts)                 # the single collective of the path: int64[num_classes]
+        return counts.cpu()
+
+    def _generic_votes(self, x, sigma, coeffs, lo, hi, seed, delta, batch_size):
+        """Purify with the HIP one-shot, then call the caller's transform / classifier modules."""
+        device = x.device
+        counts = None
+        eng = getattr(self.denoiser, 'engine', None) or getattr(self.classifier, 'engine', None)
+        pos = lo
+        while pos < hi:
+            b = min(batch_size, hi - pos)
+            x_in = x.repeat(b, 1, 1)
+            if delta is not None:
+                d = delta[pos - lo:pos - lo + b]
+            else:
+                if eng is None:
+                    raise RuntimeError('device noise needs a HIP-backed denoiser or classifier; use noise_source="torch_cpu"')
+                d = sigma * eng.philox_normal(seed, pos, 0, b).reshape(b, *x.shape)
+            x_in = x_in + d
+            if self.denoiser is not None:
+                x_in = coeffs[3] * x_in
+            out = self.forward(x_in)
+            if counts is None:
+                counts = torch.zeros(out.shape[-1], dtype=torch.int64, device=device)
+            if eng is not None and out.is_cuda and out.shape[-1] == eng.num_classes:
+                eng.vote(out, counts)
+            else:
+                pred = out.max(1, keepdim=True)[1].reshape(-1)
+                counts += torch.bincount(pred, minlength=out.shape[-1]).to(counts.dtype)
+            pos += b
+        if counts is None:
+            counts = torch.zeros(self.num_classes, dtype=torch.int64, device=device)
+        return counts
+
+    @torch.no_grad()
+    def certify(self, x: torch.Tensor, y: torch.Tensor, sigma: float = 0.25, n_0: int = 100, n: int = 100000,
+                alpha: float = 0.001, batch_size: int = 64):
+        y_pred, radius = -torch.ones_like(y), torch.zeros_like(y, dtype=torch.float32)
+        for i in range(x.shape[0]):
+            x_in = x[i]
+            counts_0 = self.smooth_predict(x_in, num_sampling=n_0, sigma=sigma, batch_size=batch_size)
+            c_A = counts_0.max(0, keepdim=True)[1].item()
+            counts = self.smooth_predict(x_in, num_sampling=n, sigma=sigma, batch_size=batch_size)
+            pa = self.lower_conf_bound(k=counts[c_A], n=n, alpha=alpha)
+            if pa > 0.5:
+                y_pred[i] = c_A
+                radius[i] = sigma * norm.ppf(pa)
+            else:
+                y_pred[i] = -1
+                radius[i] = 0
+        return y_pred, radius,
+
+    def compute_t_star(self, alpha_bar_star):
+        Alpha_bar = self.denoiser.diffusion_hyperparams['Alpha_bar']
+        return torch.abs(Alpha_bar - alpha_bar_star).min(0, keepdim=True)[1].item() + 1
+
+    def lower_conf_bound(self, k, n, alpha=0.001):
+        k = int(k)
+        if k <= 0:
+            return 0.0
+        return float(_beta.ppf(alpha, k, n - k + 1))
+
+    def certified_robust_correct(self, y_pred: torch.Tensor, y_target: torch.Tensor, r_c: torch.Tensor, r: float = 1.):
+        correct = 0
+        for i in range(len(y_pred)):
+            if y_pred[i] == y_target[i] and r_c[i] >= r:
+                correct += 1
+        return correct

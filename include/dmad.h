@@ -1,0 +1,129 @@
+/* dmad.h — C ABI of libdmad_hip.so, the MI355X (gfx950) engine behind the reference's Python
+ * surfaces for the certified-smoothing hot path.
+ *
+ * The reference (cychomatica/Diffusion-Model-for-Audio-Defense) is 100 % Python on PyTorch and has
+ * no FFI; the "plugin API" of this path is a set of Python call sites.  Each entry point below
+ * names the reference call it replaces (paths relative to the reference repo root).  Device pointers
+ * in, device pointers out, an explicit hipStream_t, no hidden allocation after dmad_create(), no
+ * torch types.  Every function returns 0 on success or a negative dmad_status; dmad_last_error()
+ * gives the message (thread-local).  One engine per process per GPU; calls on one engine must come
+ * from one thread at a time.
+ */
+#ifndef DMAD_H
+#define DMAD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dmad_engine dmad_engine;
+typedef void* dmad_stream;      /* hipStream_t (torch.cuda.current_stream().cuda_stream) */
+
+enum dmad_status {
+    DMAD_OK = 0,
+    DMAD_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+    DMAD_ERR_STATE = -2,        /* weights not finalised, batch larger than max_batch, ... */
+    DMAD_ERR_HIP = -3           /* a HIP runtime call failed */
+};
+
+enum dmad_precision {
+    DMAD_BF16 = 0,              /* WaveNet on bf16 MFMA (fp32 accumulate); mel + classifier fp32 */
+    DMAD_FP32 = 1               /* everything on the exact-fp32 matrix path (parity mode) */
+};
+
+/* configs/config.json (wavenet_config + diffusion_config) as read by
+ * diffusion_models/diffwave_ddpm.py:395-411 create_diffwave_model(). */
+typedef struct dmad_config {
+    int32_t res_channels;       /* 256 (the only supported value)       */
+    int32_t skip_channels;      /* 256                                   */
+    int32_t num_res_layers;     /* <= 64; 36 in the reference            */
+    int32_t dilation_cycle;     /* <= 12 (max dilation 2048)             */
+    int32_t embed_dim_in;       /* 128 */
+    int32_t embed_dim_mid;      /* 512 */
+    int32_t embed_dim_out;      /* 512 */
+    int32_t clip_len;           /* 16000; must be a multiple of 128      */
+    int32_t max_batch;          /* clips resident per pass               */
+    int32_t num_classes;        /* 10  */
+    int32_t precision;          /* enum dmad_precision                   */
+    int32_t with_classifier;    /* 1: VGG19_bn + mel front-end buffers   */
+} dmad_config;
+
+int dmad_create(const dmad_config* cfg, dmad_engine** out);
+void dmad_destroy(dmad_engine* e);
+const char* dmad_last_error(void);
+const char* dmad_version(void);
+
+/* Weights arrive as FOLDED fp32 host arrays (weight-norm and eval BatchNorm already folded by the
+ * Python loader, exactly as the reference's modules compute them on every forward:
+ * DiffWave_Unconditional/WaveNet.py:27-28,66-72; models/vgg.py:69-81).  Names:
+ *   init.w[256] init.b[256]  fc_t1.w[512,128] fc_t1.b  fc_t2.w[512,512] fc_t2.b
+ *   fc_t.{n}.w[256,512] fc_t.{n}.b   dil.{n}.w[512,256,3] dil.{n}.b   res.{n}.w[256,256] res.{n}.b
+ *   skip.{n}.w[256,256] skip.{n}.b   f0.w[256,256] f0.b   f2.w[256] f2.b[1]
+ *   vgg.conv{i}.w[cout,cin,3,3] vgg.conv{i}.scale[cout] vgg.conv{i}.shift[cout]  (i = 0..15)
+ *   vgg.fc{j}.w[out,in] vgg.fc{j}.b   (j = 0..2)
+ * dmad_finalize_weights() packs them into the MFMA/LDS layouts and uploads them. */
+int dmad_load_weight(dmad_engine* e, const char* name, const float* host, const int64_t* shape, int32_t ndim);
+int dmad_finalize_weights(dmad_engine* e);
+
+/* eps = WaveNet((x_t, t * ones))  — DiffWave.model(...) at diffwave_ddpm.py:157-158,169-170,177-178
+ * (WaveNet_Speech_Commands.forward, WaveNet.py:164-172).  x_t, eps: device fp32 [B][clip_len]. */
+int dmad_wavenet_eps(dmad_engine* e, const float* x_t, int32_t t, int32_t B, float* eps, dmad_stream s);
+
+/* x0_hat = c_a * x_t - c_b * eps(x_t, t)  — DiffWave.one_shot_denoise, diffwave_ddpm.py:174-182,195-205.
+ * c_a = sqrt(1/Alpha_bar)[t], c_b = sqrt(1/Alpha_bar - 1)[t] are computed by the caller in fp32
+ * exactly as the reference does (tables on the CPU, then indexed). */
+int dmad_one_shot(dmad_engine* e, const float* x_t, int32_t t, float c_a, float c_b, int32_t B, float* x0, dmad_stream s);
+
+/* One reverse step  x <- (x - c_eps * eps(x, t)) / c_div (+ c_sig * z)  — DiffWave.compute_coefficients
+ * + the loop body of DiffWave._reverse, diffwave_ddpm.py:95-102,143-164.  z: device fp32 [B][L] noise
+ * supplied by the caller, or NULL to draw Philox N(0,1) keyed (seed, sample0 + b, stream = 1 + t);
+ * pass c_sig = 0 for the t == 0 step. */
+int dmad_ddpm_step(dmad_engine* e, float* x, int32_t t, float c_eps, float c_div, float c_sig, const float* z,
+                   uint64_t seed, uint64_t sample0, int32_t B, dmad_stream s);
+
+/* x_t = c_a * x0 + c_b * z  — DiffWave._diffusion, diffwave_ddpm.py:49-73 (z as above, stream 0xD1FF). */
+int dmad_diffuse(dmad_engine* e, const float* x0, float c_a, float c_b, const float* z, uint64_t seed,
+                 uint64_t sample0, int32_t B, float* x_t, dmad_stream s);
+
+/* spec = AmplitudeToDB('power')(MelSpectrogram(n_fft=2048, hop=512, n_mels=32, slaney)(x))
+ * — the Wave2Spect transform built at certified_robustness_eval.py:85-87.  x: [B][clip_len],
+ * spec: [B][32 mel][32 frames] fp32. */
+int dmad_mel_db(dmad_engine* e, const float* x, int32_t B, float* spec, dmad_stream s);
+
+/* logits = VGG19_bn(spec)  — VGG.forward, audio_models/ConvNets_SpeechCommands/models/vgg.py:48-52.
+ * spec: [B][32][32] fp32, logits: [B][num_classes] fp32. */
+int dmad_classify(dmad_engine* e, const float* spec, int32_t B, float* logits, dmad_stream s);
+
+/* The Monte Carlo loop of RobustCertificate.smooth_predict (+ forward, compute_t_star's result),
+ * robustness_eval/certified_robust.py:17-31,33-67:  for samples i in [sample0, sample0 + n):
+ *   x_in = sqrt(alpha_bar_star) * (clip + delta_i);  x0 = one_shot(x_in, t);  logits = classifier(mel_db(x0));
+ *   counts[argmax logits] += 1.
+ * clip: device fp32 [clip_len].  delta: device fp32 [n][clip_len] (the reference's CPU torch.normal
+ * draws, parity mode) or NULL for on-device Philox noise keyed (seed, sample index).  counts: device
+ * int64[num_classes], ACCUMULATED into (zero it first).  logits_out: optional [n][num_classes].
+ * batch <= max_batch.  With with_classifier == 0, x0_out (optional, [n][clip_len]) receives the
+ * purified clips and the caller classifies them. */
+int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt_alpha_bar_star, int32_t t,
+                      float c_a, float c_b, int64_t n, int32_t batch, uint64_t seed, uint64_t sample0,
+                      const float* delta, int64_t* counts, float* logits_out, float* x0_out, dmad_stream s);
+
+/* counts[argmax_c logits[b][c]] += 1 (first maximum wins) — certified_robust.py:59-65. */
+int dmad_vote(dmad_engine* e, const float* logits, int32_t B, int64_t* counts, dmad_stream s);
+
+/* Test hooks: raw Philox4x32-10 words / N(0,1) draws of the generator used above. */
+int dmad_philox_raw(dmad_engine* e, uint64_t seed, uint64_t sample, uint32_t stream, uint32_t nblocks, uint32_t* out, dmad_stream s);
+int dmad_philox_normal(dmad_engine* e, uint64_t seed, uint64_t sample0, uint32_t stream, int32_t B, float* z, dmad_stream s);
+
+/* Timing hook for bench.py: runs `iters` launches of residual layer `layer` (bf16 path) on the resident
+ * buffers between two HIP events recorded on `s` and returns the average milliseconds per launch. */
+int dmad_time_layer(dmad_engine* e, int32_t layer, int32_t B, int32_t iters, float* ms_per_launch, dmad_stream s);
+
+/* Bytes of device memory held by the engine. */
+int64_t dmad_device_bytes(const dmad_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMAD_H */

