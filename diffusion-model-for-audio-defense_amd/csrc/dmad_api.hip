@@ -70,6 +70,10 @@ struct dmad_engine {
     std::vector<void*> allocs;
     int64_t bytes = 0;
     int emb_t = -1;
+    // optional per-launch timing of the dominant kernel (bench.py roofline): HIP event pairs on the launch stream
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    size_t prof_used = 0;
 
     // WaveNet small fp32 params
     float *init_w = nullptr, *init_b = nullptr, *fc1w = nullptr, *fc1b = nullptr, *fc2w = nullptr, *fc2b = nullptr;
@@ -350,7 +354,10 @@ int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipS
             a.emb_next = e->emb_table + (size_t)((n + 1 < NL) ? n + 1 : n) * 256;
             a.dilation = 1 << (n % e->cfg.dilation_cycle);
             a.L = L; a.LP = LP; a.last = (n == NL - 1);
+            const bool timed = e->prof_on && !a.last && e->prof_used + 2 <= e->prof_ev.size();
+            if (timed) (void)hipEventRecord(e->prof_ev[e->prof_used++], s);
             launch_wn_layer_bf16(a, B, s);
+            if (timed) (void)hipEventRecord(e->prof_ev[e->prof_used++], s);
         }
         WnFinalArgs f{};
         f.g = e->gstore; f.wsp = e->wsp; f.wf0p = e->wf0p; f.bskip_sum = e->bskip_sum; f.bf0 = e->bf0; f.wz = e->wz;
@@ -497,11 +504,41 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
 
 void dmad_destroy(dmad_engine* e) {
     if (!e) return;
+    for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
 }
 
 int64_t dmad_device_bytes(const dmad_engine* e) { return e ? e->bytes : 0; }
+
+int dmad_profile_layers(dmad_engine* e, int32_t max_launches) {
+    if (!e || max_launches < 0) return fail(DMAD_ERR_INVALID, "bad argument");
+    e->prof_used = 0;
+    e->prof_on = max_launches > 0;
+    while (e->prof_ev.size() < (size_t)max_launches * 2) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreate(&ev));
+        e->prof_ev.push_back(ev);
+    }
+    return 0;
+}
+
+int dmad_profile_read(dmad_engine* e, float* total_ms, int32_t* launches) {
+    if (!e || !total_ms || !launches) return fail(DMAD_ERR_INVALID, "null argument");
+    double tot = 0.0;
+    const size_t pairs = e->prof_used / 2;
+    if (pairs) HIPCHK(hipEventSynchronize(e->prof_ev[e->prof_used - 1]));
+    for (size_t i = 0; i < pairs; ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]));
+        tot += ms;
+    }
+    *total_ms = (float)tot;
+    *launches = (int32_t)pairs;
+    e->prof_used = 0;
+    e->prof_on = false;
+    return 0;
+}
 
 int dmad_load_weight(dmad_engine* e, const char* name, const float* host, const int64_t* shape, int32_t ndim) {
     if (!e || !name || !host || !shape || ndim < 1 || ndim > 4) return fail(DMAD_ERR_INVALID, "bad argument to dmad_load_weight");

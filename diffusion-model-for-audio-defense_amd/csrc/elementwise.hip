@@ -262,7 +262,8 @@ __global__ void mel_db_kernel(const float* __restrict__ M, float* __restrict__ s
     const long b = i >> 10;
     const int mel = (int)((i >> 5) & 31), fr = (int)(i & 31);
     const float v = fmaxf(M[(b * 32 + fr) * 32 + mel], 1e-10f);
-    spec[i] = 10.f * log10f(v);
+    // fp32 log10 rounded from a double evaluation (10*log10(1e-10f) must be exactly -100 like on the CPU)
+    spec[i] = __fmul_rn(10.f, (float)log10((double)v));
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -42,6 +42,8 @@ _SIGNATURES = {
     'dmad_philox_normal': (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int32, _P, _P]),
     'dmad_time_layer': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), _P]),
     'dmad_device_bytes': (C.c_int64, [_P]),
+    'dmad_profile_layers': (C.c_int, [_P, C.c_int32]),
+    'dmad_profile_read': (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

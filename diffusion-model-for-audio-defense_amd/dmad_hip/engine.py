@@ -246,6 +246,15 @@ class Engine:
         check(self.lib.dmad_time_layer(self._h, int(layer), int(B), int(iters), C.byref(ms), _stream()))
         return float(ms.value)
 
+    def profile_layers(self, max_launches: int):
+        check(self.lib.dmad_profile_layers(self._h, int(max_launches)))
+
+    def profile_read(self):
+        """-> (summed ms, launches) of the bracketed wn_layer_bf16 launches."""
+        ms, n = C.c_float(0), C.c_int32(0)
+        check(self.lib.dmad_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
     def device_bytes(self) -> int:
         return int(self.lib.dmad_device_bytes(self._h))
 

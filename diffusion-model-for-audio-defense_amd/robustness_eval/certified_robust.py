@@ -65,6 +65,8 @@ class RobustCertificate():
         return self.classifier(x_in)
 
     def _seed_for_call(self):
+        if self.noise_source != 'device':
+            return 0                            # the CPU generator must not be touched before the torch.normal draws
         if self.seed is not None:
             s = (int(self.seed) * 1000003 + self._calls) & 0xFFFFFFFFFFFFFFFF
         else:                                   # governed by torch.manual_seed, identical on every rank only

@@ -63,7 +63,8 @@ const char* dmad_version(void);
  *   skip.{n}.w[256,256] skip.{n}.b   f0.w[256,256] f0.b   f2.w[256] f2.b[1]
  *   vgg.conv{i}.w[cout,cin,3,3] vgg.conv{i}.scale[cout] vgg.conv{i}.shift[cout]  (i = 0..15)
  *   vgg.fc{j}.w[out,in] vgg.fc{j}.b   (j = 0..2)
- * dmad_finalize_weights() packs them into the MFMA/LDS layouts and uploads them. */
+ * dmad_finalize_weights() packs whichever complete set (WaveNet, classifier) has been loaded and is not
+ * packed yet into the MFMA/LDS layouts and uploads it; it may be called once per set. */
 int dmad_load_weight(dmad_engine* e, const char* name, const float* host, const int64_t* shape, int32_t ndim);
 int dmad_finalize_weights(dmad_engine* e);
 
@@ -119,6 +120,14 @@ int dmad_philox_normal(dmad_engine* e, uint64_t seed, uint64_t sample0, uint32_t
 /* Timing hook for bench.py: runs `iters` launches of residual layer `layer` (bf16 path) on the resident
  * buffers between two HIP events recorded on `s` and returns the average milliseconds per launch. */
 int dmad_time_layer(dmad_engine* e, int32_t layer, int32_t B, int32_t iters, float* ms_per_launch, dmad_stream s);
+
+/* Live timing of the dominant kernel (the fused residual layer, wn_layer_bf16) for bench.py's roofline:
+ * after dmad_profile_layers(e, max_launches > 0) every non-final layer launch of the bf16 path is
+ * bracketed by a HIP event pair recorded on the launch stream (until max_launches pairs are used);
+ * dmad_profile_read() waits for the last pair, returns the summed elapsed milliseconds and the number of
+ * launches, and switches the bracketing off. */
+int dmad_profile_layers(dmad_engine* e, int32_t max_launches);
+int dmad_profile_read(dmad_engine* e, float* total_ms, int32_t* launches);
 
 /* Bytes of device memory held by the engine. */
 int64_t dmad_device_bytes(const dmad_engine* e);

@@ -374,3 +374,46 @@ class CertifyOracle:
                 y_pred[i] = -1
                 radius[i] = 0
         return y_pred, radius
+
+
+# --------------------------------------------------------------------------------------
+# Philox4x32-10 (Salmon et al., SC'11) — integer restatement used to pin the device generator
+# --------------------------------------------------------------------------------------
+
+def philox4x32_10(counter: np.ndarray, key: np.ndarray) -> np.ndarray:
+    """counter [..., 4] uint32, key [2] uint32 -> [..., 4] uint32 (bit-exact reference)."""
+    c = np.array(counter, dtype=np.uint64, copy=True)
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = M0 * c[..., 0]
+        p1 = M1 * c[..., 2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[..., 1] ^ k0) & mask
+        n1 = p1 & mask
+        n2 = ((p0 >> np.uint64(32)) ^ c[..., 3] ^ k1) & mask
+        n3 = p0 & mask
+        c = np.stack([n0, n1, n2, n3], axis=-1)
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return c.astype(np.uint32)
+
+
+def philox_counters(seed: int, sample: int, stream: int, nblocks: int):
+    ctr = np.zeros((nblocks, 4), dtype=np.uint32)
+    ctr[:, 0] = np.arange(nblocks, dtype=np.uint32)
+    ctr[:, 1] = sample & 0xFFFFFFFF
+    ctr[:, 2] = (sample >> 32) & 0xFFFFFFFF
+    ctr[:, 3] = stream
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
+    return ctr, key
+
+
+def philox_normal(seed: int, sample: int, stream: int, length: int) -> np.ndarray:
+    """The device's Box-Muller on top of Philox words, in float64 (tolerance check only)."""
+    ctr, key = philox_counters(seed, sample, stream, length // 4)
+    w = philox4x32_10(ctr, key).astype(np.float64)
+    u = (np.floor(w / 256.0) + 0.5) * 2.0 ** -24
+    r0, r1 = np.sqrt(-2 * np.log(u[:, 0])), np.sqrt(-2 * np.log(u[:, 2]))
+    a0, a1 = 2 * np.pi * u[:, 1], 2 * np.pi * u[:, 3]
+    return np.stack([r0 * np.cos(a0), r0 * np.sin(a0), r1 * np.cos(a1), r1 * np.sin(a1)], 1).reshape(-1)
