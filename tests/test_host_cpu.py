@@ -1,0 +1,223 @@
+"""CPU-side tests (-m "not gpu"): C-ABI surface, host logic of the reference-named Python mirrors,
+checkpoint loaders, and the multi-process (gloo, world_size 2) vote sharding."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from dmad_hip import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'diffusion-model-for-audio-defense_amd')
+LIB = os.path.join(PKG, 'libdmad_hip.so')
+
+
+@pytest.fixture(scope='module')
+def built_lib():
+    if not os.path.exists(LIB):
+        subprocess.run(['make', '-C', os.path.join(PKG, 'csrc'), '-j4'], check=True)
+    return ctypes.CDLL(LIB)
+
+
+def test_c_abi_exports_every_declared_symbol(built_lib):
+    hdr = open(os.path.join(ROOT, 'include', 'dmad.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(dmad_[a-z_0-9]+)\s*\(', hdr))
+    assert len(declared) >= 20
+    from dmad_hip import _lib
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(built_lib, name), name
+
+
+def test_c_abi_fails_loudly_without_gpu(built_lib):
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from dmad_hip import _lib, engine
+    with pytest.raises(_lib.DmadError):
+        engine.Engine(max_batch=1)                        # python wrapper refuses: no CPU path
+    lib = _lib.load()
+    cfg = _lib.DmadConfig(256, 256, 36, 12, 128, 512, 512, 16000, 1, 10, 0, 1)
+    h = ctypes.c_void_p()
+    rc = lib.dmad_create(ctypes.byref(cfg), ctypes.byref(h))
+    assert rc == -3 and lib.dmad_last_error()             # DMAD_ERR_HIP with a message
+    bad = _lib.DmadConfig(128, 256, 36, 12, 128, 512, 512, 16000, 1, 10, 0, 1)
+    assert lib.dmad_create(ctypes.byref(bad), ctypes.byref(h)) == -1
+    assert b'256' in lib.dmad_last_error()
+
+
+def test_lds_layouts_are_bank_conflict_free():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'lds_bank_check.py')], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+
+
+def test_schedule_mirror_bit_exact_and_t_star(golden_dir):
+    from diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    from robustness_eval.certified_robust import RobustCertificate
+    z = np.load(os.path.join(golden_dir, 'schedule.npz'))
+    hp = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    for k in ('Beta', 'Alpha', 'Alpha_bar', 'Sigma'):
+        assert np.array_equal(hp[k].numpy(), z[k])
+
+    class D:
+        diffusion_hyperparams = hp
+    rc = RobustCertificate(classifier=None, denoiser=D())
+    for s, t in zip(z['sigmas'], z['t_star']):
+        assert rc.compute_t_star(1 / (1 + float(s) ** 2)) == int(t)
+
+
+def test_lower_conf_bound_known_answers(golden_dir):
+    from robustness_eval.certified_robust import RobustCertificate
+    rc = RobustCertificate(classifier=None)
+    for r in json.load(open(os.path.join(golden_dir, 'clopper_pearson.json'))):
+        assert abs(rc.lower_conf_bound(r['k'], r['n'], r['alpha']) - r['pa']) < 1e-12
+    assert rc.lower_conf_bound(0, 100) == 0.0
+    assert rc.lower_conf_bound(torch.tensor(990), 1000) == pytest.approx(0.976036, abs=1e-5)
+
+
+class _ToyClassifier(torch.nn.Module):
+    """deterministic raw-waveform classifier for host-logic tests (no HIP involved)."""
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(1)
+        self.w = torch.randn(16000, 10, generator=g) * 0.05
+
+    def forward(self, x):
+        return x.reshape(x.shape[0], -1) @ self.w
+
+
+def test_randsmooth_host_logic_matches_oracle_cpu():
+    """denoiser=None ('randsmooth' mode of certified_robustness_eval.py:94-95) runs without the engine."""
+    from oracle import dmad_oracle as orc
+    from robustness_eval.certified_robust import RobustCertificate
+    clf = _ToyClassifier()
+    x = torch.from_numpy(synth.synthetic_clip(0))
+    rc = RobustCertificate(classifier=clf, transform=None, denoiser=None, noise_source='torch_cpu')
+    torch.manual_seed(5)
+    got = rc.smooth_predict(x, num_sampling=70, sigma=0.5, batch_size=16)
+    torch.manual_seed(5)
+    ref = orc.CertifyOracle(clf, None, None).smooth_predict(x, num_sampling=70, sigma=0.5, batch_size=16)
+    assert got.dtype == torch.int64 and got.tolist() == ref.tolist() and int(got.sum()) == 70
+    torch.manual_seed(6)
+    yp, rad = rc.certify(x[None], torch.tensor([1]), sigma=0.5, n_0=20, n=50, batch_size=16)
+    torch.manual_seed(6)
+    yr, rr = orc.CertifyOracle(clf, None, None).certify(x[None], torch.tensor([1]), sigma=0.5, n_0=20, n=50, batch_size=16)
+    assert yp.tolist() == yr.tolist() and torch.allclose(rad, rr)
+    with pytest.raises(AssertionError):
+        rc.smooth_predict(torch.zeros(2, 16000), 4, 0.5, 4)
+
+
+def _gloo_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path[:0] = [PKG, ROOT]
+    from robustness_eval.certified_robust import RobustCertificate
+    rc = RobustCertificate(classifier=_ToyClassifier(), transform=None, denoiser=None, noise_source='torch_cpu')
+    torch.manual_seed(5)
+    counts = rc.smooth_predict(torch.from_numpy(synth.synthetic_clip(0)), num_sampling=70, sigma=0.5, batch_size=16)
+    if rank == 0:
+        torch.save(counts, out)
+    dist.destroy_process_group()
+
+
+def test_vote_sharding_world_size_2_gloo(tmp_path):
+    """N samples sharded over 2 ranks + one all_reduce == the single-process counts."""
+    import torch.multiprocessing as mp
+    from robustness_eval.certified_robust import RobustCertificate
+    out = str(tmp_path / 'counts.pt')
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_gloo_worker, args=(2, port, out), nprocs=2, join=True)
+    sharded = torch.load(out)
+    rc = RobustCertificate(classifier=_ToyClassifier(), transform=None, denoiser=None, noise_source='torch_cpu')
+    torch.manual_seed(5)
+    single = rc.smooth_predict(torch.from_numpy(synth.synthetic_clip(0)), num_sampling=70, sigma=0.5, batch_size=16)
+    assert sharded.tolist() == single.tolist()
+
+
+def test_acoustic_system_semantics():
+    from acoustic_system import AcousticSystem
+    calls = []
+
+    class Def(torch.nn.Module):
+        def forward(self, x):
+            calls.append('def'); return x * 2
+
+    sys_ = AcousticSystem(classifier=lambda s: s.sum(-1), transform=lambda w: w + 1, defender=Def(), defense_type='wave')
+    x = torch.full((2, 1, 4), 0.25)
+    assert torch.allclose(sys_(x), torch.full((2, 1), 6.0)) and calls == ['def']
+    assert torch.allclose(sys_(x, defend=False), torch.full((2, 1), 5.0))
+    big = torch.tensor([[[20000.0, -20000.0, 0.0, 0.0]]])
+    assert torch.allclose(sys_(big, defend=False), (big / 2 ** 15 + 1).sum(-1))     # int16-range rescale
+    with pytest.raises(NotImplementedError):
+        AcousticSystem(None, None, None, defense_type='image')
+    spec = AcousticSystem(classifier=lambda s: s, transform=lambda w: w + 1, defender=Def(), defense_type='spec')
+    assert torch.allclose(spec(x), (x + 1) * 2)
+
+
+def test_create_model_checkpoint_layouts(tmp_path, golden_dir):
+    """whole-module pickles: bare M5 and DataParallel(VGG) under a 'ConvNets_SpeechCommands' path."""
+    from audio_models.ConvNets_SpeechCommands.create_model import create_model
+    import M5Net
+    from models.vgg import VGG, vgg19_bn
+    m5 = M5Net.M5(n_input=1, first_kernel_size=160, n_output=10, stride=16, n_channel=32)
+    m5.load_state_dict({k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, 'm5_k160_state.npz')).items()})
+    p = str(tmp_path / 'm5.pth')
+    torch.save(m5.double().train(), p)
+    got = create_model(p)
+    assert isinstance(got, M5Net.M5) and not got.training and next(got.parameters()).dtype == torch.float32
+    z = np.load(os.path.join(golden_dir, 'classifiers.npz'))
+    np.testing.assert_allclose(got(torch.from_numpy(z['wave_in'])).detach().numpy(), z['m5_logp'], rtol=1e-5, atol=1e-5)
+    d = tmp_path / 'ConvNets_SpeechCommands'
+    d.mkdir()
+    net = vgg19_bn(num_classes=10, in_channels=1)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.vgg19_bn_state_dict(4321).items()})
+    p2 = str(d / 'vgg.pth')
+    torch.save(torch.nn.DataParallel(net), p2)
+    got = create_model(p2)
+    assert isinstance(got, VGG) and not got.training
+    assert set(got.state_dict()) == set(synth.vgg19_bn_state_dict(4321))
+    with pytest.raises(Exception):
+        got(torch.zeros(1, 1, 32, 32))                    # CPU tensor: the HIP module has no CPU path
+
+
+def test_weight_folding_matches_oracle():
+    from dmad_hip.engine import fold_vgg19_bn_state_dict, fold_wavenet_state_dict
+    from oracle import dmad_oracle as orc
+    sd = synth.wavenet_state_dict(1234)
+    f = fold_wavenet_state_dict(sd, 36)
+    w = orc.folded_weights(sd)
+    assert np.array_equal(f['dil.7.w'], w['dil.7.w'].numpy())
+    assert np.array_equal(f['res.35.w'], w['res.35.w'].numpy()[:, :, 0])
+    assert np.array_equal(f['init.w'], w['init.w'].numpy().reshape(256))
+    assert len(f) == 6 + 36 * 8 + 4
+    vsd = synth.vgg19_bn_state_dict(4321)
+    fv = fold_vgg19_bn_state_dict(vsd)
+    x = torch.randn(2, 64, 8, 8)
+    conv = torch.nn.functional.conv2d(x, torch.from_numpy(vsd['features.3.weight']), None, padding=1)
+    ref = torch.nn.functional.batch_norm(conv + torch.from_numpy(vsd['features.3.bias']).view(1, -1, 1, 1),
+                                         torch.from_numpy(vsd['features.4.running_mean']), torch.from_numpy(vsd['features.4.running_var']),
+                                         torch.from_numpy(vsd['features.4.weight']), torch.from_numpy(vsd['features.4.bias']), False, 0., 1e-5)
+    got = conv * torch.from_numpy(fv['vgg.conv1.scale']).view(1, -1, 1, 1) + torch.from_numpy(fv['vgg.conv1.shift']).view(1, -1, 1, 1)
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_wavenet_surface_rejects_unsupported_use():
+    from diffusion_models.diffwave_ddpm import WaveNetHIP
+
+    class FakeEngine:
+        def wavenet_eps(self, a, t):
+            return a[:, 0] * 0 + t
+    m = WaveNetHIP(FakeEngine())
+    x = torch.zeros(3, 1, 8)
+    assert torch.equal(m((x, 5 * torch.ones(3, 1))), torch.full((3, 1, 8), 5.0))
+    with pytest.raises(NotImplementedError):
+        m((x, torch.tensor([[1.0], [2.0], [1.0]])))       # per-row steps
+    with pytest.raises(NotImplementedError):
+        m((x.requires_grad_(), 5 * torch.ones(3, 1)))     # autograd
