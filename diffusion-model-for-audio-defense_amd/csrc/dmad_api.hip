@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -70,6 +71,7 @@ struct dmad_engine {
     std::vector<void*> allocs;
     int64_t bytes = 0;
     int emb_t = -1;
+    int layer_variant = 40;    // 40 = persistent production schedule (wn_layer.hip); DMAD_WN_VARIANT selects an A/B baseline
     // optional per-launch timing of the dominant kernel (bench.py roofline): HIP event pairs on the launch stream
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -77,7 +79,7 @@ struct dmad_engine {
 
     // WaveNet small fp32 params
     float *init_w = nullptr, *init_b = nullptr, *fc1w = nullptr, *fc1b = nullptr, *fc2w = nullptr, *fc2b = nullptr;
-    float *fctw = nullptr, *fctb = nullptr, *emb_table = nullptr, *emb2 = nullptr;
+    float *fctw = nullptr, *fctb = nullptr, *emb_table = nullptr, *emb2 = nullptr, *epi_c = nullptr;
     float *bf0 = nullptr, *wz = nullptr;
     float bz = 0.f;
     // bf16 path
@@ -183,7 +185,7 @@ int finalize_wavenet(dmad_engine* e) {
         memcpy(&fctb[(size_t)n * 256], bb.data(), 1024);
     }
     CHK(e->upload(&e->fctw, fctw)); CHK(e->upload(&e->fctb, fctb));
-    CHK(e->alloc(&e->emb_table, (size_t)NL * 256)); CHK(e->alloc(&e->emb2, 512));
+    CHK(e->alloc(&e->emb_table, (size_t)NL * 256)); CHK(e->alloc(&e->emb2, 512)); CHK(e->alloc(&e->epi_c, (size_t)NL * 256, true));
 
     if (e->bf16) {
         int rmap[512];
@@ -320,7 +322,8 @@ int finalize_classifier(dmad_engine* e) {
 
 int ensure_embed(dmad_engine* e, int t, hipStream_t s) {
     if (e->emb_t == t) return 0;
-    launch_embed_table((float)t, e->fc1w, e->fc1b, e->fc2w, e->fc2b, e->fctw, e->fctb, e->emb_table, e->emb2, e->NL, s);
+    launch_embed_table((float)t, e->fc1w, e->fc1b, e->fc2w, e->fc2b, e->fctw, e->fctb, e->emb_table, e->emb2, e->bf16 ? e->b2 : nullptr,
+                       e->bf16 ? e->epi_c : nullptr, e->NL, s);
     e->emb_t = t;
     return 0;
 }
@@ -352,11 +355,12 @@ int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipS
             a.b1 = e->b1p + (size_t)n * 512;
             a.b2 = e->b2 + (size_t)n * 256;
             a.emb_next = e->emb_table + (size_t)((n + 1 < NL) ? n + 1 : n) * 256;
+            a.epi_c = e->epi_c + (size_t)n * 256;
             a.dilation = 1 << (n % e->cfg.dilation_cycle);
             a.L = L; a.LP = LP; a.last = (n == NL - 1);
             const bool timed = e->prof_on && !a.last && e->prof_used + 2 <= e->prof_ev.size();
             if (timed) (void)hipEventRecord(e->prof_ev[e->prof_used++], s);
-            launch_wn_layer_bf16(a, B, s);
+            launch_wn_layer_bf16(a, B, s, e->layer_variant);
             if (timed) (void)hipEventRecord(e->prof_ev[e->prof_used++], s);
         }
         WnFinalArgs f{};
@@ -466,6 +470,7 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     e->L = cfg->clip_len; e->LP = cfg->clip_len + 2 * kPad; e->NL = cfg->num_res_layers; e->maxB = cfg->max_batch;
     e->LPm = cfg->clip_len + 2048;
     e->bf16 = cfg->precision == DMAD_BF16;
+    if (const char* v = getenv("DMAD_WN_VARIANT")) e->layer_variant = atoi(v);
     const size_t B = e->maxB, L = e->L, LP = e->LP, NL = e->NL;
     int r = 0;
     do {
@@ -679,19 +684,41 @@ int dmad_time_layer(dmad_engine* e, int32_t layer, int32_t B, int32_t iters, flo
     WnLayerArgs a{};
     a.hin = e->hA; a.hout = e->hB; a.gout = e->gstore + (size_t)layer * B * e->L * kC;
     a.w1p = e->w1p + (size_t)layer * 24 * 512 * 32; a.w2p = e->w2p + (size_t)layer * 8 * 256 * 32;
-    a.b1 = e->b1p + (size_t)layer * 512; a.b2 = e->b2 + (size_t)layer * 256; a.emb_next = e->emb_table;
+    a.b1 = e->b1p + (size_t)layer * 512; a.b2 = e->b2 + (size_t)layer * 256; a.emb_next = e->emb_table; a.epi_c = e->epi_c;
     a.dilation = 1 << (layer % e->cfg.dilation_cycle); a.L = e->L; a.LP = e->LP; a.last = 0;
+    const char* ev = getenv("DMAD_LAYER_VARIANT");        // development only: timing-only ablations of the kernel
+    const int variant = ev ? atoi(ev) : e->layer_variant;
+    unsigned long long* dbg = nullptr;
+    const size_t nblk = (size_t)B * (e->L / kTileT);
+    if (variant == 11 || variant == 21 || variant == 31 || variant == 41) {
+        HIPCHK(hipMalloc((void**)&dbg, nblk * 8 * sizeof(unsigned long long)));
+        a.dbg = dbg;
+    }
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    launch_wn_layer_bf16(a, B, st);
+    launch_wn_layer_bf16(a, B, st, variant);
     HIPCHK(hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) launch_wn_layer_bf16(a, B, st);
+    for (int i = 0; i < iters; ++i) launch_wn_layer_bf16(a, B, st, variant);
     HIPCHK(hipEventRecord(e1, st));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *ms_per_launch = ms / iters;
+    if (dbg) {      // diagnostic: mean phase lengths in shader cycles (s_memtime), printed to stderr
+        std::vector<unsigned long long> h(nblk * 8);
+        HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double sum[7] = {0};
+        if (variant == 41) {   // persistent kernel: per-WG phase sums over all its tiles, 256 WGs
+            for (size_t i = 0; i < 256 && i < nblk; ++i)
+                for (int k = 0; k < 6; ++k) sum[k + 1] += (double)h[i * 8 + k];
+        } else
+        for (size_t i = 0; i < nblk; ++i)
+            for (int k = 1; k < 7; ++k) sum[k] += (double)(h[i * 8 + k] - h[i * 8 + k - 1]);
+        fprintf(stderr, "[dmad stamps] prologue %.0f | gemm1 %.0f | gate %.0f | barrier %.0f | gemm2 %.0f | epilogue %.0f  (mean cycles per tile, %zu tiles)\n",
+                sum[1] / nblk, sum[2] / nblk, sum[3] / nblk, sum[4] / nblk, sum[5] / nblk, sum[6] / nblk, nblk);
+        (void)hipFree(dbg);
+    }
     return 0;
 }
 

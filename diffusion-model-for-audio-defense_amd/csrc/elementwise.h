@@ -9,7 +9,7 @@ void launch_philox_normal(uint64_t seed, uint64_t sample0, uint32_t stream, floa
 void launch_mc_noise_scale(const float* clip, const float* delta, float sigma, float scale, uint64_t seed, uint64_t sample0,
                            float* xt, int B, int L, hipStream_t s);
 void launch_embed_table(float t, const float* w1, const float* b1, const float* w2, const float* b2, const float* wt,
-                        const float* bt, float* table, float* emb2_out, int NL, hipStream_t s);
+                        const float* bt, float* table, float* emb2_out, const float* b_res, float* epi_c, int NL, hipStream_t s);
 void launch_lincomb(int op, const float* x, const float* y, const float* z, float c0, float c1, float c2, float* out, long n,
                     hipStream_t s);
 void launch_wn_init_f32(const float* x, const float* w, const float* bias, const float* emb0, float* h, int B, int L, int LP,

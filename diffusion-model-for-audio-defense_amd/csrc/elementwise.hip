@@ -89,7 +89,8 @@ __global__ void mc_noise_scale_kernel(const float* __restrict__ clip, const floa
 __global__ void __launch_bounds__(512) embed_table_kernel(float t, const float* __restrict__ w1, const float* __restrict__ b1,
                                                           const float* __restrict__ w2, const float* __restrict__ b2,
                                                           const float* __restrict__ wt, const float* __restrict__ bt,
-                                                          float* __restrict__ table, float* __restrict__ emb2_out) {
+                                                          float* __restrict__ table, float* __restrict__ emb2_out,
+                                                          const float* __restrict__ b_res, float* __restrict__ epi_c) {
     __shared__ float e0[128], e1[512], e2[512];
     const int tid = threadIdx.x, n = blockIdx.x;
     if (tid < 64) {
@@ -118,7 +119,10 @@ __global__ void __launch_bounds__(512) embed_table_kernel(float t, const float* 
         const float* w = wt + ((long)n * 256 + tid) * 512;
         float s = 0.f;
         for (int k = 0; k < 512; ++k) s = fmaf(w[k], e2[k], s);
-        table[n * 256 + tid] = s + bt[n * 256 + tid];
+        const float v = s + bt[n * 256 + tid];
+        table[n * 256 + tid] = v;
+        // epilogue constant of layer n-1 (bf16 path): b_res_{n-1} * sqrt(1/2) + fc_t_n(emb)
+        if (epi_c && n > 0) epi_c[(n - 1) * 256 + tid] = fmaf(b_res[(n - 1) * 256 + tid], 0.70710678118654752440f, v);
     }
 }
 
@@ -339,8 +343,8 @@ void launch_mc_noise_scale(const float* clip, const float* delta, float sigma, f
                        seed, sample0, xt, B, L);
 }
 void launch_embed_table(float t, const float* w1, const float* b1, const float* w2, const float* b2, const float* wt,
-                        const float* bt, float* table, float* emb2_out, int NL, hipStream_t s) {
-    hipLaunchKernelGGL(embed_table_kernel, dim3(NL), dim3(512), 0, s, t, w1, b1, w2, b2, wt, bt, table, emb2_out);
+                        const float* bt, float* table, float* emb2_out, const float* b_res, float* epi_c, int NL, hipStream_t s) {
+    hipLaunchKernelGGL(embed_table_kernel, dim3(NL), dim3(512), 0, s, t, w1, b1, w2, b2, wt, bt, table, emb2_out, b_res, epi_c);
 }
 void launch_lincomb(int op, const float* x, const float* y, const float* z, float c0, float c1, float c2, float* out, long n,
                     hipStream_t s) {

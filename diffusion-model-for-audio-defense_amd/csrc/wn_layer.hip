@@ -1,0 +1,387 @@
+// wn_layer_bf16_p — the residual-layer kernel of the bf16 path (persistent form).
+//
+// Math, operand orientation and HBM/LDS layouts are those documented at the top of wn_bf16.hip
+// (Residual_block.forward, DiffWave_Unconditional/WaveNet.py:75-97).  This file holds the production
+// schedule; the earlier schedules in wn_bf16.hip are kept only as A/B baselines for tools/gpu_ablate.py.
+//
+// One workgroup (8 waves, 1 per CU) walks over time tiles  tile = blockIdx.x + i * gridDim.x.
+// Per tile (128 time samples of one clip, all 512 gate rows):
+//   GEMM1   24 k-steps of 32 through a 3-slot LDS ring (slot = 32 KiB weights + 8 KiB activations);
+//           the global_load_lds pieces of k-step ks+3 and the fragment ds_reads of k-step ks+1 are
+//           spread between the 32 MFMAs of k-step ks (the CU's vector-memory path moves 64 B/clk, so a
+//           40 KiB stage occupies it for ~640 of the k-step's 1024 matrix cycles);
+//           counted vmcnt, one barrier per k-step, nothing drained inside the loop.
+//   gate    tanh*sigmoid in fp32 registers -> bf16 tile [128 t][256 ch] in LDS (over ring slot C).
+//   GEMM2   res conv, 8 weight stages through six 16 KiB buffers (stages 0-5 land under the gate math).
+//   epi     two 64-row halves through a 65 KiB fp32 LDS tile; h' = (h + res) * sqrt(1/2) + emb_{n+1}.
+//   While the epilogue runs, stages 0-1 of the NEXT tile are already in flight into ring slots A/B (the
+//   epilogue tile only covers [0, 65 KiB)), so the next tile starts without an exposed load latency.
+//
+// LDS map (160 KiB): ring slot A = [80K,120K), B = [120K,160K), C = [0,40K); gate tile [0,64K);
+// GEMM2 weight buffers 5 x 16 KiB at [80K,160K); epilogue half tile [0, 65K); pre-scaled dilated-conv
+// bias (2 KiB) at [65K, 67K) — written once per kernel, never overwritten: the accumulators start from
+// zero and the bias enters as the addend of the gate's exp2-argument FMA.
+// The DMA pieces are issued from inline asm (saddr form) and waited for with explicit counted s_waitcnt;
+// hipcc does not count them.  The few ordinary loads of the tile loop (bias, residual rows, epilogue
+// constant) are therefore issued only where NO DMA is in flight (right after a vmcnt(0) barrier) and are
+// retired by an explicit builtin wait before the next DMA-heavy phase, so that hipcc never inserts a
+// (too small) vmcnt wait of its own that would drain the prefetches.
+#include "dmad_common.h"
+#include "wn_bf16.h"
+
+namespace dmad {
+
+namespace {
+
+constexpr int SLOT_BOFF = 32768;
+constexpr int GEMM2_BUF = 81920;
+constexpr int CONST_OFF = 66560;
+constexpr float kGateKt = -2.8853900817779268f, kGateKs = -1.4426950408889634f;   // -2*log2(e), -log2(e)
+constexpr int EPI_PITCH = 1040;
+__device__ __forceinline__ constexpr int slot_base(int i) { return i == 0 ? 81920 : (i == 1 ? 122880 : 0); }
+
+// s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier — through the builtins so that hipcc's wait-count bookkeeping
+// sees them (an asm wait is invisible to it and it would re-wait lgkmcnt(0) AFTER the next k-step's
+// fragment reads have been issued).  vmcnt is 6 bits: [3:0] and [15:14].
+#define WNL_WAIT_BARRIER(N)                                                         \
+    do {                                                                            \
+        asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");                       \
+        __builtin_amdgcn_s_waitcnt(0x0070 | ((N) & 15) | (((N) >> 4) << 14));       \
+        __builtin_amdgcn_s_barrier();                                               \
+        asm volatile("" ::: "memory");                                              \
+    } while (0)
+#define WNL_BARRIER_LGKM()                                                          \
+    do {                                                                            \
+        asm volatile("" ::: "memory");                                              \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                         \
+        __builtin_amdgcn_s_barrier();                                               \
+        asm volatile("" ::: "memory");                                              \
+    } while (0)
+
+// LDS-DMA in its saddr form, written as asm because hipcc otherwise materialises a 64-bit VGPR address per
+// piece (and hoists ~150 of them out of the tile loop).  sbase: wave-uniform 64-bit base (SGPR pair), voff:
+// 32-bit lane offset, lds: wave-uniform LDS byte address (the hardware adds lane*16).  M0 is written in the
+// same statement that uses it.  hipcc does not count these loads: every wait on them is an explicit
+// s_waitcnt in WNL_WAIT_BARRIER below.
+__device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// tanh(a + ba) * sigmoid(b + bb) with 2 v_exp + 1 v_rcp:  u = e^{-2(a+ba)}, v = e^{-(b+bb)}:
+// (1-u) / ((1+u)(1+v)); bta = -2*log2(e)*ba and bsb = -log2(e)*bb come pre-scaled from LDS.
+__device__ __forceinline__ float gate_fn(float a, float b, float bta, float bsb) {
+    const float u = fast_exp2(fminf(fmaf(a, kGateKt, bta), 30.f));
+    const float v = fast_exp2(fminf(fmaf(b, kGateKs, bsb), 30.f));
+    const float p = 1.f + u;
+    return (1.f - u) * fast_rcp(fmaf(p, v, p));
+}
+
+}  // namespace
+
+template <bool LAST, bool STAMP = false>
+__global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int ntiles) {
+    // STAMP: diagnostic build only (per-phase cycle sums of wave 0 into a.dbg[block][8]); never shipped/timed
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int k) {
+        if constexpr (STAMP) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (k >= 0) tacc[k] += now - tprev;
+            tprev = now;
+        }
+    };
+    auto flush = [&]() {
+        if constexpr (STAMP) {
+            if (threadIdx.x == 0)
+                for (int k = 0; k < 6; ++k) a.dbg[(size_t)blockIdx.x * 8 + k] = tacc[k];
+        }
+    };
+    stamp(-1);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int q = lane >> 4, r16 = lane & 15;
+    const int tiles_per_clip = a.L / kTileT;
+    const int brow = tid >> 2;
+    const int boff = brow * 512 + (((tid & 3) ^ swz64(brow)) * 16);
+    const ptrdiff_t tap_bytes = (ptrdiff_t)a.dilation * 512;
+    const unsigned tid16 = (unsigned)tid * 16u;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;       // LDS byte address of the dynamic segment
+    const char* w1b = (const char*)a.w1p;
+    const char* w2b = (const char*)a.w2p;
+    const int frag_off = r16 * 64 + ((q ^ swz64(r16)) * 16);
+
+    auto tile_rows = [&](int tile, int& b, int& t0) {
+        b = tile / tiles_per_clip;
+        t0 = (tile - b * tiles_per_clip) * kTileT;
+    };
+    auto hin_center = [&](int b, int t0) { return (const char*)(a.hin + ((size_t)b * a.LP + kPad + t0) * kC); };
+    // one DMA piece of GEMM1 stage ks: p < 4 -> 8 KiB of weights, p == 4 -> the 8 KiB activation slice
+    auto stage1_piece = [&](const char* hc, int ks, int p) {
+        const int sb = slot_base(ks % 3);
+        if (p < 4) dma16(w1b + ((size_t)ks * 32768 + p * 8192), tid16, lds0 + sb + wv * 1024 + p * 8192);
+        else dma16(hc + (((ks >> 3) - 1) * tap_bytes + (ks & 7) * 64), (unsigned)boff, lds0 + sb + SLOT_BOFF + wv * 1024);
+    };
+    auto stage1 = [&](const char* hc, int ks) {
+#pragma unroll
+        for (int p = 0; p < 5; ++p) stage1_piece(hc, ks, p);
+    };
+    auto stage2 = [&](int ks2, int buf) {
+        const char* wsrc = w2b + (size_t)ks2 * 16384;
+        const unsigned la = lds0 + GEMM2_BUF + buf * 16384 + wv * 1024;
+        dma16(wsrc, tid16, la);
+        dma16(wsrc + 8192, tid16, la + 8192);
+    };
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int b, t0;
+    tile_rows(tile, b, t0);
+    const char* hin_c = hin_center(b, t0);
+
+    // pre-scaled dilated-conv bias -> LDS (one float per thread = one per gate row), retired before any DMA
+    ((float*)(smem + CONST_OFF))[tid] = a.b1[tid] * (((tid & 127) < 64) ? kGateKt : kGateKs);
+    __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0)
+    f32x4 acc[8][4];
+    stage1(hin_c, 0);
+    stage1(hin_c, 1);
+    stage1(hin_c, 2);
+    bool first = true;
+
+    for (;;) {
+        // keep the loop-invariant DMA bases and lane offsets from being hoisted out of the tile loop (spills)
+        asm volatile("" : "+s"(w1b), "+s"(w2b));
+        int tidv = tid;
+        asm volatile("" : "+v"(tidv));
+        const int qv = (tidv & 63) >> 4, r16v = tidv & 15;     // per-tile copies of q / r16 for the post-GEMM1 address math
+        // ---------------- GEMM1 ------------------------------------------------------------------
+        // outstanding VMEM ops younger than stage 0: first tile / LAST: stages 1,2 (10);
+        // later tiles: stage 1 (5) + 8 h' stores + stage 2 (5) = 18
+        if (LAST || first) { WNL_WAIT_BARRIER(10); } else { WNL_WAIT_BARRIER(18); }
+        stamp(0);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 af[2][8], bf[2][4];
+        {
+            const char* A = smem + slot_base(0) + wm * 8192 + frag_off;
+            const char* Bt = smem + slot_base(0) + SLOT_BOFF + wn * 4096 + frag_off;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bf[0][nt] = *(const bf16x8*)(Bt + nt * 1024);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) af[0][mt] = *(const bf16x8*)(A + mt * 1024);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            // stage ks+1 landed; stage ks+2 (and, on a later tile's first step, 8 stores) may still fly
+            if (ks == 0) {
+                if (LAST || first) { WNL_WAIT_BARRIER(5); } else { WNL_WAIT_BARRIER(13); }
+            } else if (ks <= 21) { WNL_WAIT_BARRIER(5); }
+            else if (ks == 22) { WNL_WAIT_BARRIER(0); }
+            else { WNL_BARRIER_LGKM(); }                   // every wave holds its last fragments: ring free
+            const char* Ar = smem + slot_base((ks + 1) % 3) + wm * 8192 + frag_off;
+            const char* Br = smem + slot_base((ks + 1) % 3) + SLOT_BOFF + wn * 4096 + frag_off;
+#pragma unroll
+            for (int p = 0; p < 5; ++p) {                  // 5 x (1 DMA piece, 4 MFMAs)
+                if (ks + 3 < 24) {
+                    stage1_piece(hin_c, ks + 3, p);
+                } else if (!LAST && ks == 23) {            // GEMM2 weight stages 0-4 land under the gate math
+                    stage2(p, p);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 4 * p; i < 4 * p + 4; ++i)
+                    acc[i >> 2][i & 3] = mfma16(af[cur][i >> 2], bf[cur][i & 3], acc[i >> 2][i & 3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int p = 0; p < 12; ++p) {                 // 12 x (1 fragment read of k-step ks+1, 1 MFMA)
+                if (ks + 1 < 24) {
+                    if (p < 4) bf[nxt][p] = *(const bf16x8*)(Br + p * 1024);
+                    else af[nxt][p - 4] = *(const bf16x8*)(Ar + (p - 4) * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int i = 20 + p;
+                acc[i >> 2][i & 3] = mfma16(af[cur][i >> 2], bf[cur][i & 3], acc[i >> 2][i & 3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        stamp(1);
+        // ---------------- gate: g[ch][t] -> LDS [t][ch] bf16 at [0, 64K) -------------------------------
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 bt = *(const f32x4*)(smem + CONST_OFF + (wm * 128 + mt * 16 + qv * 4) * 4);
+            const f32x4 bs = *(const f32x4*)(smem + CONST_OFF + (wm * 128 + 64 + mt * 16 + qv * 4) * 4);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                bf16x4 gv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gv[r] = (bf16_t)gate_fn(acc[mt][nt][r], acc[mt + 4][nt][r], bt[r], bs[r]);
+                const int t = wn * 64 + nt * 16 + r16v;
+                const int chunk = wm * 8 + mt * 2 + (qv >> 1);
+                *(bf16x4*)(smem + t * 512 + ((chunk ^ r16v) * 16) + (qv & 1) * 8) = gv;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        int nb = 0, nt0 = 0;
+        if (has_next) tile_rows(next, nb, nt0);
+        const char* hin_n = hin_center(nb, nt0);
+        char* gdst = (char*)(a.gout + ((size_t)b * a.L + t0) * kC);
+
+        if constexpr (LAST) {
+            // the last layer's residual output is never consumed (WaveNet.py:131-135): only g leaves
+            WNL_BARRIER_LGKM();            // gate tile complete
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = it * 512 + tidv, t = idx >> 5, c = idx & 31;
+                *(uint4*)(gdst + (size_t)t * 512 + c * 16) = *(const uint4*)(smem + t * 512 + ((c ^ (t & 15)) * 16));
+            }
+            if (!has_next) return;
+            WNL_BARRIER_LGKM();            // every wave has read its part of the gate tile: slot C is free
+            stage1(hin_n, 0);
+            stage1(hin_n, 1);
+            stage1(hin_n, 2);
+        } else {
+            stamp(2);
+            WNL_WAIT_BARRIER(0);           // gate tile complete, GEMM2 stages 0-4 landed
+            stamp(3);
+
+            // residual rows + embedding for the epilogue: issued now, consumed after GEMM2
+            // ordinary loads + the gate-tile stores, issued while no DMA is in flight: epilogue constant, residual
+            // rows, then the 8 stores (so that hipcc's own count sees >= 4 younger ops behind the loads, see below)
+            const f32x4 e0 = *(const f32x4*)(a.epi_c + (tidv & 31) * 8);   // b_res * sqrt(1/2) + emb_{n+1}, this thread's 8 channels
+            const f32x4 e1 = *(const f32x4*)(a.epi_c + (tidv & 31) * 8 + 4);
+            bf16x8 hv[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = it * 512 + tidv, t = idx >> 5, cg = idx & 31;
+                hv[it] = *(const bf16x8*)(hin_c + (size_t)t * 512 + cg * 16);
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {   // stream the gate tile to HBM
+                const int idx = it * 512 + tidv, t = idx >> 5, c = idx & 31;
+                *(uint4*)(gdst + (size_t)t * 512 + c * 16) = *(const uint4*)(smem + t * 512 + ((c ^ (t & 15)) * 16));
+            }
+
+            // ---------------- GEMM2: res = W_res * g ---------------------------------------------------
+            f32x4 acc2[4][4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto compute2 = [&](int ks2, int buf) {
+                const char* A = smem + GEMM2_BUF + buf * 16384 + wm * 4096 + r16v * 64 + ((qv ^ swz64(r16v)) * 16);
+                const char* G = smem + (wn * 64 + r16v) * 512 + (((ks2 * 4 + qv) ^ r16v) * 16);
+                bf16x8 b2[4], a2[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) b2[nt] = *(const bf16x8*)(G + nt * 8192);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) a2[mt] = *(const bf16x8*)(A + mt * 1024);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = mfma16(a2[mt], b2[nt], acc2[mt][nt]);
+            };
+            // 8 weight stages through 5 buffers: stage 5/6/7 reuse buffer 0/1/2 as soon as every wave has read it
+            compute2(0, 0);
+            WNL_BARRIER_LGKM();
+            stage2(5, 0);
+            compute2(1, 1);
+            WNL_BARRIER_LGKM();
+            stage2(6, 1);
+            compute2(2, 2);
+            WNL_BARRIER_LGKM();
+            stage2(7, 2);
+            compute2(3, 3);
+            compute2(4, 4);
+            WNL_WAIT_BARRIER(4);           // stage 5 landed (6-7 may fly); every ordinary load and store above is older
+            compute2(5, 0);
+            WNL_WAIT_BARRIER(2);
+            compute2(6, 1);
+            WNL_WAIT_BARRIER(0);
+            compute2(7, 2);
+
+            // ---------------- next tile's first stages + epilogue in two 64-row halves -----------------
+            stamp(4);
+            WNL_BARRIER_LGKM();            // every wave is done with the gate tile and the weight buffers
+            if (has_next) {
+                stage1(hin_n, 0);          // ring slots A/B = [80K,160K): not touched by the epilogue tile
+                stage1(hin_n, 1);
+            }
+            char* hout_c = (char*)(a.hout + ((size_t)b * a.LP + kPad + t0) * kC);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (wn == h) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const int row = nt * 16 + r16v, ch = wm * 64 + mt * 16 + qv * 4;
+                            *(f32x4*)(smem + row * EPI_PITCH + ch * 4) = acc2[mt][nt];
+                        }
+                }
+                WNL_BARRIER_LGKM();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int idx = it * 512 + tidv, row = idx >> 5, cg = idx & 31;
+                    const f32x4 r0 = *(const f32x4*)(smem + row * EPI_PITCH + cg * 32);
+                    const f32x4 r1 = *(const f32x4*)(smem + row * EPI_PITCH + cg * 32 + 16);
+                    const bf16x8 hh = hv[h * 4 + it];
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = (bf16_t)(((float)hh[j] + r0[j]) * 0.70710678118654752440f + e0[j]);
+                        o[j + 4] = (bf16_t)(((float)hh[j + 4] + r1[j]) * 0.70710678118654752440f + e1[j]);
+                    }
+                    *(bf16x8*)(hout_c + (size_t)(h * 64 + row) * 512 + cg * 16) = o;
+                }
+                WNL_BARRIER_LGKM();        // the half tile has been read: it may be overwritten
+            }
+            stamp(5);
+            if (!has_next) { flush(); return; }
+            stage1(hin_n, 2);              // ring slot C = [0,40K) is free now
+        }
+        hin_c = hin_n;
+        tile = next;
+        b = nb;
+        t0 = nt0;
+        first = false;
+    }
+}
+
+static int g_num_cus = 256;
+
+void launch_wn_layer_bf16_p(const WnLayerArgs& a, int B, hipStream_t s, bool stamps) {
+    const int ntiles = B * (a.L / kTileT);
+    const int grid = ntiles < g_num_cus ? ntiles : g_num_cus;
+    if (stamps && !a.last) {
+        hipLaunchKernelGGL((wn_layer_bf16_p<false, true>), dim3(grid), dim3(512), kWnLdsBytesV3, s, a, ntiles);
+        return;
+    }
+    if (a.last) hipLaunchKernelGGL(wn_layer_bf16_p<true>, dim3(grid), dim3(512), kWnLdsBytesV3, s, a, ntiles);
+    else hipLaunchKernelGGL(wn_layer_bf16_p<false>, dim3(grid), dim3(512), kWnLdsBytesV3, s, a, ntiles);
+}
+
+int wn_layer_p_configure() {
+    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_bf16_p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLdsBytesV3);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)wn_layer_bf16_p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLdsBytesV3);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)wn_layer_bf16_p<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLdsBytesV3);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        g_num_cus = prop.multiProcessorCount;
+    return 0;
+}
+
+}  // namespace dmad
