@@ -366,7 +366,8 @@ int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipS
         WnFinalArgs f{};
         f.g = e->gstore; f.wsp = e->wsp; f.wf0p = e->wf0p; f.bskip_sum = e->bskip_sum; f.bf0 = e->bf0; f.wz = e->wz;
         f.eps = eps; f.bz = e->bz; f.skip_scale = (float)sqrt(1.0 / NL); f.NL = NL; f.B = B; f.L = L;
-        launch_wn_final_bf16(f, s);
+        if (e->layer_variant >= 40 && wn_final_p_supported(f)) launch_wn_final_bf16_p(f, s);
+        else launch_wn_final_bf16(f, s);
     } else {
         const long N = (long)B * L;
         launch_wn_init_f32(x_t, e->init_w, e->init_b, e->emb_table, e->hA32, B, L, LP, s);

@@ -41,5 +41,8 @@ void launch_wn_init_bf16(const float* x, const float* w, const float* bias, cons
 int wn_bf16_configure();
 void launch_wn_layer_bf16_p(const WnLayerArgs& a, int B, hipStream_t s, bool stamps = false);   // persistent production schedule (wn_layer.hip)
 int wn_layer_p_configure();
+void launch_wn_final_bf16_p(const WnFinalArgs& a, hipStream_t s);            // persistent production schedule (wn_final.hip)
+bool wn_final_p_supported(const WnFinalArgs& a);
+int wn_final_p_configure();
 
 }  // namespace dmad

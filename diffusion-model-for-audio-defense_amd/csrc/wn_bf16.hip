@@ -1085,6 +1085,7 @@ void launch_wn_init_bf16(const float* x, const float* w, const float* bias, cons
 }
 int wn_bf16_configure() {
     if (int r = wn_layer_p_configure()) return r;
+    if (int r = wn_final_p_configure()) return r;
     hipError_t e = hipSuccess;
     const void* fns[] = {(const void*)wn_layer_bf16<0>, (const void*)wn_layer_bf16<1>, (const void*)wn_layer_bf16<2>,
                          (const void*)wn_layer_bf16<3>, (const void*)wn_layer_bf16<4>, (const void*)wn_layer_bf16<5>};

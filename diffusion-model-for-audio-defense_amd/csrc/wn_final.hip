@@ -1,0 +1,238 @@
+// wn_final_bf16_p — tail of the eps-network on the bf16 path (persistent form):
+//   skip = sum_n W_skip_n * g_n + sum_n b_skip_n          ONE GEMM, M = 256, K = NL*256 (9216), over the
+//                                                         gate outputs every layer kernel streamed to HBM
+//   y    = skip * sqrt(1/NL)                              (WaveNet.py:135)
+//   f    = relu(W_f0 * y + b_f0)                          (final_conv.0 + ReLU, WaveNet.py:160-161)
+//   eps  = w_z . f + b_z                                  (final_conv.2 (ZeroConv1d), WaveNet.py:162)
+//
+// One workgroup (8 waves = 4 (M) x 2 (N), 1 per CU) walks over tiles of 256 consecutive (clip, time)
+// positions; wave tile 64 ch x 128 t = 32 accumulator tiles of 16x16 (same register budget as the layer
+// kernel).  K loop: k-steps of 32 through a 3-slot LDS ring (16 KiB of packed W_skip + 16 KiB of g rows per
+// slot), the 4 DMA pieces of k-step ks+3 and the 12 fragment reads of k-step ks+1 are spread between the
+// 32 MFMAs of k-step ks; counted vmcnt; one barrier per k-step.  Then y (bf16) -> LDS [256 t][256 ch],
+// the 256x256 final_conv.0 GEMM from LDS, ReLU, dot with w_z, reduce over channels (registers -> lanes ->
+// waves through LDS).
+// LDS map (160 KiB): ring slots at 0 / 32K / 64K; y tile [0,128K); final_conv.0 weight buffers 2 x 16 KiB
+// at [128K,160K).
+#include <type_traits>
+
+#include "dmad_common.h"
+#include "wn_bf16.h"
+
+namespace dmad {
+
+namespace {
+
+constexpr int FT = 256;                       // positions per tile
+constexpr int F_SLOT = 32768, F_BOFF = 16384; // ring slot: weights then activations
+constexpr int F_W3 = 131072;                  // two final_conv.0 weight buffers
+
+#define WNF_WAIT_BARRIER(N)                                                         \
+    do {                                                                            \
+        asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");                       \
+        __builtin_amdgcn_s_waitcnt(0x0070 | ((N) & 15) | (((N) >> 4) << 14));       \
+        __builtin_amdgcn_s_barrier();                                               \
+        asm volatile("" ::: "memory");                                              \
+    } while (0)
+#define WNF_BARRIER_LGKM()                                                          \
+    do {                                                                            \
+        asm volatile("" ::: "memory");                                              \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                         \
+        __builtin_amdgcn_s_barrier();                                               \
+        asm volatile("" ::: "memory");                                              \
+    } while (0)
+
+__device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(512, 2) wn_final_bf16_p(WnFinalArgs a, long npos, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int q = lane >> 4, r16 = lane & 15;
+    const unsigned tid16 = (unsigned)tid * 16u;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    const int frag_off = r16 * 64 + ((q ^ swz64(r16)) * 16);
+    const size_t layer_bytes = (size_t)npos * 512;
+    const int nks = a.NL * 8;
+    const int brow = tid >> 2;                    // activation rows brow and brow + 128 of the tile
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long p0 = (long)tile * FT;
+        const char* wb = (const char*)a.wsp;
+        const char* w3b = (const char*)a.wf0p;
+        asm volatile("" : "+s"(wb), "+s"(w3b));   // keep the DMA bases from being hoisted (SGPR spills)
+        const char* gb = (const char*)a.g + (size_t)p0 * 512;
+        // rows beyond the end of the batch (last tile only) are clamped to the last valid position
+        const long last = npos - 1 - p0;
+        const unsigned voff0 = (unsigned)((brow < last ? brow : last) * 512 + (((tid & 3) ^ swz64(brow)) * 16));
+        const unsigned voff1 = (unsigned)(((brow + 128) < last ? (brow + 128) : last) * 512 + (((tid & 3) ^ swz64(brow)) * 16));
+
+        auto stage_piece = [&](int ks, int slot, int p) {   // p: 0,1 = weights, 2,3 = activation rows
+            const unsigned la = lds0 + slot * F_SLOT + wv * 1024;
+            if (p < 2) dma16(wb + ((size_t)ks * 16384 + p * 8192), tid16, la + p * 8192);
+            else dma16(gb + ((size_t)(ks >> 3) * layer_bytes + (ks & 7) * 64), p == 2 ? voff0 : voff1, la + F_BOFF + (p - 2) * 8192);
+        };
+        auto stage3 = [&](int ks3, int buf) {
+            const unsigned la = lds0 + F_W3 + buf * 16384 + wv * 1024;
+            dma16(w3b + (size_t)ks3 * 16384, tid16, la);
+            dma16(w3b + (size_t)ks3 * 16384 + 8192, tid16, la + 8192);
+        };
+
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 bias = *(const f32x4*)(a.bskip_sum + wm * 64 + mt * 16 + q * 4);
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = bias;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);       // retire the bias loads before the first DMA (vmcnt(0))
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) stage_piece(s, s, p);
+        WNF_WAIT_BARRIER(8);                      // stage 0 landed
+        bf16x8 af[2][4], bf[2][8];
+        {
+            const char* A = smem + wm * 4096 + frag_off;
+            const char* Bt = smem + F_BOFF + wn * 8192 + frag_off;
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) bf[0][nt] = *(const bf16x8*)(Bt + nt * 1024);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) af[0][mt] = *(const bf16x8*)(A + mt * 1024);
+        }
+        // ---------------- skip GEMM: nks k-steps, unrolled by 6 (2 fragment sets x 3 ring slots) ------------
+        // the last group of 6 is peeled (TAIL) so that the steady-state body carries no end-of-K conditions
+        auto kgroup = [&](int ks0, auto tail_tag) {
+            constexpr bool TAIL = decltype(tail_tag)::value;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int ks = ks0 + u;
+                const int cur = u & 1, nxt = cur ^ 1;
+                // stage ks+1 landed; stage ks+2 may still fly
+                if (!TAIL || u < 4) { WNF_WAIT_BARRIER(4); } else { WNF_WAIT_BARRIER(0); }
+                const char* Ar = smem + ((u + 1) % 3) * F_SLOT + wm * 4096 + frag_off;
+                const char* Br = smem + ((u + 1) % 3) * F_SLOT + F_BOFF + wn * 8192 + frag_off;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {              // 4 x (1 DMA piece, 5 MFMAs)
+                    if (!TAIL || u < 3) stage_piece(ks + 3, u % 3, p);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 5 * p; i < 5 * p + 5; ++i)
+                        acc[i >> 3][i & 7] = mfma16(af[cur][i >> 3], bf[cur][i & 7], acc[i >> 3][i & 7]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int p = 0; p < 12; ++p) {             // 12 x (1 fragment read of k-step ks+1, 1 MFMA)
+                    if (!TAIL || u < 5) {
+                        if (p < 8) bf[nxt][p] = *(const bf16x8*)(Br + p * 1024);
+                        else af[nxt][p - 8] = *(const bf16x8*)(Ar + (p - 8) * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int i = 20 + p;
+                    acc[i >> 3][i & 7] = mfma16(af[cur][i >> 3], bf[cur][i & 7], acc[i >> 3][i & 7]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        for (int ks0 = 0; ks0 < nks - 6; ks0 += 6) kgroup(ks0, std::false_type{});
+        kgroup(nks - 6, std::true_type{});
+        // ---------------- y = skip * sqrt(1/NL) -> bf16 -> LDS [256 t][256 ch] ------------------------------
+        WNF_BARRIER_LGKM();                       // every wave holds its last fragments: the ring is free
+        stage3(0, 0);
+        stage3(1, 1);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                bf16x4 yv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yv[r] = (bf16_t)(acc[mt][nt][r] * a.skip_scale);
+                const int t = wn * 128 + nt * 16 + r16;
+                const int chunk = wm * 8 + mt * 2 + (q >> 1);
+                *(bf16x4*)(smem + t * 512 + ((chunk ^ r16) * 16) + (q & 1) * 8) = yv;
+            }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 bias = *(const f32x4*)(a.bf0 + wm * 64 + mt * 16 + q * 4);
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = bias;
+        }
+        // ---------------- f = W_f0 * y: 8 k-steps, 2 weight buffers ------------------------------------------
+        for (int ks3 = 0; ks3 < 8; ks3 += 2) {
+            WNF_WAIT_BARRIER(0);                  // y tile complete (first pass), stages ks3, ks3+1 landed
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const char* A = smem + F_W3 + u * 16384 + wm * 4096 + frag_off;
+                const char* G = smem + (wn * 128 + r16) * 512 + ((((ks3 + u) * 4 + q) ^ r16) * 16);
+                bf16x8 b3[8], a3[4];
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) b3[nt] = *(const bf16x8*)(G + nt * 8192);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) a3[mt] = *(const bf16x8*)(A + mt * 1024);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = mfma16(a3[mt], b3[nt], acc[mt][nt]);
+            }
+            if (ks3 + 2 < 8) {
+                WNF_BARRIER_LGKM();               // both buffers have been read by every wave
+                stage3(ks3 + 2, 0);
+                stage3(ks3 + 3, 1);
+            }
+        }
+        // ---------------- relu, dot with w_z, reduce over channels -------------------------------------------
+        float part[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) part[nt] = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 wz = *(const f32x4*)(a.wz + wm * 64 + mt * 16 + q * 4);
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[nt] = fmaf(fmaxf(acc[mt][nt][r], 0.f), wz[r], part[nt]);
+        }
+        WNF_BARRIER_LGKM();                       // everyone is done with the y tile and the weight buffers
+        float* red = (float*)smem;                // [4 wm][256 t]
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            float p = part[nt];
+            p += __shfl_xor(p, 16);
+            p += __shfl_xor(p, 32);
+            if (q == 0) red[wm * FT + wn * 128 + nt * 16 + r16] = p;
+        }
+        WNF_BARRIER_LGKM();
+        if (tid < FT && p0 + tid < npos)
+            a.eps[p0 + tid] = ((red[tid] + red[FT + tid]) + (red[2 * FT + tid] + red[3 * FT + tid])) + a.bz;
+        WNF_BARRIER_LGKM();                       // `red` is read before the next tile's DMA overwrites it
+    }
+}
+
+static int g_final_cus = 256;
+
+bool wn_final_p_supported(const WnFinalArgs& a) { return (a.NL * 8) % 6 == 0 && a.NL * 8 >= 12; }
+
+void launch_wn_final_bf16_p(const WnFinalArgs& a, hipStream_t s) {
+    const long npos = (long)a.B * a.L;
+    const int ntiles = (int)((npos + FT - 1) / FT);
+    const int grid = ntiles < g_final_cus ? ntiles : g_final_cus;
+    hipLaunchKernelGGL(wn_final_bf16_p, dim3(grid), dim3(512), 163840, s, a, npos, ntiles);
+}
+
+int wn_final_p_configure() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        g_final_cus = prop.multiProcessorCount;
+    return (int)hipFuncSetAttribute((const void*)wn_final_bf16_p, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+}
+
+}  // namespace dmad
