@@ -99,7 +99,8 @@ struct dmad_engine {
     float* vshift[16] = {nullptr};
     float* vfcw[3] = {nullptr};
     float* vfcb[3] = {nullptr};
-    float *act0 = nullptr, *act1 = nullptr, *logits = nullptr;
+    float *act0 = nullptr, *act1 = nullptr, *logits = nullptr, *slab = nullptr;
+    long slab_floats = 0;
 
     template <typename T>
     int alloc(T** p, size_t n, bool zero = false) {
@@ -428,7 +429,7 @@ int classify(dmad_engine* e, const float* spec, int B, float* logits, hipStream_
             g.A = e->vconvw[li]; g.X = cur; g.C = nxt; g.scale = e->vscale[li]; g.shift = e->vshift[li];
             g.M = v; g.K = cin; g.taps = 9; g.ldc = v; g.relu = 1; g.N = (long)B * H * H; g.mode = 2;
             g.H = H; g.W = H; g.Cin = cin;
-            launch_gemm_f32(g, s);
+            launch_gemm_f32(g, s, e->slab, e->slab_floats, (long)e->maxB * H * H);
             cin = v;
             ++li;
         }
@@ -437,7 +438,8 @@ int classify(dmad_engine* e, const float* spec, int B, float* logits, hipStream_
     const int fin[3] = {512, 4096, 4096}, fout[3] = {4096, 4096, e->cfg.num_classes};
     for (int j = 0; j < 3; ++j) {
         float* dst = (j == 2) ? logits : nxt;
-        launch_gemm_f32(plain_gemm(e->vfcw[j], cur, dst, nullptr, e->vfcb[j], fout[j], fin[j], B, fout[j], fin[j], j < 2), s);
+        launch_gemm_f32(plain_gemm(e->vfcw[j], cur, dst, nullptr, e->vfcb[j], fout[j], fin[j], B, fout[j], fin[j], j < 2), s, e->slab,
+                        e->slab_floats, (long)e->maxB);
         float* t = cur; cur = nxt; nxt = t;
     }
     HIPCHK(hipGetLastError());
@@ -500,6 +502,9 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
             if ((r = e->alloc(&e->act0, B * 1024 * 64))) break;
             if ((r = e->alloc(&e->act1, B * 1024 * 64))) break;
             if ((r = e->alloc(&e->logits, B * cfg->num_classes))) break;
+            e->slab_floats = 8l << 20;           // 32 MiB split-K workspace (largest user: 16 x [B*4][512])
+            if (e->slab_floats < (long)B * 16 * 4096) e->slab_floats = (long)B * 16 * 4096;
+            if ((r = e->alloc(&e->slab, (size_t)e->slab_floats))) break;
             if ((r = init_mel_constants(e))) break;
         }
     } while (0);

@@ -16,8 +16,12 @@ struct GemmF32Args {
                           // 2: 3x3 conv over NHWC [B][H][W][Cin] with zero padding (taps == 9, K == Cin)
     long rows_per_batch, batch_stride, row_stride, tap_stride;   // floats (mode 0)
     int H, W, Cin;        // mode 2
+    int splits;           // > 1: split-K over grid.z; partial sums go to `slab` [splits][N][ldc] (fixed-order reduce)
+    float* slab;
 };
 
-void launch_gemm_f32(const GemmF32Args& a, hipStream_t s);
+// `slab` (device workspace of `slab_floats` floats) enables deterministic split-K for launches that would not
+// fill the chip (deep VGG layers at small spatial size, batch-sized Linear layers); pass nullptr to disable.
+void launch_gemm_f32(const GemmF32Args& a, hipStream_t s, float* slab = nullptr, long slab_floats = 0, long n_ref = 0);
 
 }  // namespace dmad

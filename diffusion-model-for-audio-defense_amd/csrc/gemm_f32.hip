@@ -41,7 +41,9 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
     const int wm = wv >> 1, wn = wv & 1, q = lane >> 4, r16 = lane & 15;
     const long n0 = (long)blockIdx.x * BN;
     const int m0 = blockIdx.y * BM;
-    const int ksteps_per_tap = a.K / BK, nks = a.taps * ksteps_per_tap;
+    const int ksteps_per_tap = a.K / BK, nks_all = a.taps * ksteps_per_tap;
+    const int S = a.splits > 1 ? a.splits : 1, z = blockIdx.z;
+    const int ks_begin = (int)((long)nks_all * z / S), nks = (int)((long)nks_all * (z + 1) / S);
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -72,10 +74,10 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
         }
     };
 
-    gload(0);
-    lstore(0);
+    gload(ks_begin);
+    lstore(ks_begin & 1);
     __syncthreads();
-    for (int ks = 0; ks < nks; ++ks) {
+    for (int ks = ks_begin; ks < nks; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < nks) gload(ks + 1);
 #pragma unroll
@@ -96,6 +98,22 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
         __syncthreads();
     }
 
+    if (S > 1) {   // split-K: raw partial sums to this split's slab; scale/shift/act happen in the reduce kernel
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + q * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long n = n0 + wn * 64 + j * 16 + r16;
+                if (n >= a.N) continue;
+                float* dst = a.slab + ((long)z * a.N + n) * a.ldc + m;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < a.M) dst[r] = acc[i][j][r];
+            }
+        }
+        return;
+    }
     const bool vec = ((a.ldc & 3) == 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -128,9 +146,42 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
     }
 }
 
-void launch_gemm_f32(const GemmF32Args& a, hipStream_t s) {
-    dim3 grid((unsigned)((a.N + BN - 1) / BN), (unsigned)((a.M + BM - 1) / BM));
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, a);
+// C[n][m] = act(scale[m] * sum_z slab[z][n][m] + shift[m]), splits summed in index order (deterministic)
+__global__ void gemm_f32_reduce_kernel(GemmF32Args a) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N * a.M) return;
+    const long n = i / a.M;
+    const int m = (int)(i - n * a.M);
+    float s = 0.f;
+    for (int z = 0; z < a.splits; ++z) s += a.slab[((long)z * a.N + n) * a.ldc + m];
+    float t = a.scale ? s * a.scale[m] + (a.shift ? a.shift[m] : 0.f) : s + (a.shift ? a.shift[m] : 0.f);
+    a.C[n * a.ldc + m] = a.relu ? fmaxf(t, 0.f) : t;
+}
+
+void launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab_floats, long n_ref) {
+    GemmF32Args a = a0;
+    const unsigned gx = (unsigned)((a.N + BN - 1) / BN), gy = (unsigned)((a.M + BM - 1) / BM);
+    const int nks = a.taps * (a.K / BK);
+    int S = 1;
+    if (slab) {
+        // The split count is derived from the REFERENCE row count n_ref (the engine's max batch), not from the
+        // rows of this launch, so that a sample's result does not depend on the batch it was computed in.
+        const long nr = n_ref > 0 ? n_ref : a.N;
+        const long wgs_ref = ((nr + BN - 1) / BN) * gy;
+        if (wgs_ref < 128) {                       // fewer than half a wave of workgroups: split K
+            S = (int)(256 / wgs_ref);
+            if (S > nks / 4) S = nks / 4;          // keep >= 4 k-steps per split
+            while (S > 1 && (long)S * nr * a.ldc > slab_floats) --S;
+            if (S < 2 || a.N > nr) S = 1;
+        }
+    }
+    a.splits = S;
+    a.slab = slab;
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(gx, gy, S), dim3(256), 0, s, a);
+    if (S > 1) {
+        const long total = a.N * a.M;
+        hipLaunchKernelGGL(gemm_f32_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    }
 }
 
 }  // namespace dmad
