@@ -71,7 +71,6 @@ struct dmad_engine {
     std::vector<void*> allocs;
     int64_t bytes = 0;
     int emb_t = -1;
-    int layer_variant = 40;    // 40 = persistent production schedule (wn_layer.hip); DMAD_WN_VARIANT selects an A/B baseline
     // optional per-launch timing of the dominant kernel (bench.py roofline): HIP event pairs on the launch stream
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -354,21 +353,18 @@ int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipS
             a.w1p = e->w1p + (size_t)n * 24 * 512 * 32;
             a.w2p = e->w2p + (size_t)n * 8 * 256 * 32;
             a.b1 = e->b1p + (size_t)n * 512;
-            a.b2 = e->b2 + (size_t)n * 256;
-            a.emb_next = e->emb_table + (size_t)((n + 1 < NL) ? n + 1 : n) * 256;
             a.epi_c = e->epi_c + (size_t)n * 256;
             a.dilation = 1 << (n % e->cfg.dilation_cycle);
-            a.L = L; a.LP = LP; a.last = (n == NL - 1);
+            a.L = L; a.LP = LP; a.last = (n == NL - 1); a.npos = (long)B * L;
             const bool timed = e->prof_on && !a.last && e->prof_used + 2 <= e->prof_ev.size();
             if (timed) (void)hipEventRecord(e->prof_ev[e->prof_used++], s);
-            launch_wn_layer_bf16(a, B, s, e->layer_variant);
+            launch_wn_layer_bf16_p(a, B, s);
             if (timed) (void)hipEventRecord(e->prof_ev[e->prof_used++], s);
         }
         WnFinalArgs f{};
         f.g = e->gstore; f.wsp = e->wsp; f.wf0p = e->wf0p; f.bskip_sum = e->bskip_sum; f.bf0 = e->bf0; f.wz = e->wz;
         f.eps = eps; f.bz = e->bz; f.skip_scale = (float)sqrt(1.0 / NL); f.NL = NL; f.B = B; f.L = L;
-        if (e->layer_variant >= 40 && wn_final_p_supported(f)) launch_wn_final_bf16_p(f, s);
-        else launch_wn_final_bf16(f, s);
+        launch_wn_final_bf16_p(f, s);
     } else {
         const long N = (long)B * L;
         launch_wn_init_f32(x_t, e->init_w, e->init_b, e->emb_table, e->hA32, B, L, LP, s);
@@ -473,7 +469,10 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     e->L = cfg->clip_len; e->LP = cfg->clip_len + 2 * kPad; e->NL = cfg->num_res_layers; e->maxB = cfg->max_batch;
     e->LPm = cfg->clip_len + 2048;
     e->bf16 = cfg->precision == DMAD_BF16;
-    if (const char* v = getenv("DMAD_WN_VARIANT")) e->layer_variant = atoi(v);
+    if (e->bf16 && !wn_final_p_supported(cfg->num_res_layers)) {
+        delete e;
+        return fail(DMAD_ERR_INVALID, "bf16 path needs num_res_layers to be a multiple of 3 (>= 3); got %d", cfg->num_res_layers);
+    }
     const size_t B = e->maxB, L = e->L, LP = e->LP, NL = e->NL;
     int r = 0;
     do {
@@ -690,21 +689,21 @@ int dmad_time_layer(dmad_engine* e, int32_t layer, int32_t B, int32_t iters, flo
     WnLayerArgs a{};
     a.hin = e->hA; a.hout = e->hB; a.gout = e->gstore + (size_t)layer * B * e->L * kC;
     a.w1p = e->w1p + (size_t)layer * 24 * 512 * 32; a.w2p = e->w2p + (size_t)layer * 8 * 256 * 32;
-    a.b1 = e->b1p + (size_t)layer * 512; a.b2 = e->b2 + (size_t)layer * 256; a.emb_next = e->emb_table; a.epi_c = e->epi_c;
-    a.dilation = 1 << (layer % e->cfg.dilation_cycle); a.L = e->L; a.LP = e->LP; a.last = 0;
-    const char* ev = getenv("DMAD_LAYER_VARIANT");        // development only: timing-only ablations of the kernel
-    const int variant = ev ? atoi(ev) : e->layer_variant;
+    a.b1 = e->b1p + (size_t)layer * 512; a.epi_c = e->epi_c + (size_t)layer * 256;
+    a.dilation = 1 << (layer % e->cfg.dilation_cycle); a.L = e->L; a.LP = e->LP; a.last = 0; a.npos = (long)B * e->L;
+    const char* ev = getenv("DMAD_LAYER_STAMPS");         // development only: per-phase cycle stamps (diagnostic build)
+    const bool stamps = ev && atoi(ev) != 0;
     unsigned long long* dbg = nullptr;
     const size_t nblk = (size_t)B * (e->L / kTileT);
-    if (variant == 11 || variant == 21 || variant == 31 || variant == 41) {
+    if (stamps) {
         HIPCHK(hipMalloc((void**)&dbg, nblk * 8 * sizeof(unsigned long long)));
         a.dbg = dbg;
     }
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    launch_wn_layer_bf16(a, B, st, variant);
+    launch_wn_layer_bf16_p(a, B, st, stamps);
     HIPCHK(hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) launch_wn_layer_bf16(a, B, st, variant);
+    for (int i = 0; i < iters; ++i) launch_wn_layer_bf16_p(a, B, st, stamps);
     HIPCHK(hipEventRecord(e1, st));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -715,12 +714,8 @@ int dmad_time_layer(dmad_engine* e, int32_t layer, int32_t B, int32_t iters, flo
         std::vector<unsigned long long> h(nblk * 8);
         HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
         double sum[7] = {0};
-        if (variant == 41) {   // persistent kernel: per-WG phase sums over all its tiles, 256 WGs
-            for (size_t i = 0; i < 256 && i < nblk; ++i)
-                for (int k = 0; k < 6; ++k) sum[k + 1] += (double)h[i * 8 + k];
-        } else
-        for (size_t i = 0; i < nblk; ++i)
-            for (int k = 1; k < 7; ++k) sum[k] += (double)(h[i * 8 + k] - h[i * 8 + k - 1]);
+        for (size_t i = 0; i < 256 && i < nblk; ++i)   // per-workgroup phase sums over all its tiles
+            for (int k = 0; k < 6; ++k) sum[k + 1] += (double)h[i * 8 + k];
         fprintf(stderr, "[dmad stamps] prologue %.0f | gemm1 %.0f | gate %.0f | barrier %.0f | gemm2 %.0f | epilogue %.0f  (mean cycles per tile, %zu tiles)\n",
                 sum[1] / nblk, sum[2] / nblk, sum[3] / nblk, sum[4] / nblk, sum[5] / nblk, sum[6] / nblk, nblk);
         (void)hipFree(dbg);

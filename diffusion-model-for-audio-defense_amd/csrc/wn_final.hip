@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(512, 2) wn_final_bf16_p(WnFinalArgs a, long np
     const unsigned tid16 = (unsigned)tid * 16u;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
     const int frag_off = r16 * 64 + ((q ^ swz64(r16)) * 16);
-    const size_t layer_bytes = (size_t)npos * 512;
+    const size_t kc_bytes = (size_t)npos * 64;      // one k-chunk plane of the gate store: [npos][32] bf16
     const int nks = a.NL * 8;
     const int brow = tid >> 2;                    // activation rows brow and brow + 128 of the tile
 
@@ -69,16 +69,16 @@ __global__ void __launch_bounds__(512, 2) wn_final_bf16_p(WnFinalArgs a, long np
         const char* wb = (const char*)a.wsp;
         const char* w3b = (const char*)a.wf0p;
         asm volatile("" : "+s"(wb), "+s"(w3b));   // keep the DMA bases from being hoisted (SGPR spills)
-        const char* gb = (const char*)a.g + (size_t)p0 * 512;
+        const char* gb = (const char*)a.g + (size_t)p0 * 64;
         // rows beyond the end of the batch (last tile only) are clamped to the last valid position
         const long last = npos - 1 - p0;
-        const unsigned voff0 = (unsigned)((brow < last ? brow : last) * 512 + (((tid & 3) ^ swz64(brow)) * 16));
-        const unsigned voff1 = (unsigned)(((brow + 128) < last ? (brow + 128) : last) * 512 + (((tid & 3) ^ swz64(brow)) * 16));
+        const unsigned voff0 = (unsigned)((brow < last ? brow : last) * 64 + (((tid & 3) ^ swz64(brow)) * 16));
+        const unsigned voff1 = (unsigned)(((brow + 128) < last ? (brow + 128) : last) * 64 + (((tid & 3) ^ swz64(brow)) * 16));
 
         auto stage_piece = [&](int ks, int slot, int p) {   // p: 0,1 = weights, 2,3 = activation rows
             const unsigned la = lds0 + slot * F_SLOT + wv * 1024;
             if (p < 2) dma16(wb + ((size_t)ks * 16384 + p * 8192), tid16, la + p * 8192);
-            else dma16(gb + ((size_t)(ks >> 3) * layer_bytes + (ks & 7) * 64), p == 2 ? voff0 : voff1, la + F_BOFF + (p - 2) * 8192);
+            else dma16(gb + (size_t)ks * kc_bytes, p == 2 ? voff0 : voff1, la + F_BOFF + (p - 2) * 8192);   // plane ks = layer*8 + kc
         };
         auto stage3 = [&](int ks3, int buf) {
             const unsigned la = lds0 + F_W3 + buf * 16384 + wv * 1024;
@@ -218,13 +218,13 @@ __global__ void __launch_bounds__(512, 2) wn_final_bf16_p(WnFinalArgs a, long np
 
 static int g_final_cus = 256;
 
-bool wn_final_p_supported(const WnFinalArgs& a) { return (a.NL * 8) % 6 == 0 && a.NL * 8 >= 12; }
+bool wn_final_p_supported(int num_res_layers) { return (num_res_layers * 8) % 6 == 0 && num_res_layers * 8 >= 12; }
 
 void launch_wn_final_bf16_p(const WnFinalArgs& a, hipStream_t s) {
     const long npos = (long)a.B * a.L;
     const int ntiles = (int)((npos + FT - 1) / FT);
     const int grid = ntiles < g_final_cus ? ntiles : g_final_cus;
-    hipLaunchKernelGGL(wn_final_bf16_p, dim3(grid), dim3(512), 163840, s, a, npos, ntiles);
+    hipLaunchKernelGGL(wn_final_bf16_p, dim3(grid), dim3(512), kWnLdsBytes, s, a, npos, ntiles);
 }
 
 int wn_final_p_configure() {

@@ -234,7 +234,9 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
         int nb = 0, nt0 = 0;
         if (has_next) tile_rows(next, nb, nt0);
         const char* hin_n = hin_center(nb, nt0);
-        char* gdst = (char*)(a.gout + ((size_t)b * a.L + t0) * kC);
+        // gate store, k-chunk-major [8][npos][32]: 16-B chunk c of row t -> k-chunk c>>2, 16-B sub-chunk c&3
+        char* gdst = (char*)a.gout + ((size_t)b * a.L + t0) * 64;
+        const size_t gkc = (size_t)a.npos * 64;
 
         if constexpr (LAST) {
             // the last layer's residual output is never consumed (WaveNet.py:131-135): only g leaves
@@ -242,7 +244,7 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int idx = it * 512 + tidv, t = idx >> 5, c = idx & 31;
-                *(uint4*)(gdst + (size_t)t * 512 + c * 16) = *(const uint4*)(smem + t * 512 + ((c ^ (t & 15)) * 16));
+                *(uint4*)(gdst + (size_t)(c >> 2) * gkc + (size_t)t * 64 + (c & 3) * 16) = *(const uint4*)(smem + t * 512 + ((c ^ (t & 15)) * 16));
             }
             if (!has_next) return;
             WNL_BARRIER_LGKM();            // every wave has read its part of the gate tile: slot C is free
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
 #pragma unroll
             for (int it = 0; it < 8; ++it) {   // stream the gate tile to HBM
                 const int idx = it * 512 + tidv, t = idx >> 5, c = idx & 31;
-                *(uint4*)(gdst + (size_t)t * 512 + c * 16) = *(const uint4*)(smem + t * 512 + ((c ^ (t & 15)) * 16));
+                *(uint4*)(gdst + (size_t)(c >> 2) * gkc + (size_t)t * 64 + (c & 3) * 16) = *(const uint4*)(smem + t * 512 + ((c ^ (t & 15)) * 16));
             }
 
             // ---------------- GEMM2: res = W_res * g ---------------------------------------------------
@@ -363,19 +365,19 @@ void launch_wn_layer_bf16_p(const WnLayerArgs& a, int B, hipStream_t s, bool sta
     const int ntiles = B * (a.L / kTileT);
     const int grid = ntiles < g_num_cus ? ntiles : g_num_cus;
     if (stamps && !a.last) {
-        hipLaunchKernelGGL((wn_layer_bf16_p<false, true>), dim3(grid), dim3(512), kWnLdsBytesV3, s, a, ntiles);
+        hipLaunchKernelGGL((wn_layer_bf16_p<false, true>), dim3(grid), dim3(512), kWnLdsBytes, s, a, ntiles);
         return;
     }
-    if (a.last) hipLaunchKernelGGL(wn_layer_bf16_p<true>, dim3(grid), dim3(512), kWnLdsBytesV3, s, a, ntiles);
-    else hipLaunchKernelGGL(wn_layer_bf16_p<false>, dim3(grid), dim3(512), kWnLdsBytesV3, s, a, ntiles);
+    if (a.last) hipLaunchKernelGGL(wn_layer_bf16_p<true>, dim3(grid), dim3(512), kWnLdsBytes, s, a, ntiles);
+    else hipLaunchKernelGGL(wn_layer_bf16_p<false>, dim3(grid), dim3(512), kWnLdsBytes, s, a, ntiles);
 }
 
 int wn_layer_p_configure() {
-    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_bf16_p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLdsBytesV3);
+    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_bf16_p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLdsBytes);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)wn_layer_bf16_p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLdsBytesV3);
+    e = hipFuncSetAttribute((const void*)wn_layer_bf16_p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLdsBytes);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)wn_layer_bf16_p<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLdsBytesV3);
+    e = hipFuncSetAttribute((const void*)wn_layer_bf16_p<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLdsBytes);
     if (e != hipSuccess) return (int)e;
     int dev = 0;
     hipDeviceProp_t prop;
