@@ -189,7 +189,9 @@ int finalize_wavenet(dmad_engine* e) {
 
     if (e->bf16) {
         int rmap[512];
-        for (int R = 0; R < 512; ++R) rmap[R] = ((R % 128) / 64) * 256 + (R / 128) * 64 + (R % 64);
+        // tile row R = wm*128 + half*64 + mt*16 + i  <->  gate row half*256 + (mt*64 + wm*16 + i): channel ownership is
+        // interleaved over the M-waves so that GEMM2 can start on channels [64 mt, 64 mt + 64) as soon as tiles mt are gated
+        for (int R = 0; R < 512; ++R) rmap[R] = ((R % 128) / 64) * 256 + ((R % 64) / 16) * 64 + (R / 128) * 16 + (R % 16);
         std::vector<uint16_t> w1p((size_t)NL * 24 * 512 * 32), w2p((size_t)NL * 8 * 256 * 32), wsp((size_t)NL * 8 * 256 * 32),
             wf0p((size_t)8 * 256 * 32);
         std::vector<float> b1p((size_t)NL * 512), b2((size_t)NL * 256), bsum(256, 0.f), tapw((size_t)512 * 256);

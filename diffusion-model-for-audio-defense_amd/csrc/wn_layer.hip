@@ -12,7 +12,9 @@
 //           40 KiB stage occupies it for ~640 of the k-step's 1024 matrix cycles);
 //           counted vmcnt, one barrier per k-step, nothing drained inside the loop.
 //   gate    tanh*sigmoid in fp32 registers -> bf16 tile [128 t][256 ch] in LDS (over ring slot C).
-//   GEMM2   res conv, 8 weight stages through six 16 KiB buffers (stages 0-5 land under the gate math).
+//   GEMM2   res conv, 8 weight stages through five 16 KiB buffers.  Gate channels are interleaved over the
+//           waves so that GEMM2 k-steps 2mt, 2mt+1 only need the gate tiles `mt`: their MFMAs run under the
+//           VALU-bound gate math of tiles mt+1 (the matrix pipe would otherwise idle through the gate).
 //   epi     two 64-row halves through a 65 KiB fp32 LDS tile; h' = (h + res) * sqrt(1/2) + emb_{n+1}.
 //   While the epilogue runs, stages 0-1 of the NEXT tile are already in flight into ring slots A/B (the
 //   epilogue tile only covers [0, 65 KiB)), so the next tile starts without an exposed load latency.
@@ -71,13 +73,22 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// tanh(a + ba) * sigmoid(b + bb) with 2 v_exp + 1 v_rcp:  u = e^{-2(a+ba)}, v = e^{-(b+bb)}:
-// (1-u) / ((1+u)(1+v)); bta = -2*log2(e)*ba and bsb = -log2(e)*bb come pre-scaled from LDS.
-__device__ __forceinline__ float gate_fn(float a, float b, float bta, float bsb) {
-    const float u = fast_exp2(fminf(fmaf(a, kGateKt, bta), 30.f));
-    const float v = fast_exp2(fminf(fmaf(b, kGateKs, bsb), 30.f));
-    const float p = 1.f + u;
-    return (1.f - u) * fast_rcp(fmaf(p, v, p));
+// g = tanh(a + ba) * sigmoid(b + bb) for two values at a time with packed fp32 math (v_pk_fma/add/mul):
+//   u = 2^min(kt*a + bta, 30) = e^{-2(a+ba)},  v = 2^(ks*b + bsb) = e^{-(b+bb)},  g = (1-u) / ((1+u)(1+v))
+// 2 v_exp + 1 v_rcp per value; bta = kt*ba and bsb = ks*bb come pre-scaled from LDS.  Only the tanh side
+// needs the clamp: v = inf gives (1+u)(1+v) = inf -> rcp = 0 -> g = 0, the correct limit.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gate2(f32x2 a, f32x2 b, f32x2 bta, f32x2 bsb) {
+    f32x2 at = a * f32x2{kGateKt, kGateKt} + bta;
+    const f32x2 as = b * f32x2{kGateKs, kGateKs} + bsb;
+    at[0] = fminf(at[0], 30.f);
+    at[1] = fminf(at[1], 30.f);
+    const f32x2 u = {fast_exp2(at[0]), fast_exp2(at[1])};
+    const f32x2 v = {fast_exp2(as[0]), fast_exp2(as[1])};
+    const f32x2 p = u + f32x2{1.f, 1.f};
+    const f32x2 d = p * v + p;
+    const f32x2 r = {fast_rcp(d[0]), fast_rcp(d[1])};
+    return (f32x2{1.f, 1.f} - u) * r;
 }
 
 }  // namespace
@@ -213,22 +224,6 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
         }
 
         stamp(1);
-        // ---------------- gate: g[ch][t] -> LDS [t][ch] bf16 at [0, 64K) -------------------------------
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const f32x4 bt = *(const f32x4*)(smem + CONST_OFF + (wm * 128 + mt * 16 + qv * 4) * 4);
-            const f32x4 bs = *(const f32x4*)(smem + CONST_OFF + (wm * 128 + 64 + mt * 16 + qv * 4) * 4);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                bf16x4 gv;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gv[r] = (bf16_t)gate_fn(acc[mt][nt][r], acc[mt + 4][nt][r], bt[r], bs[r]);
-                const int t = wn * 64 + nt * 16 + r16v;
-                const int chunk = wm * 8 + mt * 2 + (qv >> 1);
-                *(bf16x4*)(smem + t * 512 + ((chunk ^ r16v) * 16) + (qv & 1) * 8) = gv;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
         const int next = tile + gridDim.x;
         const bool has_next = next < ntiles;
         int nb = 0, nt0 = 0;
@@ -237,29 +232,119 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
         // gate store, k-chunk-major [8][npos][32]: 16-B chunk c of row t -> k-chunk c>>2, 16-B sub-chunk c&3
         char* gdst = (char*)a.gout + ((size_t)b * a.L + t0) * 64;
         const size_t gkc = (size_t)a.npos * 64;
-
-        if constexpr (LAST) {
-            // the last layer's residual output is never consumed (WaveNet.py:131-135): only g leaves
-            WNL_BARRIER_LGKM();            // gate tile complete
+        auto store_g = [&]() {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int idx = it * 512 + tidv, t = idx >> 5, c = idx & 31;
                 *(uint4*)(gdst + (size_t)(c >> 2) * gkc + (size_t)t * 64 + (c & 3) * 16) = *(const uint4*)(smem + t * 512 + ((c ^ (t & 15)) * 16));
             }
+        };
+        // ---------------- gate: g[ch][t] -> LDS [t][ch] bf16 at [0, 64K) -------------------------------------
+        // Channel ownership is interleaved over the waves: tile (wm, mt) holds gate channels mt*64 + wm*16 + [0,16),
+        // so after every wave has gated its tiles `mt`, channels [64 mt, 64 mt + 64) — GEMM2 k-steps 2mt, 2mt+1 —
+        // are complete and their MFMAs run under the gate math (VALU) of tiles mt+1.
+        auto gate_tile = [&](int mt, int nt, const f32x4& bt, const f32x4& bs) {
+            const f32x4 ha = acc[mt][nt], hb = acc[mt + 4][nt];
+            const f32x2 g01 = gate2(f32x2{ha[0], ha[1]}, f32x2{hb[0], hb[1]}, f32x2{bt[0], bt[1]}, f32x2{bs[0], bs[1]});
+            const f32x2 g23 = gate2(f32x2{ha[2], ha[3]}, f32x2{hb[2], hb[3]}, f32x2{bt[2], bt[3]}, f32x2{bs[2], bs[3]});
+            const bf16x4 gv = {(bf16_t)g01[0], (bf16_t)g01[1], (bf16_t)g23[0], (bf16_t)g23[1]};
+            const int t = wn * 64 + nt * 16 + r16v;
+            const int chunk = mt * 8 + wm * 2 + (qv >> 1);
+            *(bf16x4*)(smem + t * 512 + ((chunk ^ r16v) * 16) + (qv & 1) * 8) = gv;
+        };
+        auto gate_bias = [&](int mt, f32x4& bt, f32x4& bs) {
+            bt = *(const f32x4*)(smem + CONST_OFF + (wm * 128 + mt * 16 + qv * 4) * 4);
+            bs = *(const f32x4*)(smem + CONST_OFF + (wm * 128 + 64 + mt * 16 + qv * 4) * 4);
+        };
+
+        if constexpr (LAST) {
+            // the last layer's residual output is never consumed (WaveNet.py:131-135): only g leaves
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                f32x4 bt, bs;
+                gate_bias(mt, bt, bs);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    gate_tile(mt, nt, bt, bs);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            WNL_BARRIER_LGKM();            // gate tile complete
+            store_g();
             if (!has_next) return;
             WNL_BARRIER_LGKM();            // every wave has read its part of the gate tile: slot C is free
             stage1(hin_n, 0);
             stage1(hin_n, 1);
             stage1(hin_n, 2);
         } else {
+            {
+                f32x4 bt, bs;
+                gate_bias(0, bt, bs);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    gate_tile(0, nt, bt, bs);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             stamp(2);
-            WNL_WAIT_BARRIER(0);           // gate tile complete, GEMM2 stages 0-4 landed
+            WNL_WAIT_BARRIER(0);           // g channels [0,64) complete, GEMM2 weight stages 0-4 landed
             stamp(3);
 
-            // residual rows + embedding for the epilogue: issued now, consumed after GEMM2
-            // ordinary loads + the gate-tile stores, issued while no DMA is in flight: epilogue constant, residual
-            // rows, then the 8 stores (so that hipcc's own count sees >= 4 younger ops behind the loads, see below)
-            const f32x4 e0 = *(const f32x4*)(a.epi_c + (tidv & 31) * 8);   // b_res * sqrt(1/2) + emb_{n+1}, this thread's 8 channels
+            // ---------------- GEMM2 (res = W_res * g) pipelined against the rest of the gate ------------------
+            f32x4 acc2[4][4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 b2[4], a2[4];
+            auto read2 = [&](int ks2, int buf) {
+                const char* A = smem + GEMM2_BUF + buf * 16384 + wm * 4096 + r16v * 64 + ((qv ^ swz64(r16v)) * 16);
+                const char* G = smem + (wn * 64 + r16v) * 512 + (((ks2 * 4 + qv) ^ r16v) * 16);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) b2[nt] = *(const bf16x8*)(G + nt * 8192);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) a2[mt] = *(const bf16x8*)(A + mt * 1024);
+            };
+            auto mfma2 = [&](int m0, int m1) {
+#pragma unroll
+                for (int mt = m0; mt < m1; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = mfma16(a2[mt], b2[nt], acc2[mt][nt]);
+            };
+            // one phase: gate tiles (mt, 0..3) interleaved with the 2 x 16 MFMAs of k-steps ka (buffer bufa), kb (bufb)
+            auto phase = [&](int mt, int ka, int bufa, int kb, int bufb) {
+                f32x4 bt, bs;
+                gate_bias(mt, bt, bs);
+                read2(ka, bufa);
+                __builtin_amdgcn_sched_barrier(0);
+                gate_tile(mt, 0, bt, bs);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma2(0, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                gate_tile(mt, 1, bt, bs);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma2(2, 4);
+                __builtin_amdgcn_sched_barrier(0);
+                read2(kb, bufb);
+                __builtin_amdgcn_sched_barrier(0);
+                gate_tile(mt, 2, bt, bs);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma2(0, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                gate_tile(mt, 3, bt, bs);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma2(2, 4);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            phase(1, 0, 0, 1, 1);
+            WNL_WAIT_BARRIER(0);           // g channels [64,128) complete; buffers 0-1 free (nothing is in flight)
+            stage2(5, 0);
+            stage2(6, 1);
+            phase(2, 2, 2, 3, 3);
+            WNL_WAIT_BARRIER(0);           // g channels [128,192) complete; stages 5-6 landed; buffers 2-3 free
+            // ordinary loads, issued right behind a vmcnt(0) barrier and retired by the next one (see the header):
+            // epilogue constant b_res * sqrt(1/2) + emb_{n+1} of this thread's 8 channels, residual rows
+            const f32x4 e0 = *(const f32x4*)(a.epi_c + (tidv & 31) * 8);
             const f32x4 e1 = *(const f32x4*)(a.epi_c + (tidv & 31) * 8 + 4);
             bf16x8 hv[8];
 #pragma unroll
@@ -267,49 +352,14 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
                 const int idx = it * 512 + tidv, t = idx >> 5, cg = idx & 31;
                 hv[it] = *(const bf16x8*)(hin_c + (size_t)t * 512 + cg * 16);
             }
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {   // stream the gate tile to HBM
-                const int idx = it * 512 + tidv, t = idx >> 5, c = idx & 31;
-                *(uint4*)(gdst + (size_t)(c >> 2) * gkc + (size_t)t * 64 + (c & 3) * 16) = *(const uint4*)(smem + t * 512 + ((c ^ (t & 15)) * 16));
-            }
-
-            // ---------------- GEMM2: res = W_res * g ---------------------------------------------------
-            f32x4 acc2[4][4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            auto compute2 = [&](int ks2, int buf) {
-                const char* A = smem + GEMM2_BUF + buf * 16384 + wm * 4096 + r16v * 64 + ((qv ^ swz64(r16v)) * 16);
-                const char* G = smem + (wn * 64 + r16v) * 512 + (((ks2 * 4 + qv) ^ r16v) * 16);
-                bf16x8 b2[4], a2[4];
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) b2[nt] = *(const bf16x8*)(G + nt * 8192);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) a2[mt] = *(const bf16x8*)(A + mt * 1024);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = mfma16(a2[mt], b2[nt], acc2[mt][nt]);
-            };
-            // 8 weight stages through 5 buffers: stage 5/6/7 reuse buffer 0/1/2 as soon as every wave has read it
-            compute2(0, 0);
-            WNL_BARRIER_LGKM();
-            stage2(5, 0);
-            compute2(1, 1);
-            WNL_BARRIER_LGKM();
-            stage2(6, 1);
-            compute2(2, 2);
-            WNL_BARRIER_LGKM();
             stage2(7, 2);
-            compute2(3, 3);
-            compute2(4, 4);
-            WNL_WAIT_BARRIER(4);           // stage 5 landed (6-7 may fly); every ordinary load and store above is older
-            compute2(5, 0);
-            WNL_WAIT_BARRIER(2);
-            compute2(6, 1);
-            WNL_WAIT_BARRIER(0);
-            compute2(7, 2);
+            phase(3, 4, 4, 5, 0);
+            WNL_WAIT_BARRIER(0);           // gate tile complete; stage 7 and the ordinary loads landed
+            store_g();                     // stream the gate tile to HBM
+            read2(6, 1);
+            mfma2(0, 4);
+            read2(7, 2);
+            mfma2(0, 4);
 
             // ---------------- next tile's first stages + epilogue in two 64-row halves -----------------
             stamp(4);
