@@ -393,7 +393,7 @@ int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipS
     return 0;
 }
 
-int mel_db(dmad_engine* e, const float* x, int B, float* spec, hipStream_t s) {
+int mel_db(dmad_engine* e, const float* x, int B, float* spec, hipStream_t s, int to_db = 1) {
     if (!e->cfg.with_classifier) return fail(DMAD_ERR_STATE, "engine was created with with_classifier = 0");
     if (B < 1 || B > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d]", B, e->maxB);
     const long rows = (long)B * 32;
@@ -405,7 +405,7 @@ int mel_db(dmad_engine* e, const float* x, int B, float* spec, hipStream_t s) {
     launch_gemm_f32(g, s);
     launch_mel_power(e->dftD, e->melP, kDftLd, kMelLd, rows, s);
     launch_gemm_f32(plain_gemm(e->fbA, e->melP, e->melM, nullptr, nullptr, 32, kMelLd, rows, 32, kMelLd, 0), s);
-    launch_mel_db(e->melM, spec, B, s);
+    launch_mel_db(e->melM, spec, B, to_db, s);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -629,6 +629,18 @@ int dmad_diffuse(dmad_engine* e, const float* x0, float c_a, float c_b, const fl
 int dmad_mel_db(dmad_engine* e, const float* x, int32_t B, float* spec, dmad_stream s) {
     if (!e || !x || !spec) return fail(DMAD_ERR_INVALID, "null argument");
     return mel_db(e, x, B, spec, (hipStream_t)s);
+}
+
+int dmad_mel_power(dmad_engine* e, const float* x, int32_t B, float* mel, dmad_stream s) {
+    if (!e || !x || !mel) return fail(DMAD_ERR_INVALID, "null argument");
+    return mel_db(e, x, B, mel, (hipStream_t)s, 0);
+}
+
+int dmad_power_to_db(dmad_engine* e, const float* x, int64_t n, float* y, dmad_stream s) {
+    if (!e || !x || !y || n < 0) return fail(DMAD_ERR_INVALID, "bad argument");
+    if (n) launch_power_to_db(x, y, (long)n, (hipStream_t)s);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 int dmad_classify(dmad_engine* e, const float* spec, int32_t B, float* logits, dmad_stream s) {

@@ -260,11 +260,12 @@ __global__ void mel_power_kernel(const float* __restrict__ D, float* __restrict_
 }
 
 // spec[b][mel][frame] = 10 * log10(max(M[b*32 + frame][mel], 1e-10))
-__global__ void mel_db_kernel(const float* __restrict__ M, float* __restrict__ spec, long total) {
+__global__ void mel_db_kernel(const float* __restrict__ M, float* __restrict__ spec, long total, int to_db) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const long b = i >> 10;
     const int mel = (int)((i >> 5) & 31), fr = (int)(i & 31);
+    if (!to_db) { spec[i] = M[(b * 32 + fr) * 32 + mel]; return; }     // MelSpectrogram alone: power, [b][mel][frame]
     const float v = fmaxf(M[(b * 32 + fr) * 32 + mel], 1e-10f);
     // fp32 log10 rounded from a double evaluation (10*log10(1e-10f) must be exactly -100 like on the CPU)
     spec[i] = __fmul_rn(10.f, (float)log10((double)v));
@@ -378,9 +379,17 @@ void launch_mel_power(const float* D, float* P, int ldd, int ldp, long rows, hip
     const long total = rows * ldp;
     hipLaunchKernelGGL(mel_power_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, D, P, ldd, ldp, total);
 }
-void launch_mel_db(const float* M, float* spec, int B, hipStream_t s) {
+void launch_mel_db(const float* M, float* spec, int B, int to_db, hipStream_t s) {
     const long total = (long)B * 1024;
-    hipLaunchKernelGGL(mel_db_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, M, spec, total);
+    hipLaunchKernelGGL(mel_db_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, M, spec, total, to_db);
+}
+// AmplitudeToDB(stype='power') on its own: y = 10 * log10(max(x, 1e-10))
+__global__ void power_to_db_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = __fmul_rn(10.f, (float)log10((double)fmaxf(x[i], 1e-10f)));
+}
+void launch_power_to_db(const float* x, float* y, long n, hipStream_t s) {
+    hipLaunchKernelGGL(power_to_db_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, x, y, n);
 }
 void launch_vgg_conv1(const float* in, const float* w, const float* scale, const float* shift, float* out, int B, hipStream_t s) {
     const long total = (long)B * 1024 * 64;

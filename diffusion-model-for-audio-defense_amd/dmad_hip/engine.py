@@ -197,6 +197,21 @@ class Engine:
             check(self.lib.dmad_mel_db(self._h, _ptr(x[s:e]), e - s, _ptr(out[s:e]), _stream()))
         return out
 
+    def mel_power(self, x: torch.Tensor) -> torch.Tensor:
+        x = self._wave(x)
+        out = torch.empty((x.shape[0], 1, 32, 32), device=x.device, dtype=torch.float32)
+        for s, e in self._chunks(x.shape[0]):
+            check(self.lib.dmad_mel_power(self._h, _ptr(x[s:e]), e - s, _ptr(out[s:e]), _stream()))
+        return out
+
+    def power_to_db(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise DmadError('input must live on the GPU (the dmad engine has no CPU path)')
+        xc = x.detach().contiguous().float()
+        out = torch.empty_like(xc)
+        check(self.lib.dmad_power_to_db(self._h, _ptr(xc), xc.numel(), _ptr(out), _stream()))
+        return out
+
     def classify(self, spec: torch.Tensor) -> torch.Tensor:
         if not spec.is_cuda:
             raise DmadError('input must live on the GPU (the dmad engine has no CPU path)')

@@ -50,10 +50,15 @@ class RobustCertificate():
     def _fused(self):
         """True when every stage is HIP-backed and lives in one engine."""
         from dmad_hip.transforms import MelSpectrogramDB
-        den, cls = self.denoiser, self.classifier
+        den, cls, tr = self.denoiser, self.classifier, self.transform
         eng = getattr(den, 'engine', None)
-        return (eng is not None and isinstance(self.transform, MelSpectrogramDB) and getattr(cls, 'engine', None) is eng
-                and eng.has_classifier and eng.has_wavenet)
+        is_mel_db = isinstance(tr, MelSpectrogramDB)
+        if not is_mel_db:       # the reference's own Compose([MelSpectrogram, AmplitudeToDB]) through the opt-in shims
+            stages = [getattr(t, '_dmad_stage', None) for t in getattr(tr, 'transforms', [])]
+            is_mel_db = stages == ['mel_power', 'power_to_db']
+        if eng is not None and is_mel_db and 'engine' not in getattr(cls, '__dict__', {}) and hasattr(cls, 'bind_engine'):
+            cls.bind_engine(eng)                            # HIP-backed VGG not yet bound: bind it to the denoiser's engine
+        return (eng is not None and is_mel_db and getattr(cls, 'engine', None) is eng and eng.has_classifier and eng.has_wavenet)
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor):

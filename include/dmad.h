@@ -93,6 +93,11 @@ int dmad_diffuse(dmad_engine* e, const float* x0, float c_a, float c_b, const fl
  * spec: [B][32 mel][32 frames] fp32. */
 int dmad_mel_db(dmad_engine* e, const float* x, int32_t B, float* spec, dmad_stream s);
 
+/* The two stages of that transform on their own (for callers that keep torchaudio's two-module Compose):
+ * mel = MelSpectrogram(...)(x): power mel spectrogram [B][32][32]; y = AmplitudeToDB('power')(x) elementwise. */
+int dmad_mel_power(dmad_engine* e, const float* x, int32_t B, float* mel, dmad_stream s);
+int dmad_power_to_db(dmad_engine* e, const float* x, int64_t n, float* y, dmad_stream s);
+
 /* logits = VGG19_bn(spec)  — VGG.forward, audio_models/ConvNets_SpeechCommands/models/vgg.py:48-52.
  * spec: [B][32][32] fp32, logits: [B][num_classes] fp32. */
 int dmad_classify(dmad_engine* e, const float* spec, int32_t B, float* logits, dmad_stream s);

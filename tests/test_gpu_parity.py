@@ -299,3 +299,52 @@ def test_full_size_properties(engines, sched):
     assert int(a.sum()) == 60 and torch.equal(a, b)
     c, _, _ = eng.smooth_votes(clip, 0.5, sc, 65, *coef(65), 0, seed=5)
     assert int(c.sum()) == 0                                                    # empty input
+
+
+def test_reference_driver_surfaces_through_shims(engines, golden_dir, tmp_path, monkeypatch):
+    """The certification driver's own construction sequence (certified_robustness_eval.py:52-96), with the opt-in
+    torchaudio / torchvision shims: create_model -> create_diffwave_model -> Compose([MelSpectrogram, AmplitudeToDB])
+    -> RobustCertificate.certify, on synthetic checkpoints written in the reference's formats."""
+    import json
+    import sys
+    shim_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'diffusion-model-for-audio-defense_amd', 'shims')
+    monkeypatch.syspath_prepend(shim_dir)
+    for m in ('torchaudio', 'torchaudio.transforms', 'torchvision', 'torchvision.transforms'):
+        monkeypatch.delitem(sys.modules, m, raising=False)
+    import torchaudio
+    from torchvision.transforms import Compose
+    from audio_models.ConvNets_SpeechCommands.create_model import create_model
+    from models.vgg import vgg19_bn          # the module path the reference's checkpoints were pickled under
+    from diffusion_models.diffwave_ddpm import create_diffwave_model
+    from dmad_hip import engine as E
+    from robustness_eval.certified_robust import RobustCertificate
+    eng = engines['fp32']
+    monkeypatch.setitem(E._ENGINES, (torch.cuda.current_device(), E.BF16), eng)     # what get_engine() hands out
+    # checkpoints in the reference's on-disk formats (SURVEY Appendix B)
+    d = tmp_path / 'ConvNets_SpeechCommands'
+    d.mkdir()
+    net = vgg19_bn(num_classes=10, in_channels=1)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.vgg19_bn_state_dict(4321).items()})
+    torch.save(torch.nn.DataParallel(net), str(d / 'vgg.pth'))
+    torch.save({'model_state_dict': {k: torch.from_numpy(v) for k, v in synth.wavenet_state_dict(1234).items()},
+                'optimizer_state_dict': {}}, str(tmp_path / '1000000.pkl'))
+    cfg = str(tmp_path / 'config.json')
+    json.dump({'wavenet_config': synth.WAVENET_CONFIG, 'diffusion_config': synth.DIFFUSION_CONFIG}, open(cfg, 'w'))
+
+    Classifier = create_model(str(d / 'vgg.pth'))
+    Classifier.cuda()
+    DiffWave_Denoiser = create_diffwave_model(model_path=str(tmp_path / '1000000.pkl'), config_path=cfg, engine=eng)
+    DiffWave_Denoiser.eval().cuda()
+    MelSpecTrans = torchaudio.transforms.MelSpectrogram(n_fft=2048, hop_length=512, n_mels=32, norm='slaney', pad_mode='constant', mel_scale='slaney')
+    Amp2DB = torchaudio.transforms.AmplitudeToDB(stype='power')
+    Wave2Spect = Compose([MelSpecTrans.cuda(), Amp2DB.cuda()])
+    x = torch.from_numpy(np.stack([synth.synthetic_clip(0), synth.synthetic_clip(3)])).cuda()
+    ref = eng.mel_db(x)
+    assert torch.equal(Wave2Spect(x), ref)                                # two-stage shim == fused transform
+    RC = RobustCertificate(classifier=Classifier, transform=Wave2Spect, denoiser=DiffWave_Denoiser, noise_source='torch_cpu')
+    assert RC._fused()
+    z = G(golden_dir, 'smooth_predict.npz')
+    torch.manual_seed(int(z['certify_seed']))
+    y_certified, r_certified = RC.certify(x=x[:1], y=torch.tensor([3]).cuda(), sigma=0.25, n_0=16, n=32, batch_size=16)
+    assert y_certified.tolist() == z['certify_ypred'].tolist()
+    assert abs(float(r_certified[0]) - float(z['certify_radius'][0])) < 1e-6
