@@ -727,11 +727,11 @@ int dmad_time_layer(dmad_engine* e, int32_t layer, int32_t B, int32_t iters, flo
     if (dbg) {      // diagnostic: mean phase lengths in shader cycles (s_memtime), printed to stderr
         std::vector<unsigned long long> h(nblk * 8);
         HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-        double sum[7] = {0};
+        double sum[9] = {0};
         for (size_t i = 0; i < 256 && i < nblk; ++i)   // per-workgroup phase sums over all its tiles
-            for (int k = 0; k < 6; ++k) sum[k + 1] += (double)h[i * 8 + k];
-        fprintf(stderr, "[dmad stamps] prologue %.0f | gemm1 %.0f | gate %.0f | barrier %.0f | gemm2 %.0f | epilogue %.0f  (mean cycles per tile, %zu tiles)\n",
-                sum[1] / nblk, sum[2] / nblk, sum[3] / nblk, sum[4] / nblk, sum[5] / nblk, sum[6] / nblk, nblk);
+            for (int k = 0; k < 8; ++k) sum[k + 1] += (double)h[i * 8 + k];
+        fprintf(stderr, "[dmad stamps] top-wait %.0f | gemm1 %.0f | gate0+barrier %.0f | gate||gemm2 %.0f | barrier %.0f | epi0 write %.0f | epi0 rows %.0f | epi1 %.0f  (mean cycles per tile, %zu tiles)\n",
+                sum[1] / nblk, sum[2] / nblk, sum[3] / nblk, sum[4] / nblk, sum[5] / nblk, sum[6] / nblk, sum[7] / nblk, sum[8] / nblk, nblk);
         (void)hipFree(dbg);
     }
     return 0;

@@ -96,7 +96,7 @@ __device__ __forceinline__ f32x2 gate2(f32x2 a, f32x2 b, f32x2 bta, f32x2 bsb) {
 template <bool LAST, bool STAMP = false>
 __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int ntiles) {
     // STAMP: diagnostic build only (per-phase cycle sums of wave 0 into a.dbg[block][8]); never shipped/timed
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int k) {
         if constexpr (STAMP) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
     auto flush = [&]() {
         if constexpr (STAMP) {
             if (threadIdx.x == 0)
-                for (int k = 0; k < 6; ++k) a.dbg[(size_t)blockIdx.x * 8 + k] = tacc[k];
+                for (int k = 0; k < 8; ++k) a.dbg[(size_t)blockIdx.x * 8 + k] = tacc[k];
         }
     };
     stamp(-1);
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
             const int cur = ks & 1, nxt = cur ^ 1;
             // stage ks+1 landed; stage ks+2 (and, on a later tile's first step, 8 stores) may still fly
             if (ks == 0) {
-                if (LAST || first) { WNL_WAIT_BARRIER(5); } else { WNL_WAIT_BARRIER(13); }
+                if (LAST || first) { WNL_WAIT_BARRIER(5); } else { WNL_WAIT_BARRIER(9); }   // 4 h' stores + stage 2
             } else if (ks <= 21) { WNL_WAIT_BARRIER(5); }
             else if (ks == 22) { WNL_WAIT_BARRIER(0); }
             else { WNL_BARRIER_LGKM(); }                   // every wave holds its last fragments: ring free
@@ -286,9 +286,8 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            stamp(2);
             WNL_WAIT_BARRIER(0);           // g channels [0,64) complete, GEMM2 weight stages 0-4 landed
-            stamp(3);
+            stamp(2);
 
             // ---------------- GEMM2 (res = W_res * g) pipelined against the rest of the gate ------------------
             f32x4 acc2[4][4];
@@ -362,15 +361,18 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
             mfma2(0, 4);
 
             // ---------------- next tile's first stages + epilogue in two 64-row halves -----------------
-            stamp(4);
+            stamp(3);
             WNL_BARRIER_LGKM();            // every wave is done with the gate tile and the weight buffers
-            if (has_next) {
-                stage1(hin_n, 0);          // ring slots A/B = [80K,160K): not touched by the epilogue tile
-                stage1(hin_n, 1);
-            }
+            stamp(4);
+            // The 10 DMA pieces of the next tile's stages 0-1 (ring slots A/B = [80K,160K), not touched by the epilogue
+            // tile) are spread over the epilogue: the waves that have nothing to write in half 0 issue stage 0 while the
+            // others fill the LDS tile, stage 1 goes out piece by piece between the row items.  Every wave issues the
+            // same ORDER of vector-memory ops (5 DMA, store, DMA, store, DMA, store, DMA, store, 2 DMA, 4 stores, 5 DMA),
+            // so the counted waits of the next tile are the same for all of them.
             char* hout_c = (char*)(a.hout + ((size_t)b * a.LP + kPad + t0) * kC);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                if (h == 0 && has_next && wn == 1) stage1(hin_n, 0);
                 if (wn == h) {
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
@@ -380,7 +382,9 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
                             *(f32x4*)(smem + row * EPI_PITCH + ch * 4) = acc2[mt][nt];
                         }
                 }
+                if (h == 0 && has_next && wn == 0) stage1(hin_n, 0);
                 WNL_BARRIER_LGKM();
+                if (h == 0) stamp(5);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int idx = it * 512 + tidv, row = idx >> 5, cg = idx & 31;
@@ -394,10 +398,16 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
                         o[j + 4] = (bf16_t)(((float)hh[j + 4] + r1[j]) * 0.70710678118654752440f + e1[j]);
                     }
                     *(bf16x8*)(hout_c + (size_t)(h * 64 + row) * 512 + cg * 16) = o;
+                    if (h == 0 && has_next) {
+                        stage1_piece(hin_n, 1, it);
+                        if (it == 3) stage1_piece(hin_n, 1, 4);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 WNL_BARRIER_LGKM();        // the half tile has been read: it may be overwritten
+                if (h == 0) stamp(6);
             }
-            stamp(5);
+            stamp(7);
             if (!has_next) { flush(); return; }
             stage1(hin_n, 2);              // ring slot C = [0,40K) is free now
         }
