@@ -19,6 +19,13 @@ constexpr int kC = 256;          // res_channels == skip_channels
 constexpr int kPad = 2048;       // zero rows on each side of a clip in the residual stream (max dilation)
 constexpr int kTileT = 128;      // time positions per workgroup tile
 
+// Residual stream layout "H16" (bf16, per clip kPad + L + kPad rows of 256 channels): 16 consecutive rows form
+// an 8 KiB block stored [32 chunks of 8 channels][16 rows][8 ch], i.e. the 16-byte chunk (row, c) lives at
+// (row >> 4) * 8192 + c * 256 + (row & 15) * 16.  A 16x16 MFMA accumulator tile (16 samples x 4 channels per lane
+// group) then maps to 256-byte contiguous runs, so the epilogue stores straight from registers, and the LDS-DMA
+// of the next layer (per-lane source address) gathers its 16-byte chunks from the same layout.
+__host__ __device__ inline unsigned h16_off(unsigned row, unsigned chunk) { return (row >> 4) * 8192u + chunk * 256u + (row & 15u) * 16u; }
+
 // 16-byte-chunk swizzle for 64-byte LDS rows read as MFMA 16x16x32 operands with ds_read_b128
 // (conflict-free for the four 16-lane groups of ds_read_b128, see DESIGN.md "LDS images").
 __host__ __device__ inline int swz64(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }  // {0,2,3,1}[(row>>2)&3]

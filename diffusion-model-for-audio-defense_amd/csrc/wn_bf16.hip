@@ -17,7 +17,8 @@
 //                  relu(W_f0 * skip/6 + b) and the 256->1 output conv.
 //
 // Layouts:
-//   residual stream h : bf16 [B][kPad + L + kPad][256], pad rows are zero and never written
+//   residual stream h : bf16 [B][kPad + L + kPad rows][256] in the blocked "H16" order (dmad_common.h: 16-row blocks,
+//                       chunk-major inside a block); pad rows are zero and never written
 //   gate store g      : bf16 [layer][8 k-chunks][B*L positions][32 ch]  (k-chunk-major: one k-step of the
 //                       skip GEMM reads 256 positions x 64 B = 16 KiB of CONTIGUOUS HBM)
 //   packed weights    : bf16 LDS images [k-step][row][32 k], 64-B rows with the swz64 chunk swizzle
@@ -46,7 +47,7 @@ __global__ void __launch_bounds__(256) wn_init_bf16(const float* __restrict__ x,
             const float v = w[c] * xv + bias[c];
             o[j] = (bf16_t)(fmaxf(v, 0.f) + emb0[c]);
         }
-        *(bf16x8*)(h + ((bb * LP + kPad + t) * kC + cg * 8)) = o;
+        *(bf16x8*)((char*)(h + (size_t)bb * LP * kC) + h16_off((unsigned)(kPad + t), (unsigned)cg)) = o;
     }
 }
 

@@ -15,12 +15,14 @@
 //   GEMM2   res conv, 8 weight stages through five 16 KiB buffers.  Gate channels are interleaved over the
 //           waves so that GEMM2 k-steps 2mt, 2mt+1 only need the gate tiles `mt`: their MFMAs run under the
 //           VALU-bound gate math of tiles mt+1 (the matrix pipe would otherwise idle through the gate).
-//   epi     two 64-row halves through a 65 KiB fp32 LDS tile; h' = (h + res) * sqrt(1/2) + emb_{n+1}.
-//   While the epilogue runs, stages 0-1 of the NEXT tile are already in flight into ring slots A/B (the
-//   epilogue tile only covers [0, 65 KiB)), so the next tile starts without an exposed load latency.
+//   epi     h' = (h + res) * sqrt(1/2) + emb_{n+1} straight from the accumulators: the residual stream is kept in the
+//           blocked "H16" order (dmad_common.h) so that lane pairs (v_permlane16_swap) assemble 16-byte chunks and a
+//           wave-store writes 256-byte contiguous runs; no LDS round trip, no barrier.
+//   While the epilogue runs, stages 0-2 of the NEXT tile are already in flight into the ring, so the next
+//   tile starts without an exposed load latency.
 //
 // LDS map (160 KiB): ring slot A = [80K,120K), B = [120K,160K), C = [0,40K); gate tile [0,64K);
-// GEMM2 weight buffers 5 x 16 KiB at [80K,160K); epilogue half tile [0, 65K); pre-scaled dilated-conv
+// GEMM2 weight buffers 5 x 16 KiB at [80K,160K); stage-0 activation slice 8 KiB at [68K,76K); pre-scaled dilated-conv
 // bias (2 KiB) at [65K, 67K) — written once per kernel, never overwritten: the accumulators start from
 // zero and the bias enters as the addend of the gate's exp2-argument FMA.
 // The DMA pieces are issued from inline asm (saddr form) and waited for with explicit counted s_waitcnt;
@@ -38,8 +40,8 @@ namespace {
 constexpr int SLOT_BOFF = 32768;
 constexpr int GEMM2_BUF = 81920;
 constexpr int CONST_OFF = 66560;
+constexpr int B0_OFF = 69632;                 // 8 KiB: activation part of a tile's stage 0 (issued a whole phase early)
 constexpr float kGateKt = -2.8853900817779268f, kGateKs = -1.4426950408889634f;   // -2*log2(e), -log2(e)
-constexpr int EPI_PITCH = 1040;
 __device__ __forceinline__ constexpr int slot_base(int i) { return i == 0 ? 81920 : (i == 1 ? 122880 : 0); }
 
 // s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier — through the builtins so that hipcc's wait-count bookkeeping
@@ -117,9 +119,11 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
     const int wm = wv >> 1, wn = wv & 1;
     const int q = lane >> 4, r16 = lane & 15;
     const int tiles_per_clip = a.L / kTileT;
-    const int brow = tid >> 2;
-    const int boff = brow * 512 + (((tid & 3) ^ swz64(brow)) * 16);
-    const ptrdiff_t tap_bytes = (ptrdiff_t)a.dilation * 512;
+    // activation stage in LDS: 4 planes (16-byte k-chunks) x 128 rows x 16 B; wave w DMAs plane w>>1, rows (w&1)*64 + lane:
+    // consecutive lanes read consecutive 16-byte chunks of the H16 layout (256-byte runs) and write consecutive LDS bytes,
+    // and a fragment read (16 lanes = 16 consecutive rows of one plane) is bank-conflict free without a swizzle
+    const unsigned brow_w = (unsigned)((wv & 1) * 64 + lane), bplane = (unsigned)(wv >> 1) * 256u;
+    const int bfrag_off = q * 2048 + r16 * 16;
     const unsigned tid16 = (unsigned)tid * 16u;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;       // LDS byte address of the dynamic segment
     const char* w1b = (const char*)a.w1p;
@@ -130,14 +134,21 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
         b = tile / tiles_per_clip;
         t0 = (tile - b * tiles_per_clip) * kTileT;
     };
-    auto hin_center = [&](int b, int t0) { return (const char*)(a.hin + ((size_t)b * a.LP + kPad + t0) * kC); };
+    // a tile's activation source: clip base + first row (pad included) of the tile
+    struct TileSrc { const char* clip; int row0; };
+    auto tile_src = [&](int b, int t0) { return TileSrc{(const char*)(a.hin + (size_t)b * a.LP * kC), kPad + t0}; };
     // one DMA piece of GEMM1 stage ks: p < 4 -> 8 KiB of weights, p == 4 -> the 8 KiB activation slice
-    auto stage1_piece = [&](const char* hc, int ks, int p) {
+    auto stage1_piece = [&](const TileSrc& hc, int ks, int p) {
         const int sb = slot_base(ks % 3);
-        if (p < 4) dma16(w1b + ((size_t)ks * 32768 + p * 8192), tid16, lds0 + sb + wv * 1024 + p * 8192);
-        else dma16(hc + (((ks >> 3) - 1) * tap_bytes + (ks & 7) * 64), (unsigned)boff, lds0 + sb + SLOT_BOFF + wv * 1024);
+        if (p < 4) {
+            dma16(w1b + ((size_t)ks * 32768 + p * 8192), tid16, lds0 + sb + wv * 1024 + p * 8192);
+        } else {   // rows row0 + brow + (tap-1)*d, chunks kc*4 .. kc*4+3 of the H16 layout (16-byte gather per lane)
+            const unsigned row = (unsigned)(hc.row0 + ((ks >> 3) - 1) * a.dilation) + brow_w;
+            dma16(hc.clip + (ks & 7) * 1024, (row >> 4) * 8192u + (row & 15u) * 16u + bplane,
+                  lds0 + (ks == 0 ? B0_OFF : sb + SLOT_BOFF) + wv * 1024);
+        }
     };
-    auto stage1 = [&](const char* hc, int ks) {
+    auto stage1 = [&](const TileSrc& hc, int ks) {
 #pragma unroll
         for (int p = 0; p < 5; ++p) stage1_piece(hc, ks, p);
     };
@@ -151,7 +162,7 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
     if (tile >= ntiles) return;
     int b, t0;
     tile_rows(tile, b, t0);
-    const char* hin_c = hin_center(b, t0);
+    TileSrc hin_c = tile_src(b, t0);
 
     // pre-scaled dilated-conv bias -> LDS (one float per thread = one per gate row), retired before any DMA
     ((float*)(smem + CONST_OFF))[tid] = a.b1[tid] * (((tid & 127) < 64) ? kGateKt : kGateKs);
@@ -169,8 +180,13 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
         asm volatile("" : "+v"(tidv));
         const int qv = (tidv & 63) >> 4, r16v = tidv & 15;     // per-tile copies of q / r16 for the post-GEMM1 address math
         // ---------------- GEMM1 ------------------------------------------------------------------
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        int nb = 0, nt0 = 0;
+        if (has_next) tile_rows(next, nb, nt0);
+        const TileSrc hin_n = tile_src(nb, nt0);
         // outstanding VMEM ops younger than stage 0: first tile / LAST: stages 1,2 (10);
-        // later tiles: stage 1 (5) + 8 h' stores + stage 2 (5) = 18
+        // later tiles: stages 1,2 (10) + the previous tile's 8 h' stores = 18
         if (LAST || first) { WNL_WAIT_BARRIER(10); } else { WNL_WAIT_BARRIER(18); }
         stamp(0);
 #pragma unroll
@@ -180,9 +196,9 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
         bf16x8 af[2][8], bf[2][4];
         {
             const char* A = smem + slot_base(0) + wm * 8192 + frag_off;
-            const char* Bt = smem + slot_base(0) + SLOT_BOFF + wn * 4096 + frag_off;
+            const char* Bt = smem + B0_OFF + wn * 1024 + bfrag_off;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bf[0][nt] = *(const bf16x8*)(Bt + nt * 1024);
+            for (int nt = 0; nt < 4; ++nt) bf[0][nt] = *(const bf16x8*)(Bt + nt * 256);
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) af[0][mt] = *(const bf16x8*)(A + mt * 1024);
         }
@@ -190,19 +206,21 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
         for (int ks = 0; ks < 24; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
             // stage ks+1 landed; stage ks+2 (and, on a later tile's first step, 8 stores) may still fly
-            if (ks == 0) {
-                if (LAST || first) { WNL_WAIT_BARRIER(5); } else { WNL_WAIT_BARRIER(9); }   // 4 h' stores + stage 2
+            if (ks <= 1) {                                 // later tiles: the 8 h' stores are younger than stages 1, 2
+                if (LAST || first) { WNL_WAIT_BARRIER(5); } else { WNL_WAIT_BARRIER(13); }
             } else if (ks <= 21) { WNL_WAIT_BARRIER(5); }
             else if (ks == 22) { WNL_WAIT_BARRIER(0); }
             else { WNL_BARRIER_LGKM(); }                   // every wave holds its last fragments: ring free
             const char* Ar = smem + slot_base((ks + 1) % 3) + wm * 8192 + frag_off;
-            const char* Br = smem + slot_base((ks + 1) % 3) + SLOT_BOFF + wn * 4096 + frag_off;
+            const char* Br = smem + slot_base((ks + 1) % 3) + SLOT_BOFF + wn * 1024 + bfrag_off;
 #pragma unroll
             for (int p = 0; p < 5; ++p) {                  // 5 x (1 DMA piece, 4 MFMAs)
                 if (ks + 3 < 24) {
                     stage1_piece(hin_c, ks + 3, p);
                 } else if (!LAST && ks == 23) {            // GEMM2 weight stages 0-4 land under the gate math
                     stage2(p, p);
+                } else if (LAST && ks == 23 && p == 0 && has_next) {
+                    stage1_piece(hin_n, 0, 4);             // next tile's first activation slice: hide its HBM latency
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -213,7 +231,7 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
 #pragma unroll
             for (int p = 0; p < 12; ++p) {                 // 12 x (1 fragment read of k-step ks+1, 1 MFMA)
                 if (ks + 1 < 24) {
-                    if (p < 4) bf[nxt][p] = *(const bf16x8*)(Br + p * 1024);
+                    if (p < 4) bf[nxt][p] = *(const bf16x8*)(Br + p * 256);
                     else af[nxt][p - 4] = *(const bf16x8*)(Ar + (p - 4) * 1024);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -224,11 +242,6 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
         }
 
         stamp(1);
-        const int next = tile + gridDim.x;
-        const bool has_next = next < ntiles;
-        int nb = 0, nt0 = 0;
-        if (has_next) tile_rows(next, nb, nt0);
-        const char* hin_n = hin_center(nb, nt0);
         // gate store, k-chunk-major [8][npos][32]: 16-B chunk c of row t -> k-chunk c>>2, 16-B sub-chunk c&3
         char* gdst = (char*)a.gout + ((size_t)b * a.L + t0) * 64;
         const size_t gkc = (size_t)a.npos * 64;
@@ -273,7 +286,8 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
             store_g();
             if (!has_next) return;
             WNL_BARRIER_LGKM();            // every wave has read its part of the gate tile: slot C is free
-            stage1(hin_n, 0);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) stage1_piece(hin_n, 0, p);       // its activation slice is already in flight
             stage1(hin_n, 1);
             stage1(hin_n, 2);
         } else {
@@ -288,6 +302,9 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
             }
             WNL_WAIT_BARRIER(0);           // g channels [0,64) complete, GEMM2 weight stages 0-4 landed
             stamp(2);
+            // the next tile's first activation slice comes from HBM (~8k cycles): issue it three phases early into its
+            // own 8 KiB LDS region so that the next tile's first wait only covers L2-hot weight pieces
+            if (has_next) stage1_piece(hin_n, 0, 4);
 
             // ---------------- GEMM2 (res = W_res * g) pipelined against the rest of the gate ------------------
             f32x4 acc2[4][4];
@@ -336,20 +353,23 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
                 __builtin_amdgcn_sched_barrier(0);
             };
             phase(1, 0, 0, 1, 1);
-            WNL_WAIT_BARRIER(0);           // g channels [64,128) complete; buffers 0-1 free (nothing is in flight)
+            WNL_WAIT_BARRIER(1);           // g channels [64,128) complete; buffers 0-1 free (only the early slice may fly)
             stage2(5, 0);
             stage2(6, 1);
             phase(2, 2, 2, 3, 3);
             WNL_WAIT_BARRIER(0);           // g channels [128,192) complete; stages 5-6 landed; buffers 2-3 free
             // ordinary loads, issued right behind a vmcnt(0) barrier and retired by the next one (see the header):
             // epilogue constant b_res * sqrt(1/2) + emb_{n+1} of this thread's 8 channels, residual rows
-            const f32x4 e0 = *(const f32x4*)(a.epi_c + (tidv & 31) * 8);
-            const f32x4 e1 = *(const f32x4*)(a.epi_c + (tidv & 31) * 8 + 4);
-            bf16x8 hv[8];
+            f32x4 ec[4];                   // ... of this lane's output channels wm*64 + mt*16 + 4q + [0,4)
+            bf16x8 hc16[4][2];             // residual h: the 16-byte chunk this lane will overwrite (tile 2p + (q&1), see epilogue)
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int idx = it * 512 + tidv, t = idx >> 5, cg = idx & 31;
-                hv[it] = *(const bf16x8*)(hin_c + (size_t)t * 512 + cg * 16);
+            for (int mt = 0; mt < 4; ++mt) {
+                ec[mt] = *(const f32x4*)(a.epi_c + wm * 64 + mt * 16 + qv * 4);
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    const unsigned row = (unsigned)(hin_c.row0 + wn * 64 + (2 * p2 + (qv & 1)) * 16 + r16v);
+                    hc16[mt][p2] = *(const bf16x8*)(hin_c.clip + h16_off(row, (unsigned)(wm * 8 + mt * 2 + (qv >> 1))));
+                }
             }
             stage2(7, 2);
             phase(3, 4, 4, 5, 0);
@@ -360,56 +380,49 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
             read2(7, 2);
             mfma2(0, 4);
 
-            // ---------------- next tile's first stages + epilogue in two 64-row halves -----------------
+            // ---------------- next tile's stages, then the epilogue straight from the accumulators ---------------
+            // h' = (h + res) * sqrt(1/2) + c.  A lane holds 4 channels x 1 sample per accumulator tile (8 bytes); one
+            // v_permlane16_swap per dword pairs the lanes q / q^1 so that every lane ends up with a full 16-byte
+            // chunk (even q: tile 2p, odd q: tile 2p+1) and a wave-store writes 4 x 256 B contiguous runs of the H16
+            // layout.  The residual h was fetched with the same pattern and un-swapped the same way.  No LDS
+            // round trip and no barrier besides the one that frees the LDS for the next tile's stages.
             stamp(3);
             WNL_BARRIER_LGKM();            // every wave is done with the gate tile and the weight buffers
             stamp(4);
-            // The 10 DMA pieces of the next tile's stages 0-1 (ring slots A/B = [80K,160K), not touched by the epilogue
-            // tile) are spread over the epilogue: the waves that have nothing to write in half 0 issue stage 0 while the
-            // others fill the LDS tile, stage 1 goes out piece by piece between the row items.  Every wave issues the
-            // same ORDER of vector-memory ops (5 DMA, store, DMA, store, DMA, store, DMA, store, 2 DMA, 4 stores, 5 DMA),
-            // so the counted waits of the next tile are the same for all of them.
-            char* hout_c = (char*)(a.hout + ((size_t)b * a.LP + kPad + t0) * kC);
+            if (has_next) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (h == 0 && has_next && wn == 1) stage1(hin_n, 0);
-                if (wn == h) {
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < 4; ++nt) {
-                            const int row = nt * 16 + r16v, ch = wm * 64 + mt * 16 + qv * 4;
-                            *(f32x4*)(smem + row * EPI_PITCH + ch * 4) = acc2[mt][nt];
-                        }
-                }
-                if (h == 0 && has_next && wn == 0) stage1(hin_n, 0);
-                WNL_BARRIER_LGKM();
-                if (h == 0) stamp(5);
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int idx = it * 512 + tidv, row = idx >> 5, cg = idx & 31;
-                    const f32x4 r0 = *(const f32x4*)(smem + row * EPI_PITCH + cg * 32);
-                    const f32x4 r1 = *(const f32x4*)(smem + row * EPI_PITCH + cg * 32 + 16);
-                    const bf16x8 hh = hv[h * 4 + it];
-                    bf16x8 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        o[j] = (bf16_t)(((float)hh[j] + r0[j]) * 0.70710678118654752440f + e0[j]);
-                        o[j + 4] = (bf16_t)(((float)hh[j + 4] + r1[j]) * 0.70710678118654752440f + e1[j]);
-                    }
-                    *(bf16x8*)(hout_c + (size_t)(h * 64 + row) * 512 + cg * 16) = o;
-                    if (h == 0 && has_next) {
-                        stage1_piece(hin_n, 1, it);
-                        if (it == 3) stage1_piece(hin_n, 1, 4);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                WNL_BARRIER_LGKM();        // the half tile has been read: it may be overwritten
-                if (h == 0) stamp(6);
+                for (int p = 0; p < 4; ++p) stage1_piece(hin_n, 0, p);   // its activation slice is already in flight
+                stage1(hin_n, 1);
+                stage1(hin_n, 2);
             }
+            char* hout_clip = (char*)(a.hout + (size_t)b * a.LP * kC);
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    // un-swap the residual: X = this lane's 4 channels of tile 2p, Y = of tile 2p+1
+                    const u32x4 hc4 = __builtin_bit_cast(u32x4, hc16[mt][p2]);
+                    const auto h0 = __builtin_amdgcn_permlane16_swap(hc4[0], hc4[2], false, false);
+                    const auto h1 = __builtin_amdgcn_permlane16_swap(hc4[1], hc4[3], false, false);
+                    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                    const bf16x4 hx = __builtin_bit_cast(bf16x4, u32x2{h0[0], h1[0]});
+                    const bf16x4 hy = __builtin_bit_cast(bf16x4, u32x2{h0[1], h1[1]});
+                    bf16x4 ox, oy;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ox[r] = (bf16_t)(((float)hx[r] + acc2[mt][2 * p2][r]) * 0.70710678118654752440f + ec[mt][r]);
+                        oy[r] = (bf16_t)(((float)hy[r] + acc2[mt][2 * p2 + 1][r]) * 0.70710678118654752440f + ec[mt][r]);
+                    }
+                    const u32x2 oxu = __builtin_bit_cast(u32x2, ox), oyu = __builtin_bit_cast(u32x2, oy);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(oxu[0], oyu[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(oxu[1], oyu[1], false, false);
+                    const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};
+                    const unsigned row = (unsigned)(hin_c.row0 + wn * 64 + (2 * p2 + (qv & 1)) * 16 + r16v);
+                    *(u32x4*)(hout_clip + h16_off(row, (unsigned)(wm * 8 + mt * 2 + (qv >> 1)))) = chunk;
+                }
             stamp(7);
             if (!has_next) { flush(); return; }
-            stage1(hin_n, 2);              // ring slot C = [0,40K) is free now
         }
         hin_c = hin_n;
         tile = next;
