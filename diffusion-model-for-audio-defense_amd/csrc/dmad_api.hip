@@ -145,14 +145,16 @@ struct dmad_engine {
 namespace {
 
 // [ksteps][rows][32] bf16 LDS image of W[row][K] (row-major, K = ksteps*32), 64-B rows, swz64 chunks
-void pack_rows(const float* W, int rows, int K, long ldw, const int* row_map, std::vector<uint16_t>& out, size_t base) {
+// k-step ks of W lands in stage ks * smul + sadd of the image (GEMM1 interleaves the three taps' k-steps)
+void pack_rows(const float* W, int rows, int K, long ldw, const int* row_map, std::vector<uint16_t>& out, size_t base,
+               int smul = 1, int sadd = 0) {
     const int ksteps = K / 32;
     for (int ks = 0; ks < ksteps; ++ks)
         for (int R = 0; R < rows; ++R) {
             const float* src = W + (long)(row_map ? row_map[R] : R) * ldw + ks * 32;
             for (int slot = 0; slot < 4; ++slot) {
                 const int c = slot ^ swz64(R);
-                for (int j = 0; j < 8; ++j) out[base + ((size_t)(ks * rows + R) * 32) + slot * 8 + j] = f2bf(src[c * 8 + j]);
+                for (int j = 0; j < 8; ++j) out[base + ((size_t)((ks * smul + sadd) * rows + R) * 32) + slot * 8 + j] = f2bf(src[c * 8 + j]);
             }
         }
 }
@@ -206,7 +208,7 @@ int finalize_wavenet(dmad_engine* e) {
             for (int tap = 0; tap < 3; ++tap) {
                 for (int oc = 0; oc < 512; ++oc)
                     for (int ci = 0; ci < 256; ++ci) tapw[(size_t)oc * 256 + ci] = dw[((size_t)oc * 256 + ci) * 3 + tap];
-                pack_rows(tapw.data(), 512, 256, 256, rmap, w1p, ((size_t)n * 24 + tap * 8) * 512 * 32);
+                pack_rows(tapw.data(), 512, 256, 256, rmap, w1p, (size_t)n * 24 * 512 * 32, 3, tap);   // stage = 3 * kchunk + tap
             }
             for (int R = 0; R < 512; ++R) b1p[(size_t)n * 512 + R] = db[rmap[R]];
             pack_rows(rw.data(), 256, 256, 256, nullptr, w2p, (size_t)n * 8 * 256 * 32);

@@ -10,7 +10,7 @@ struct WnLayerArgs {
     const bf16_t* hin;       // [B][LP][256] residual stream in  (h_n = x_n + fc_t_n(emb))
     bf16_t* hout;            // [B][LP][256] residual stream out (h_{n+1})
     bf16_t* gout;            // [8][B*L][32]  gate output of this layer, k-chunk-major
-    const bf16_t* w1p;       // [24][512][32] dilated-conv weights, packed LDS images
+    const bf16_t* w1p;       // [24][512][32] dilated-conv weights, packed LDS images; stage = 3 * kchunk + tap
     const bf16_t* w2p;       // [8][256][32]  res-conv weights, packed LDS images
     const float* b1;         // [512] dilated-conv bias in tile-row order
     const float* epi_c;      // [256] b_res * sqrt(1/2) + fc_t_{n+1}(emb): epilogue constant (unused when last)

@@ -4,9 +4,11 @@
 // (Residual_block.forward, DiffWave_Unconditional/WaveNet.py:75-97).  This file holds the production
 // schedule; the earlier schedules in wn_bf16.hip are kept only as A/B baselines for tools/gpu_ablate.py.
 //
-// One workgroup (8 waves, 1 per CU) walks over time tiles  tile = blockIdx.x + i * gridDim.x.
+// One workgroup (8 waves, 1 per CU) walks over time tiles; each XCD's workgroups share one contiguous tile range.
 // Per tile (128 time samples of one clip, all 512 gate rows):
-//   GEMM1   24 k-steps of 32 through a 3-slot LDS ring (slot = 32 KiB weights + 8 KiB activations);
+//   GEMM1   24 k-steps of 32 through a 3-slot LDS ring (slot = 32 KiB weights + 8 KiB activations), k-step
+//           ks = 3 * kchunk + tap: the three taps of one 32-channel chunk follow each other, so the rows
+//           they share (or that a neighbouring tile of the same XCD reads as its other tap) are still in L2;
 //           the global_load_lds pieces of k-step ks+3 and the fragment ds_reads of k-step ks+1 are
 //           spread between the 32 MFMAs of k-step ks (the CU's vector-memory path moves 64 B/clk, so a
 //           40 KiB stage occupies it for ~640 of the k-step's 1024 matrix cycles);
@@ -143,8 +145,8 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
         if (p < 4) {
             dma16(w1b + ((size_t)ks * 32768 + p * 8192), tid16, lds0 + sb + wv * 1024 + p * 8192);
         } else {   // rows row0 + brow + (tap-1)*d, chunks kc*4 .. kc*4+3 of the H16 layout (16-byte gather per lane)
-            const unsigned row = (unsigned)(hc.row0 + ((ks >> 3) - 1) * a.dilation) + brow_w;
-            dma16(hc.clip + (ks & 7) * 1024, (row >> 4) * 8192u + (row & 15u) * 16u + bplane,
+            const unsigned row = (unsigned)(hc.row0 + ((ks % 3) - 1) * a.dilation) + brow_w;
+            dma16(hc.clip + (ks / 3) * 1024, (row >> 4) * 8192u + (row & 15u) * 16u + bplane,
                   lds0 + (ks == 0 ? B0_OFF : sb + SLOT_BOFF) + wv * 1024);
         }
     };
@@ -158,8 +160,18 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
         dma16(wsrc, tid16, la);
         dma16(wsrc + 8192, tid16, la + 8192);
     };
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
+    // XCD-aware walk: workgroups are placed round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  XCD x takes
+    // the contiguous tile range [x * chunk, (x+1) * chunk) and its CUs walk it side by side, so the rows a tile reads as
+    // taps -d / +d are the centre rows of tiles the same XCD is processing at the same time: two of the three tap reads
+    // hit that XCD's L2 instead of going to HBM.
+    int tile = blockIdx.x, tile_hi = ntiles, tile_step = gridDim.x;
+    if ((gridDim.x & 7) == 0) {
+        const int chunk = (ntiles + 7) >> 3, lo = (blockIdx.x & 7) * chunk;
+        tile = lo + (blockIdx.x >> 3);
+        tile_hi = lo + chunk < ntiles ? lo + chunk : ntiles;
+        tile_step = gridDim.x >> 3;
+    }
+    if (tile >= tile_hi) return;
     int b, t0;
     tile_rows(tile, b, t0);
     TileSrc hin_c = tile_src(b, t0);
@@ -180,8 +192,8 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
         asm volatile("" : "+v"(tidv));
         const int qv = (tidv & 63) >> 4, r16v = tidv & 15;     // per-tile copies of q / r16 for the post-GEMM1 address math
         // ---------------- GEMM1 ------------------------------------------------------------------
-        const int next = tile + gridDim.x;
-        const bool has_next = next < ntiles;
+        const int next = tile + tile_step;
+        const bool has_next = next < tile_hi;
         int nb = 0, nt0 = 0;
         if (has_next) tile_rows(next, nb, nt0);
         const TileSrc hin_n = tile_src(nb, nt0);

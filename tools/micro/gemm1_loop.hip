@@ -1,0 +1,215 @@
+// Micro-benchmark (development only): the layer kernel's GEMM1 k-loop (8 waves, 128x64 wave tiles, 3-slot
+// LDS ring filled by LDS-DMA, counted vmcnt + one barrier per k-step) with its ingredients switchable, to see
+// which of them costs time beyond the MFMA-bound.  Build: hipcc -O3 --offload-arch=gfx950 gemm1_loop.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int SLOT = 40960, SLOT_BOFF = 32768;
+__device__ __forceinline__ constexpr int slot_base(int i) { return i == 0 ? 81920 : (i == 1 ? 122880 : 0); }
+__device__ __forceinline__ int swz64(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+__device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+#define WAIT_BARRIER_(N)                                                             \
+    do {                                                                            \
+        asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");                       \
+        __builtin_amdgcn_s_waitcnt(0x0070 | ((N) & 15) | (((N) >> 4) << 14));       \
+        __builtin_amdgcn_s_barrier();                                               \
+        asm volatile("" ::: "memory");                                              \
+    } while (0)
+
+// DMA: 0 none, 1 all five pieces.  READS: fragment reads on/off.  BAR: 0 none, 1 wait+barrier per k-step,
+// 2 wait only (no barrier).  ORDER: 0 = DMA pieces first (as shipped), 1 = fragment reads first.
+template <int DMA, int READS, int BAR, int ORDER>
+__global__ void __launch_bounds__(512, 2) k(const char* __restrict__ w, const char* __restrict__ h, float* __restrict__ out, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1, q = lane >> 4, r16 = lane & 15;
+    const unsigned tid16 = tid * 16u;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int frag_off = r16 * 64 + ((q ^ swz64(r16)) * 16);
+    const int bfrag_off = q * 2048 + r16 * 16;
+    for (int i = tid; i < 163840 / 4; i += 512) ((unsigned*)smem)[i] = 0x3f803f80u;
+    __syncthreads();
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[2][8], bf[2][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { af[0][i] = af[1][i] = bf16x8{0x3f80, 0, 0, 0, 0, 0, 0, 0}; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bf[0][i] = bf[1][i] = bf16x8{0x3f80, 0, 0, 0, 0, 0, 0, 0}; }
+    auto piece5 = [&](int tile, int ks, int p) {   // ks: weights stage for p < 4; activation stage for p == 4
+        if (p < 4) dma16(w + ((size_t)(ks % 24) * 32768 + p * 8192), tid16, lds0 + (ks % 3) * 32768 + wv * 1024 + p * 8192);
+        else dma16(h + ((size_t)(blockIdx.x * 64 + ((tile + ks / 24) & 63)) * 24 + (ks % 24)) * 8192, tid16, lds0 + 98304 + (ks & 3) * 8192 + wv * 1024);
+    };
+    const int role = wv >> 2;   // uniform
+    auto rdma = [&](int want_role, const void* sbase, unsigned voff, unsigned lds) {
+        asm volatile("s_cmp_lg_u32 %3, %4\n\ts_cbranch_scc1 Lskip%=\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\nLskip%=:"
+                     ::"v"(voff), "s"(sbase), "s"(lds), "s"(role), "n"(0 + 0), "i"(0) : "memory", "scc");
+    };
+    (void)rdma;
+    auto piece6w = [&](int ks, int j) {   // weight piece j (0..7) of this wave: wave wv (0..3) covers bytes [wv*8K, wv*8K+8K) of the 32 KiB stage
+        const unsigned off = (unsigned)((wv & 3) * 8192 + j * 1024);
+        asm volatile("s_cmp_lg_u32 %3, 0\n\ts_cbranch_scc1 Lskip%=\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\nLskip%=:"
+                     ::"v"((unsigned)(lane * 16)), "s"(w + (size_t)(ks % 24) * 32768 + off), "s"(lds0 + (ks % 3) * 32768 + off), "s"(role) : "memory", "scc");
+    };
+    auto piece6a = [&](int tile, int ks, int j) {   // activation piece j (0..1) of this wave (4..7)
+        const unsigned off = (unsigned)((wv & 3) * 2048 + j * 1024);
+        asm volatile("s_cmp_lg_u32 %3, 1\n\ts_cbranch_scc1 Lskip%=\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\nLskip%=:"
+                     ::"v"((unsigned)(lane * 16)), "s"(h + ((size_t)(blockIdx.x * 64 + ((tile + ks / 24) & 63)) * 24 + (ks % 24)) * 8192 + off),
+                       "s"(lds0 + 98304 + (ks % 7) * 8192 + off), "s"(role) : "memory", "scc");
+    };
+    auto wait6 = [&]() {
+        asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 La%=\n\ts_waitcnt vmcnt(8)\n\ts_branch Lb%=\nLa%=:\n\ts_waitcnt vmcnt(10)\nLb%=:" ::"s"(role) : "memory", "scc");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto piece = [&](int tile, int ks, int p) {
+        const int sb = slot_base(ks % 3);
+        if (p < 4) dma16(w + ((size_t)ks * 32768 + p * 8192), tid16, lds0 + sb + wv * 1024 + p * 8192);
+        else dma16(h + ((size_t)(blockIdx.x * 64 + (tile & 63)) * 24 + ks) * 8192, tid16, lds0 + sb + SLOT_BOFF + wv * 1024);
+    };
+    if (ORDER == 6) { for (int s = 0; s < 3; ++s) for (int j = 0; j < 8; ++j) piece6w(s, j); for (int s = 0; s < 7; ++s) for (int j = 0; j < 2; ++j) piece6a(0, s, j); }
+    else if (ORDER == 5) { for (int s = 0; s < 3; ++s) for (int p = 0; p < 4; ++p) piece5(0, s, p); for (int s = 0; s < 4; ++s) piece5(0, s, 4); }
+    else if (DMA) { for (int s = 0; s < 3; ++s) for (int p = 0; p < DMA; ++p) piece(0, s, p); }
+    for (int tile = 0; tile < tiles; ++tile) {
+        asm volatile("" : "+s"(w), "+s"(h));
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ORDER == 6) { wait6(); }
+            else if (ORDER == 5) { WAIT_BARRIER_(6); }
+            else if (BAR == 1) { if (DMA == 5) { WAIT_BARRIER_(5); } else if (DMA == 4) { WAIT_BARRIER_(4); } else if (DMA == 3) { WAIT_BARRIER_(3); } else if (DMA == 2) { WAIT_BARRIER_(2); } else if (DMA == 1) { WAIT_BARRIER_(1); } else { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); } }
+            else if (BAR == 2) { if (DMA) { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); } __builtin_amdgcn_s_waitcnt(0xC07F); }
+            const char* Ar; Ar = smem + slot_base((ks + 1) % 3) + wm * 8192 + frag_off;
+            const char* Br; Br = smem + slot_base((ks + 1) % 3) + SLOT_BOFF + wn * 1024 + bfrag_off;
+            auto dma_part = [&](int base) {
+#pragma unroll
+                for (int p = 0; p < 5; ++p) {
+                    if (p < DMA) piece(tile + (ks + 3) / 24, (ks + 3) % 24, p);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = base + 4 * p; i < base + 4 * p + 4; ++i)
+                        acc[i >> 2][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][i >> 2], bf[cur][i & 3], acc[i >> 2][i & 3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            auto read_part = [&](int base) {
+#pragma unroll
+                for (int p = 0; p < 12; ++p) {
+                    if (READS) {
+                        if (p < 4) bf[nxt][p] = *(const bf16x8*)(Br + p * 256);
+                        else af[nxt][p - 4] = *(const bf16x8*)(Ar + (p - 4) * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int i = base + p;
+                    acc[i >> 2][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][i >> 2], bf[cur][i & 3], acc[i >> 2][i & 3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            auto even_part = [&]() {   // 32 MFMAs; a DMA piece before MFMAs 0, 6, 12, 19, 25; a fragment read before the others' first 12
+                int rp = 0;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const bool is_dma = (i == 0 || i == 6 || i == 12 || i == 19 || i == 25);
+                    if (is_dma) { const int p = i == 0 ? 0 : i == 6 ? 1 : i == 12 ? 2 : i == 19 ? 3 : 4; if (p < DMA) piece(tile + (ks + 3) / 24, (ks + 3) % 24, p); }
+                    else if (READS && rp < 12) {
+                        if (rp < 4) bf[nxt][rp] = *(const bf16x8*)(Br + rp * 256);
+                        else af[nxt][rp - 4] = *(const bf16x8*)(Ar + (rp - 4) * 1024);
+                        ++rp;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[i >> 2][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][i >> 2], bf[cur][i & 3], acc[i >> 2][i & 3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            auto dma5_part = [&](int base) {
+#pragma unroll
+                for (int p = 0; p < 5; ++p) {
+                    piece5(tile, p < 4 ? ks + 3 : ks + 4, p);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = base + 4 * p; i < base + 4 * p + 4; ++i)
+                        acc[i >> 2][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][i >> 2], bf[cur][i & 3], acc[i >> 2][i & 3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (ORDER == 6) {
+                Ar = smem + ((ks + 1) % 3) * 32768 + wm * 8192 + frag_off;
+                Br = smem + 98304 + ((ks + 1) % 7) * 8192 + wn * 1024 + bfrag_off;
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {     // 10 x (1 role-selected DMA piece, 2 MFMAs)
+                    if (j < 8) piece6w(ks + 3, j); else piece6a(tile, ks + 7, j - 8);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 2 * j; i < 2 * j + 2; ++i)
+                        acc[i >> 2][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][i >> 2], bf[cur][i & 3], acc[i >> 2][i & 3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                read_part(20);
+            } else
+            if (ORDER == 5) {
+                Ar = smem + ((ks + 1) % 3) * 32768 + wm * 8192 + frag_off;
+                Br = smem + 98304 + ((ks + 1) & 3) * 8192 + wn * 1024 + bfrag_off;
+                dma5_part(0); read_part(20);
+            } else
+            if (ORDER == 0) { dma_part(0); read_part(20); }
+            else if (ORDER == 1) { read_part(0); dma_part(12); }
+            else if (ORDER == 2) { even_part(); }
+            else { if (wv < 4) { dma_part(0); read_part(20); } else { read_part(0); dma_part(12); } }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) s += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
+    out[blockIdx.x * 512 + tid] = s;
+}
+
+template <int DMA, int READS, int BAR, int ORDER>
+void run(const char* name, const char* w, const char* h, float* out, double& base) {
+    const int tiles = 62;
+    hipFuncSetAttribute((const void*)k<DMA, READS, BAR, ORDER>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<DMA, READS, BAR, ORDER>), dim3(256), dim3(512), 163840, 0, w, h, out, 4);
+    hipDeviceSynchronize();
+    float best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k<DMA, READS, BAR, ORDER>), dim3(256), dim3(512), 163840, 0, w, h, out, tiles);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double ns = best * 1e6 / (tiles * 24);
+    if (base == 0) base = ns;
+    printf("%-44s %.3f ms  %.1f ns/k-step  x%.3f of mfma-only  (%.0f TFLOP/s GEMM1-equivalent)\n", name, best, ns, ns / base,
+           256.0 * 2 * 512 * 128 * 32 / ns / 1e3);
+}
+
+int main() {
+    char *w, *h; float* out;
+    hipMalloc(&w, 24 * 32768); hipMemset(w, 0, 24 * 32768);
+    const size_t hb = (size_t)256 * 64 * 24 * 8192;     // 3.2 GB of once-read activation slices
+    hipMalloc(&h, hb); hipMemset(h, 0, hb);
+    hipMalloc(&out, 256 * 512 * 4);
+    double base = 0;
+    run<0, 0, 0, 0>("mfma only", w, h, out, base);
+    run<0, 1, 1, 0>("reads + barrier, no dma", w, h, out, base);
+    run<4, 1, 1, 0>("4 weight pieces", w, h, out, base);
+    run<5, 1, 1, 0>("5 pieces (as shipped)", w, h, out, base);
+    run<5, 1, 1, 5>("W x4 then A(k+4), 4-slot activation ring", w, h, out, base);
+    run<5, 1, 1, 6>("role split: 4 weight waves, 4 act waves (k+7)", w, h, out, base);
+    return 0;
+}
