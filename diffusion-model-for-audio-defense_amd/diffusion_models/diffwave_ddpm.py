@@ -4,7 +4,10 @@ engine (libdmad_hip.so).  Same names, argument meaning and error behaviour as th
   create_diffwave_model(model_path, config_path, reverse_timestep=25) -> DiffWave   (ref l.395-411)
   DiffWave.model((audio [B,1,L], steps [B,1])) -> eps [B,1,L]                       (ref l.158,170,178)
   DiffWave.forward / _diffusion / _reverse / compute_coefficients / compute_eps_t /
-  one_shot_denoise / two_shot_denoise / fast_reverse, .diffusion_hyperparams, .reverse_timestep
+  one_shot_denoise / two_shot_denoise / fast_reverse / _predict_x0_from_eps / _predict_x1_from_eps /
+  _predict_x0_from_x1 / _extract_into_tensor, .diffusion_hyperparams, .reverse_timestep     (ref l.16-249)
+  ReffWave(model, diffusion_hyperparams, reverse_timestep, num_re).forward / diffusion /
+  one_shot_denoise                                                                       (ref l.251-349)
 
 Inference only: the eps-network runs in hand-written HIP kernels without autograd.  There is no CPU
 path; inputs must be CUDA tensors (the reference itself hard-codes .cuda()).
@@ -147,10 +150,44 @@ class DiffWave(torch.nn.Module):
         hp = self.diffusion_hyperparams
         Alpha, Alpha_bar, Beta = hp["Alpha"], hp["Alpha_bar"], hp["Beta"]
         eps = self.model((x_t, t * torch.ones((x_t.shape[0], 1))))
+        x_1 = self._predict_x1_from_eps(x_t, t, eps)
+        return self._predict_x0_from_x1(x_1)
+
+    def _predict_x0_from_eps(self, x_t, t, eps):
+        """ref l.195-205"""
+        assert x_t.shape == eps.shape
+        Alpha_bar = self.diffusion_hyperparams["Alpha_bar"]
+        sqrt_recip = (1 / Alpha_bar).sqrt()
+        sqrt_recipm1 = (1 / Alpha_bar - 1).sqrt()
+        return self._extract_into_tensor(sqrt_recip, t, x_t.shape) * x_t - self._extract_into_tensor(sqrt_recipm1, t, x_t.shape) * eps
+
+    def _predict_x1_from_eps(self, x_t, t, eps):
+        """ref l.207-218"""
+        hp = self.diffusion_hyperparams
+        Alpha, Alpha_bar, Beta = hp["Alpha"], hp["Alpha_bar"], hp["Beta"]
         mu = (Alpha_bar[t] / Alpha[0]).sqrt().to(x_t.device)
         sigma = (1 - Alpha_bar[t] - (Alpha_bar[t] / Alpha[0]) * Beta[0] ** 2).sqrt().to(x_t.device)
-        x_1 = (x_t - sigma * eps) / mu
+        return (x_t - sigma * eps) / mu
+
+    def _predict_x0_from_x1(self, x_1):
+        """ref l.220-226"""
         return self.compute_coefficients(x_1, 0)[1]
+
+    @staticmethod
+    def _extract_into_tensor(arr_or_func, timesteps, broadcast_shape, device=None):
+        """ref l.228-249: a table (tensor / ndarray) or a callable, indexed by `timesteps`, broadcast to the shape."""
+        device = device or ('cuda' if torch.cuda.is_available() else 'cpu')
+        if callable(arr_or_func):
+            res = arr_or_func(timesteps).float()
+        elif isinstance(arr_or_func, torch.Tensor):
+            res = arr_or_func.to(device)[timesteps].float()
+        elif isinstance(arr_or_func, np.ndarray):
+            res = torch.from_numpy(arr_or_func).to(device)[timesteps].float()
+        else:
+            raise TypeError('Unsupported data type {} in arr_or_func'.format(type(arr_or_func)))
+        while len(res.shape) < len(broadcast_shape):
+            res = res[..., None]
+        return res.expand(broadcast_shape)
 
     @torch.no_grad()
     def fast_reverse(self, x_t):
@@ -179,6 +216,57 @@ class DiffWave(torch.nn.Module):
             x = mu + beta_tilde_new[t].to(x.device) * z
         self._draws += x.shape[0]
         return x
+
+
+class ReffWave(torch.nn.Module):
+    """ref l.251-349: `num_re` rounds of (diffuse to t*, one-shot denoise); same engine calls as DiffWave."""
+
+    def __init__(self, model, diffusion_hyperparams: dict, reverse_timestep: int = 200, num_re: int = 5,
+                 noise_source: str = 'device', seed: int = 0):
+        super().__init__()
+        self.model = model
+        self.diffusion_hyperparams = diffusion_hyperparams
+        self.reverse_timestep = reverse_timestep
+        self.freeze = False
+        self.num_re = num_re
+        assert noise_source in ('device', 'torch_cpu')
+        self.noise_source = noise_source
+        self.seed = seed
+        self._draws = 0
+
+    @torch.no_grad()
+    def forward(self, waveforms: Union[torch.Tensor, np.ndarray]):
+        output = DiffWave._to_tensor(waveforms)
+        for _ in range(self.num_re):
+            output = self.diffusion(output)
+            output = self.one_shot_denoise(output)
+        return output
+
+    @torch.no_grad()
+    def diffusion(self, x_0) -> torch.Tensor:
+        x_0 = DiffWave._to_tensor(x_0)
+        hp = self.diffusion_hyperparams
+        T, Alpha, Alpha_bar, Sigma = hp["T"], hp["Alpha"], hp["Alpha_bar"], hp["Sigma"]
+        assert len(Alpha) == T
+        assert len(Alpha_bar) == T
+        assert len(Sigma) == T
+        assert x_0.ndim == 3
+        t = self.reverse_timestep - 1
+        z = torch.normal(0, 1, size=tuple(x_0.shape)).to(x_0.device) if self.noise_source == 'torch_cpu' else None
+        out = self.model.engine.diffuse(x_0, float(torch.sqrt(Alpha_bar[t])), float(torch.sqrt(1 - Alpha_bar[t])), z,
+                                        seed=self.seed, sample0=self._draws)
+        self._draws += x_0.shape[0]
+        return out.unsqueeze(1)
+
+    @torch.no_grad()
+    def one_shot_denoise(self, x_t):
+        x_t = DiffWave._to_tensor(x_t)
+        t = self.reverse_timestep - 1
+        Alpha_bar = self.diffusion_hyperparams["Alpha_bar"]
+        return self.model.engine.one_shot(x_t, t, float((1 / Alpha_bar).sqrt()[t]), float((1 / Alpha_bar - 1).sqrt()[t])).unsqueeze(1)
+
+    _predict_x0_from_eps = DiffWave._predict_x0_from_eps
+    _extract_into_tensor = DiffWave._extract_into_tensor
 
 
 def create_diffwave_model(model_path, config_path, reverse_timestep=25, state_dict=None, noise_source='device',

@@ -196,6 +196,52 @@ class DiffWaveOracle:
         x1 = (x_t - sigma * eps) / mu
         return self.compute_coefficients(x1, 0)[1]
 
+    def predict_x0_from_eps(self, x_t, t, eps):
+        """diffwave_ddpm.py:195-205."""
+        ab = self.hp['Alpha_bar']
+        return (1 / ab).sqrt()[t] * x_t - (1 / ab - 1).sqrt()[t] * eps
+
+    def predict_x1_from_eps(self, x_t, t, eps):
+        """diffwave_ddpm.py:207-218."""
+        A, Ab, Be = self.hp['Alpha'], self.hp['Alpha_bar'], self.hp['Beta']
+        mu = (Ab[t] / A[0]).sqrt()
+        sigma = (1 - Ab[t] - (Ab[t] / A[0]) * Be[0] ** 2).sqrt()
+        return (x_t - sigma * eps) / mu
+
+    def predict_x0_from_x1(self, x_1):
+        """diffwave_ddpm.py:220-226."""
+        return self.compute_coefficients(x_1, 0)[1]
+
+    def fast_reverse(self, x_t):
+        """diffwave_ddpm.py:106-141: K = 3 strided steps S = round(linspace(1, t*, 3)) - 1 with the re-derived
+        schedule; a draw at EVERY step (also the last) and beta_tilde itself — not its square root — as the step's
+        sigma (beta_tilde_new[0] = 0, so the last draw is consumed but multiplied by zero)."""
+        ab = self.hp['Alpha_bar']
+        K = 3
+        S = torch.round(torch.linspace(1, self.reverse_timestep, K)).int() - 1
+        beta_new, beta_tilde_new = torch.zeros(K), torch.zeros(K)
+        for i in range(K):
+            if i > 0:
+                beta_new[i] = 1 - ab[S[i]] / ab[S[i - 1]]
+                beta_tilde_new[i] = (1 - ab[S[i - 1]]) / (1 - ab[S[i]]) * beta_new[i]
+            else:
+                beta_new[i] = 1 - ab[S[i]]
+        alpha_new = 1 - beta_new
+        alpha_bar_new = torch.cumprod(alpha_new, dim=0)
+        x = x_t.clone()
+        for t in range(K - 1, -1, -1):
+            eps = self.model(x, int(S[t]))
+            mu = (x - (1 - alpha_new[t]) / torch.sqrt(1 - alpha_bar_new[t]) * eps) / torch.sqrt(alpha_new[t])
+            x = mu + beta_tilde_new[t] * self.noise_fn(x.shape)
+        return x
+
+    def reff_wave(self, x0, num_re=5):
+        """ReffWave.forward, diffwave_ddpm.py:251-325: num_re rounds of (diffuse to t*, one-shot denoise)."""
+        out = x0
+        for _ in range(num_re):
+            out = self.one_shot_denoise(self.diffusion(out))
+        return out
+
 
 # --------------------------------------------------------------------------------------
 # mel front-end (torchaudio 0.11 semantics, SURVEY Appendix C) — PARITY UNPINNED

@@ -197,6 +197,42 @@ def test_two_shot_and_coefficients(engines, golden_dir):
     assert relmax(got, z['one_shot_t66']) < FP32_TOL
 
 
+def test_sampler_variants_and_reffwave_vs_reference_fixture(engines, golden_dir):
+    """DiffWave.fast_reverse / _predict_x1_from_eps / _predict_x0_from_x1 and ReffWave.forward through the host
+    mirror, with the reference's own CPU noise stream (torch.manual_seed + torch.normal, as the generator did)."""
+    from diffusion_models.diffwave_ddpm import DiffWave, ReffWave, WaveNetHIP
+    from diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    z = G(golden_dir, 'samplers2.npz')
+    hp = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    x0 = torch.from_numpy(z['x0']).cuda()
+    for name, tol in (('fp32', 5e-5), ('bf16', BF16_MAX_TOL)):
+        den = DiffWave(WaveNetHIP(engines[name]), hp, reverse_timestep=9, noise_source='torch_cpu')
+        torch.manual_seed(501)
+        x_t = den._diffusion(x0)
+        assert relmax(x_t.cpu().numpy(), z['fast_t9_x_t']) < 1e-6, name
+        got = den.fast_reverse(x_t)
+        assert got.shape == (1, 1, 16000)
+        assert relmax(got.cpu().numpy(), z['fast_t9']) < tol, name
+        eps = den.compute_eps_t(x_t, 8)
+        assert relmax(eps.cpu().numpy(), z['eps_t9']) < tol, name
+        eps_ref = torch.from_numpy(z['eps_t9']).cuda()
+        assert relmax(den._predict_x0_from_eps(x_t, 8, eps_ref).cpu().numpy(), z['x0_from_eps_t9']) < 1e-5, name
+        assert relmax(den._predict_x1_from_eps(x_t, 8, eps_ref).cpu().numpy(), z['x1_t9']) < 1e-5, name
+        got = den._predict_x0_from_x1(torch.from_numpy(z['x1_t9']).cuda())
+        assert relmax(got.cpu().numpy(), z['x0_from_x1_t9']) < tol, name
+
+        rw = ReffWave(WaveNetHIP(engines[name]), hp, reverse_timestep=4, num_re=3, noise_source='torch_cpu')
+        torch.manual_seed(502)
+        got = rw(x0)
+        assert got.shape == (1, 1, 16000)
+        assert relmax(got.cpu().numpy(), z['reff_t4_n3']) < tol, name
+    # device-noise mode: deterministic per (seed, sample counter), finite
+    rw = ReffWave(WaveNetHIP(engines['bf16']), hp, reverse_timestep=4, num_re=2, seed=9)
+    a = rw(x0); rw._draws = 0
+    b = rw(x0)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+
+
 # ------------------------------------------------------------------------------------------ votes
 def _ref_noise(seed, sigma, batches):
     torch.manual_seed(seed)
@@ -348,3 +384,47 @@ def test_reference_driver_surfaces_through_shims(engines, golden_dir, tmp_path, 
     y_certified, r_certified = RC.certify(x=x[:1], y=torch.tensor([3]).cuda(), sigma=0.25, n_0=16, n=32, batch_size=16)
     assert y_certified.tolist() == z['certify_ypred'].tolist()
     assert abs(float(r_certified[0]) - float(z['certify_radius'][0])) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ driver + host ingest (N2)
+def test_certification_driver_end_to_end(engines, tmp_path, monkeypatch):
+    """certified_robustness_eval.run: WAV folder -> SC09Dataset/LoadAudio/FixAudioLength -> DataLoader ->
+    RobustCertificate.certify (fused HIP loop) -> JSON records in the reference's layout; deterministic under
+    torch.manual_seed; --resume continues after the last stored record."""
+    import json
+    import wave
+    import certified_robustness_eval as drv
+    from audio_models.ConvNets_SpeechCommands.models.vgg import vgg19_bn
+    from datasets.sc_dataset import SC09_CLASSES
+    from diffusion_models.diffwave_ddpm import create_diffwave_model
+    eng = engines['bf16']
+    data = tmp_path / 'test'
+    for ci, c in enumerate(SC09_CLASSES):
+        (data / c).mkdir(parents=True)
+        clip = synth.synthetic_clip(ci)[0][: 16000 - 500 * ci]               # ragged lengths: FixAudioLength pads
+        with wave.open(str(data / c / 'a.wav'), 'wb') as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes(np.clip(np.round(clip * 32768.0), -32768, 32767).astype('<i2').tobytes())
+    cfg = str(tmp_path / 'config.json')
+    json.dump({'wavenet_config': synth.WAVENET_CONFIG, 'diffusion_config': synth.DIFFUSION_CONFIG}, open(cfg, 'w'))
+    den = create_diffwave_model(None, cfg, state_dict=synth.wavenet_state_dict(1234), engine=eng)
+    net = vgg19_bn(num_classes=10, in_channels=1)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.vgg19_bn_state_dict(4321).items()})
+    net.eval()
+    args = drv.build_parser().parse_args(['--data_path', str(data), '--num_per_class', '1', '--config', cfg, '--sigma', '0.5',
+                                          '--num_sampling', '28', '--batch_size', '4', '--dataload_workers_nums', '0',
+                                          '--save_path', str(tmp_path / 'records')])
+    torch.manual_seed(3)
+    recs = drv.run(args, classifier=net, denoiser=den, log=lambda *_: None)
+    path = tmp_path / 'records' / 'sigma=0.5' / 'sigma=0.5_N=28.json'
+    assert json.load(open(path)) == recs and len(recs) == 10
+    assert [r['id'] for r in recs] == list(range(10)) and [r['y_true'] for r in recs] == list(range(10))
+    assert all(r['y_pred'] in range(-1, 10) and r['certified_radius'] >= 0 for r in recs)
+    assert all((r['y_pred'] == -1) == (r['certified_radius'] == 0) for r in recs)
+    torch.manual_seed(3)
+    assert drv.run(args, classifier=net, denoiser=den, log=lambda *_: None) == recs
+    json.dump(recs[:6], open(path, 'w'))                                     # an interrupted run: 6 of 10 stored
+    args.resume = True
+    again = drv.run(args, classifier=net, denoiser=den, log=lambda *_: None)
+    assert len(again) == 10 and again[:6] == recs[:6] and [r['id'] for r in again] == list(range(10))
+    assert [r['y_true'] for r in again] == list(range(10))

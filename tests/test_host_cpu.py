@@ -221,3 +221,79 @@ def test_wavenet_surface_rejects_unsupported_use():
         m((x, torch.tensor([[1.0], [2.0], [1.0]])))       # per-row steps
     with pytest.raises(NotImplementedError):
         m((x.requires_grad_(), 5 * torch.ones(3, 1)))     # autograd
+
+
+# ------------------------------------------------------------------------------------------ host ingest
+def _write_wav(path, samples_i16, rate=16000, channels=1):
+    import wave
+    with wave.open(path, 'wb') as w:
+        w.setnchannels(channels); w.setsampwidth(2); w.setframerate(rate)
+        w.writeframes(np.asarray(samples_i16, dtype='<i2').tobytes())
+
+
+def test_wav_loader_and_fix_length(tmp_path):
+    """LoadAudio = PCM16 / 32768 as float32 (what librosa.load returns for a 16 kHz mono file), channel mean for
+    stereo, a loud failure on another sample rate; FixAudioLength pads with zeros / truncates to time * rate."""
+    from transforms import LoadAudio, FixAudioLength
+    rng = np.random.default_rng(0)
+    pcm = rng.integers(-32768, 32767, size=12000, dtype=np.int16)
+    _write_wav(str(tmp_path / 'a.wav'), pcm)
+    d = LoadAudio()({'path': str(tmp_path / 'a.wav'), 'target': 3})
+    assert d['sample_rate'] == 16000 and d['samples'].dtype == np.float32 and d['target'] == 3
+    assert np.array_equal(d['samples'], pcm.astype(np.float32) / 32768.0)
+    d = FixAudioLength()(d)
+    assert d['samples'].shape == (16000,) and np.all(d['samples'][12000:] == 0)
+    assert np.array_equal(d['samples'][:12000], pcm.astype(np.float32) / 32768.0)
+    long = rng.integers(-1000, 1000, size=20000, dtype=np.int16)
+    _write_wav(str(tmp_path / 'b.wav'), long)
+    d = FixAudioLength()(LoadAudio()({'path': str(tmp_path / 'b.wav')}))
+    assert np.array_equal(d['samples'], long[:16000].astype(np.float32) / 32768.0)
+    st = rng.integers(-1000, 1000, size=(500, 2), dtype=np.int16)
+    _write_wav(str(tmp_path / 'c.wav'), st.reshape(-1), channels=2)
+    d = LoadAudio()({'path': str(tmp_path / 'c.wav')})
+    np.testing.assert_allclose(d['samples'], (st.astype(np.float32) / 32768.0).mean(1), rtol=0, atol=1e-7)
+    d = LoadAudio()({'path': ''})                                   # the reference's "silence" item
+    assert d['samples'].shape == (16000,) and not d['samples'].any()
+    _write_wav(str(tmp_path / 'd.wav'), pcm, rate=8000)
+    with pytest.raises(ValueError):
+        LoadAudio()({'path': str(tmp_path / 'd.wav')})
+
+
+def test_sc09_dataset_index(tmp_path):
+    from datasets.sc_dataset import SC09Dataset, SC09_CLASSES
+    from transforms import LoadAudio, FixAudioLength
+    for ci, c in enumerate(SC09_CLASSES):
+        os.makedirs(tmp_path / c)
+        for k in range(3):
+            _write_wav(str(tmp_path / c / ('%s_%d.wav' % (c, k))), np.full(100 * (k + 1), ci * 100 + k, dtype=np.int16))
+    os.makedirs(tmp_path / '_background_noise_')
+    ds = SC09Dataset(str(tmp_path), transform=lambda d: FixAudioLength()(LoadAudio()(d)), num_per_class=2)
+    assert len(ds) == 20
+    assert [t for _, t in ds.data] == sorted([t for _, t in ds.data])          # class-major order, targets 0..9
+    item = ds[5]
+    assert item['target'] == 2 and item['samples'].shape == (16000,)
+    assert os.path.basename(os.path.dirname(item['path'])) == 'two'
+    assert len(SC09Dataset(str(tmp_path), num_per_class=100)) == 30           # fewer files than num_per_class
+    w = ds.make_weights_for_balanced_classes()
+    assert w.shape == (20,) and np.allclose(w, 10.0)
+    with pytest.raises(AssertionError):                                        # a missing class folder
+        os.rename(tmp_path / 'three', tmp_path / 'x3')
+        SC09Dataset(str(tmp_path))
+
+
+def test_certification_records_format_and_resume(tmp_path):
+    import json
+    from robustness_eval.records import CertificationRecords
+    r = CertificationRecords(str(tmp_path), 0.5, 1000)
+    r.append_batch([1, 2], [1, -1], [0.25, 0.0])
+    r.flush()
+    path = tmp_path / 'sigma=0.5' / 'sigma=0.5_N=1000.json'
+    got = json.load(open(path))
+    assert got == [{'id': 0, 'y_true': 1, 'y_pred': 1, 'certified_radius': 0.25},
+                   {'id': 1, 'y_true': 2, 'y_pred': -1, 'certified_radius': 0.0}]
+    assert open(path).read().startswith('[\n    {\n        "id": 0,')        # indent=4, the reference's layout
+    r2 = CertificationRecords(str(tmp_path), 0.5, 1000, resume=True)
+    assert len(r2) == 2
+    r2.append_batch([7], [7], [1.5]); r2.flush()
+    assert [d['id'] for d in json.load(open(path))] == [0, 1, 2]
+    assert len(CertificationRecords(str(tmp_path), 0.5, 1000)) == 0           # no resume: starts over

@@ -89,6 +89,36 @@ def test_samplers(golden_dir):
     assert np.abs(got - z['ddpm_t%d' % tstar]).max() <= 3e-5 * np.abs(z['ddpm_t%d' % tstar]).max()
 
 
+def test_sampler_variants_and_reffwave(golden_dir):
+    """fast_reverse, the x1 predictors and ReffWave against outputs of the imported reference
+    (tests/golden/make_golden_samplers2.py), with the CPU noise draws the reference consumed."""
+    z = _load(golden_dir, 'samplers2.npz')
+    w = orc.folded_weights(synth.wavenet_state_dict(1234))
+    hp = orc.calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    x0 = torch.from_numpy(z['x0'])
+
+    def close(got, name, tol=3e-5):
+        assert np.abs(got.numpy() - z[name]).max() <= tol * np.abs(z[name]).max(), name
+
+    zs = list(torch.from_numpy(z['fast_t9_noise']))
+    den = orc.DiffWaveOracle(w, hp, reverse_timestep=9, noise_fn=lambda shape: zs.pop(0))
+    x_t = den.diffusion(x0)
+    close(x_t, 'fast_t9_x_t', 1e-6)
+    close(den.fast_reverse(x_t), 'fast_t9')
+    assert not zs
+    eps = den.model(x_t, 8)
+    close(eps, 'eps_t9')
+    close(den.predict_x0_from_eps(x_t, 8, eps), 'x0_from_eps_t9')
+    x1 = den.predict_x1_from_eps(x_t, 8, eps)
+    close(x1, 'x1_t9')
+    close(den.predict_x0_from_x1(torch.from_numpy(z['x1_t9'])), 'x0_from_x1_t9')
+
+    zs = list(torch.from_numpy(z['reff_t4_n3_noise']))
+    den = orc.DiffWaveOracle(w, hp, reverse_timestep=4, noise_fn=lambda shape: zs.pop(0))
+    close(den.reff_wave(x0, num_re=3), 'reff_t4_n3')
+    assert not zs
+
+
 def test_classifiers(golden_dir):
     z = _load(golden_dir, 'classifiers.npz')
     m5 = dict(_load(golden_dir, 'm5_k160_state.npz'))
