@@ -428,3 +428,64 @@ def test_certification_driver_end_to_end(engines, tmp_path, monkeypatch):
     again = drv.run(args, classifier=net, denoiser=den, log=lambda *_: None)
     assert len(again) == 10 and again[:6] == recs[:6] and [r['id'] for r in again] == list(range(10))
     assert [r['y_true'] for r in again] == list(range(10))
+
+
+# ------------------------------------------------------------------------------------------ batched query path (N3)
+def test_eot_nes_query_path(engines, orc):
+    """AcousticSystem(defender = t*-step DDPM purifier) queried through the EOT / NES wrappers of the black-box drivers
+    (reference _EOT.py:19-69, _NES.py:15-55): repeated batches through the HIP path, checked against the oracle's
+    purify -> mel-dB -> VGG chain driven by the same CPU noise stream."""
+    from acoustic_system import AcousticSystem
+    from audio_models.ConvNets_SpeechCommands.models.vgg import vgg19_bn
+    from diffusion_models.diffwave_ddpm import DiffWave, WaveNetHIP
+    from diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    from dmad_hip.transforms import MelSpectrogramDB
+    from robustness_eval._EOT import EOT
+    from robustness_eval._NES import NES
+    from robustness_eval._utils import resolve_loss, resolve_prediction
+    eng = engines['fp32']
+    hp = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    den = DiffWave(WaveNetHIP(eng), hp, reverse_timestep=2, noise_source='torch_cpu')
+    net = vgg19_bn(num_classes=10, in_channels=1)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.vgg19_bn_state_dict(4321).items()})
+    net.eval().bind_engine(eng)
+    model = AcousticSystem(classifier=net, transform=MelSpectrogramDB(eng), defender=den, defense_type='wave')
+    loss_fn, grad_sign = resolve_loss('Margin', False, 0., 'SCR', None, False)
+    assert grad_sign == 1
+    x = torch.from_numpy(np.stack([synth.synthetic_clip(0), synth.synthetic_clip(5)])).cuda()
+    y = torch.tensor([0, 6]).cuda()
+
+    # one EOT batch of two repeats == the oracle chain on the repeated batch with the same CPU draws
+    eot = EOT(model, loss_fn, EOT_size=2, EOT_batch_size=2, use_grad=False)
+    torch.manual_seed(77)
+    scores, loss, grad, decisions = eot(x, y)
+    assert grad is None and scores.shape == (2, 10) and loss.shape == (2,) and [len(d) for d in decisions] == [2, 2]
+    torch.manual_seed(77)
+    w = orc.folded_weights(synth.wavenet_state_dict(1234))
+    oden = orc.DiffWaveOracle(w, orc.calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG), reverse_timestep=2)
+    pur = oden.forward(x.cpu().repeat(2, 1, 1))
+    ref_logits = orc.vgg19_bn_forward(synth.vgg19_bn_state_dict(4321), orc.mel_db(pur))
+    ref_scores = ref_logits.view(2, 2, 10).mean(0)
+    assert float((scores.cpu() - ref_scores).abs().max()) < 2e-3 * float(ref_scores.abs().max())
+    ref_loss = torch.nn.functional.cross_entropy(ref_logits, y.cpu().repeat(2), reduction='none').view(2, 2).mean(0)
+    assert float((loss.cpu() - ref_loss).abs().max()) < 2e-3 * max(1.0, float(ref_loss.abs().max()))
+    assert [list(map(int, d)) for d in decisions] == ref_logits.argmax(1).view(2, 2).t().tolist()
+    assert resolve_prediction(decisions).shape == (2,)
+
+    # several EOT batches accumulate the per-batch means (ref l.46-55)
+    eot4 = EOT(model, loss_fn, EOT_size=4, EOT_batch_size=2, use_grad=False)
+    torch.manual_seed(5)
+    s4, l4, _, d4 = eot4(x, y)
+    torch.manual_seed(5)
+    parts = [model(x.repeat(2, 1, 1)) for _ in range(2)]
+    want = sum(p.view(2, 2, 10).mean(0) for p in parts) / 2
+    assert torch.allclose(s4, want, rtol=0, atol=1e-6) and [len(d) for d in d4] == [4, 4]
+    with pytest.raises(NotImplementedError):
+        EOT(model, loss_fn, 2, 2, use_grad=True)(x, y)
+
+    # NES: shapes, finiteness, the unperturbed probe first (ref l.20-21,41-47)
+    nes = NES(samples_per_draw=4, samples_per_draw_batch=4, sigma=1e-3, EOT_wrapper=EOT(model, loss_fn, 1, 1, False))
+    torch.manual_seed(9)
+    mean_loss, g, adver_loss, adver_score, predict = nes(x, y)
+    assert mean_loss.shape == (2,) and g.shape == x.shape and adver_loss.shape == (2,) and adver_score.shape == (2, 10)
+    assert predict.shape == (2,) and bool(torch.isfinite(g).all()) and bool(torch.isfinite(mean_loss).all())
