@@ -100,6 +100,14 @@ struct dmad_engine {
     float* vfcb[3] = {nullptr};
     float *act0 = nullptr, *act1 = nullptr, *logits = nullptr, *slab = nullptr;
     long slab_floats = 0;
+    // ResNeXt29 8x64d (models/resnext.py): 9 bottlenecks, every conv with its folded eval-BatchNorm scale/shift
+    int cls_kind = 0;                      // 0 = VGG19_bn, 1 = ResNeXt29
+    struct RxConv { float *w = nullptr, *scale = nullptr, *shift = nullptr; };
+    struct RxBlock { RxConv reduce, conv, expand, shortc; bool has_short = false; int cin = 0, cout = 0, D = 0, stride = 1; };
+    RxBlock rx[9];
+    RxConv rxconv1;
+    float *rxfcw = nullptr, *rxfcb = nullptr;
+    float *rxX = nullptr, *rxY = nullptr, *rxT1 = nullptr, *rxT2 = nullptr, *rxS = nullptr;   // NHWC work buffers
 
     template <typename T>
     int alloc(T** p, size_t n, bool zero = false) {
@@ -324,6 +332,106 @@ int finalize_classifier(dmad_engine* e) {
     return 0;
 }
 
+GemmF32Args plain_gemm(const float* A, const float* X, float* C, const float* scale, const float* shift, int M, int K, long N,
+                       int ldc, long ldx, int relu);
+
+// ResNeXt29 8x64d: names rx.conv1.*, rx.b<i>.{reduce,conv,expand,short}.{w,scale,shift} (i = 3 * stage + bottleneck),
+// rx.fc.{w,b}.  GEMM images: 1x1 convs [M][K]; the grouped 3x3 conv per group [tap][M/8][K/8] (models/resnext.py:23-62).
+int finalize_resnext(dmad_engine* e) {
+    const HostW* w;
+    auto up3 = [&](const std::string& base, dmad_engine::RxConv& c, const std::vector<float>& A, int M) -> int {
+        CHK(e->upload(&c.w, A));
+        w = e->get(base + ".scale", {M}); if (!w) return DMAD_ERR_STATE;
+        CHK(e->upload(&c.scale, w->v));
+        w = e->get(base + ".shift", {M}); if (!w) return DMAD_ERR_STATE;
+        CHK(e->upload(&c.shift, w->v));
+        return 0;
+    };
+    w = e->get("rx.conv1.w", {64, 1, 3, 3}); if (!w) return DMAD_ERR_STATE;
+    CHK(up3("rx.conv1", e->rxconv1, w->v, 64));
+    const int stages[4] = {64, 256, 512, 1024};
+    for (int i = 0; i < 9; ++i) {
+        dmad_engine::RxBlock& b = e->rx[i];
+        const int st = i / 3, k = i % 3;
+        b.cin = k == 0 ? stages[st] : stages[st + 1];
+        b.cout = stages[st + 1];
+        b.D = 8 * (64 * b.cout / 256);
+        b.stride = (k == 0 && st > 0) ? 2 : 1;
+        b.has_short = b.cin != b.cout;
+        const std::string base = "rx.b" + std::to_string(i);
+        w = e->get(base + ".reduce.w", {b.D, b.cin}); if (!w) return DMAD_ERR_STATE;
+        CHK(up3(base + ".reduce", b.reduce, w->v, b.D));
+        const int G = b.D / 8;
+        w = e->get(base + ".conv.w", {b.D, G, 3, 3}); if (!w) return DMAD_ERR_STATE;
+        std::vector<float> A((size_t)8 * 9 * G * G);
+        for (int g = 0; g < 8; ++g)
+            for (int m = 0; m < G; ++m)
+                for (int kk = 0; kk < G; ++kk)
+                    for (int t = 0; t < 9; ++t)
+                        A[(((size_t)g * 9 + t) * G + m) * G + kk] = w->v[(((size_t)g * G + m) * G + kk) * 9 + t];
+        CHK(up3(base + ".conv", b.conv, A, b.D));
+        w = e->get(base + ".expand.w", {b.cout, b.D}); if (!w) return DMAD_ERR_STATE;
+        CHK(up3(base + ".expand", b.expand, w->v, b.cout));
+        if (b.has_short) {
+            w = e->get(base + ".short.w", {b.cout, b.cin}); if (!w) return DMAD_ERR_STATE;
+            CHK(up3(base + ".short", b.shortc, w->v, b.cout));
+        }
+    }
+    w = e->get("rx.fc.w", {e->cfg.num_classes, 1024}); if (!w) return DMAD_ERR_STATE;
+    CHK(e->upload(&e->rxfcw, w->v));
+    w = e->get("rx.fc.b", {e->cfg.num_classes}); if (!w) return DMAD_ERR_STATE;
+    CHK(e->upload(&e->rxfcb, w->v));
+    const size_t B = (size_t)e->maxB;
+    CHK(e->alloc(&e->rxX, B * 1024 * 256));
+    CHK(e->alloc(&e->rxY, B * 1024 * 256));
+    CHK(e->alloc(&e->rxS, B * 1024 * 256));
+    CHK(e->alloc(&e->rxT1, B * 1024 * 1024));     // stage 2's first reduce: 32x32 pixels x D = 1024
+    CHK(e->alloc(&e->rxT2, B * 1024 * 512));
+    return 0;
+}
+
+// CifarResNeXt.forward (models/resnext.py:133-142) on NHWC fp32 maps
+int classify_resnext(dmad_engine* e, const float* spec, int B, float* logits, hipStream_t s) {
+    float *X = e->rxX, *Y = e->rxY;
+    launch_vgg_conv1(spec, e->rxconv1.w, e->rxconv1.scale, e->rxconv1.shift, X, B, s);      // 1 -> 64, 3x3, BN, ReLU
+    int H = 32;
+    for (int i = 0; i < 9; ++i) {
+        const dmad_engine::RxBlock& b = e->rx[i];
+        const int Ho = (H - 1) / b.stride + 1;
+        const long Nin = (long)B * H * H, Nout = (long)B * Ho * Ho, nref_in = (long)e->maxB * H * H, nref_out = (long)e->maxB * Ho * Ho;
+        // conv_reduce + bn_reduce + ReLU (1x1)
+        GemmF32Args g = plain_gemm(b.reduce.w, X, e->rxT1, b.reduce.scale, b.reduce.shift, b.D, b.cin, Nin, b.D, b.cin, 1);
+        launch_gemm_f32(g, s, e->slab, e->slab_floats, nref_in);
+        // conv_conv (3x3, 8 groups, stride) + bn + ReLU
+        GemmF32Args c{};
+        c.A = b.conv.w; c.X = e->rxT1; c.C = e->rxT2; c.scale = b.conv.scale; c.shift = b.conv.shift;
+        c.M = b.D / 8; c.K = b.D / 8; c.taps = 9; c.ldc = b.D; c.relu = 1; c.N = Nout; c.mode = 2;
+        c.H = H; c.W = H; c.Cin = b.D / 8; c.ldx = b.D; c.stride = b.stride; c.groups = 8;
+        launch_gemm_f32(c, s);
+        // shortcut: identity, or 1x1 conv (stride) + BN
+        const float* res = X;
+        if (b.has_short) {
+            GemmF32Args h{};
+            h.A = b.shortc.w; h.X = X; h.C = e->rxS; h.scale = b.shortc.scale; h.shift = b.shortc.shift;
+            h.M = b.cout; h.K = b.cin; h.taps = 1; h.ldc = b.cout; h.relu = 0; h.N = Nout; h.mode = 2;
+            h.H = H; h.W = H; h.Cin = b.cin; h.ldx = b.cin; h.stride = b.stride;
+            launch_gemm_f32(h, s, e->slab, e->slab_floats, nref_out);
+            res = e->rxS;
+        }
+        // conv_expand + bn_expand, + shortcut, ReLU
+        GemmF32Args x = plain_gemm(b.expand.w, e->rxT2, Y, b.expand.scale, b.expand.shift, b.cout, b.D, Nout, b.cout, b.D, 1);
+        x.res = res;
+        launch_gemm_f32(x, s, e->slab, e->slab_floats, nref_out);
+        float* t = X; X = Y; Y = t;
+        H = Ho;
+    }
+    launch_avgpool_nhwc(X, e->rxT2, B, H * H, 1024, s);
+    launch_gemm_f32(plain_gemm(e->rxfcw, e->rxT2, logits, nullptr, e->rxfcb, e->cfg.num_classes, 1024, B, e->cfg.num_classes, 1024, 0), s,
+                    e->slab, e->slab_floats, (long)e->maxB);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int ensure_embed(dmad_engine* e, int t, hipStream_t s) {
     if (e->emb_t == t) return 0;
     launch_embed_table((float)t, e->fc1w, e->fc1b, e->fc2w, e->fc2b, e->fctw, e->fctb, e->emb_table, e->emb2, e->bf16 ? e->b2 : nullptr,
@@ -416,6 +524,7 @@ int classify(dmad_engine* e, const float* spec, int B, float* logits, hipStream_
     if (!e->cfg.with_classifier) return fail(DMAD_ERR_STATE, "engine was created with with_classifier = 0");
     if (!e->cls_final) return fail(DMAD_ERR_STATE, "classifier weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
     if (B < 1 || B > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d]", B, e->maxB);
+    if (e->cls_kind == 1) return classify_resnext(e, spec, B, logits, s);
     float *cur = e->act0, *nxt = e->act1;
     launch_vgg_conv1(spec, e->vconv1w, e->vscale[0], e->vshift[0], cur, B, s);
     int H = 32, cin = 64, li = 1;
@@ -577,7 +686,10 @@ int dmad_finalize_weights(dmad_engine* e) {
     }
     if (e->cfg.with_classifier && !e->cls_final && e->hw.count("vgg.conv0.w")) {
         CHK(finalize_classifier(e));
-        e->cls_final = true; did = true;
+        e->cls_final = true; e->cls_kind = 0; did = true;
+    } else if (e->cfg.with_classifier && !e->cls_final && e->hw.count("rx.conv1.w")) {
+        CHK(finalize_resnext(e));
+        e->cls_final = true; e->cls_kind = 1; did = true;
     }
     if (!did) return fail(DMAD_ERR_STATE, "nothing to finalise: no complete weight set was loaded");
     e->hw.clear();

@@ -25,6 +25,7 @@ void launch_mel_db(const float* M, float* spec, int B, int to_db, hipStream_t s)
 void launch_power_to_db(const float* x, float* y, long n, hipStream_t s);
 void launch_vgg_conv1(const float* in, const float* w, const float* scale, const float* shift, float* out, int B, hipStream_t s);
 void launch_maxpool2_nhwc(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
+void launch_avgpool_nhwc(const float* in, float* out, int B, int HW, int C, hipStream_t s);
 void launch_vote(const float* logits, int B, int C, unsigned long long* counts, int* pred_out, hipStream_t s);
 void philox4x32_10_host(uint32_t c[4], uint32_t k0, uint32_t k1);
 

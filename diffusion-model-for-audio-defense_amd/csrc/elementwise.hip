@@ -312,6 +312,19 @@ __global__ void maxpool2_nhwc_kernel(const float* __restrict__ in, float* __rest
     ((float4*)out)[i] = o;
 }
 
+// global average pool over the HW pixels of an NHWC map (F.avg_pool2d(x, 8, 1) on the 8x8 map of ResNeXt29,
+// models/resnext.py:139): pixels summed in index order, then one division
+__global__ void avgpool_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int HW, int C, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one output element [b][c]
+    if (i >= total) return;
+    const long b = i / C;
+    const int c = (int)(i - b * C);
+    const float* s = in + b * HW * (long)C + c;
+    float acc = 0.f;
+    for (int p = 0; p < HW; ++p) acc += s[(long)p * C];
+    out[i] = acc / (float)HW;
+}
+
 // ----------------------------------------------------------------------------------------------
 // votes: arg-max (first maximum wins, like torch.max) + per-class count (certified_robust.py:59-65)
 // ----------------------------------------------------------------------------------------------
@@ -398,6 +411,10 @@ void launch_vgg_conv1(const float* in, const float* w, const float* scale, const
 void launch_maxpool2_nhwc(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
     const long total4 = (long)B * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(maxpool2_nhwc_kernel, dim3(nblk(total4, 256)), dim3(256), 0, s, in, out, H, W, C, total4);
+}
+void launch_avgpool_nhwc(const float* in, float* out, int B, int HW, int C, hipStream_t s) {
+    const long total = (long)B * C;
+    hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, in, out, HW, C, total);
 }
 void launch_vote(const float* logits, int B, int C, unsigned long long* counts, int* pred_out, hipStream_t s) {
     hipLaunchKernelGGL(vote_kernel, dim3(nblk(B, 64)), dim3(64), 0, s, logits, B, C, counts, pred_out);

@@ -13,9 +13,14 @@ struct GemmF32Args {
     int M, K, taps, ldc, relu;
     long N;
     int mode;             // 0: row(n,tap) = (n / R) * batch_stride + (n % R) * row_stride + (tap - taps/2) * tap_stride
-                          // 2: 3x3 conv over NHWC [B][H][W][Cin] with zero padding (taps == 9, K == Cin)
+                          // 2: 3x3 (taps == 9, zero padding 1) or 1x1 (taps == 1) conv over NHWC [B][H][W][ldx]
     long rows_per_batch, batch_stride, row_stride, tap_stride;   // floats (mode 0)
-    int H, W, Cin;        // mode 2
+    int H, W, Cin;        // mode 2: input height / width, K == Cin (channels of this group)
+    int ldx;              // mode 2: floats between two pixels of X (0 = Cin; larger when X holds several groups)
+    int stride;           // mode 2: spatial stride (0/1 = 1, 2 = output (H-1)/2+1 x (W-1)/2+1); taps == 1 is a 1x1 conv
+    int groups;           // > 1: grouped conv, one group per grid.z; M, K and the A image are per group, X / C / scale /
+                          //      shift / res advance by K resp. M per group (ldx / ldc = all groups); excludes split-K
+    const float* res;     // optional residual [N][ldc] added before the ReLU (ResNeXt bottleneck sum)
     int splits;           // > 1: split-K over grid.z; partial sums go to `slab` [splits][N][ldc] (fixed-order reduce)
     float* slab;
 };

@@ -22,12 +22,13 @@ __device__ __forceinline__ const float* row_ptr(const GemmF32Args& a, long n, in
     // returns nullptr for a zero row
     if (n >= a.N) return nullptr;
     if (a.mode == 2) {
-        const int hw = a.H * a.W;
+        const int st = a.stride > 1 ? a.stride : 1;
+        const int Ho = (a.H - 1) / st + 1, Wo = (a.W - 1) / st + 1, hw = Ho * Wo;
         const long b = n / hw;
-        const int p = (int)(n - b * hw), y = p / a.W, x = p - y * a.W;
-        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        const int p = (int)(n - b * hw), y = p / Wo, x = p - y * Wo;
+        const int yy = y * st + (a.taps == 9 ? tap / 3 - 1 : 0), xx = x * st + (a.taps == 9 ? tap % 3 - 1 : 0);
         if ((unsigned)yy >= (unsigned)a.H || (unsigned)xx >= (unsigned)a.W) return nullptr;
-        return a.X + ((b * a.H + yy) * a.W + xx) * (long)a.Cin + kc;
+        return a.X + ((b * a.H + yy) * a.W + xx) * (long)(a.ldx ? a.ldx : a.Cin) + kc;
     }
     const long b = n / a.rows_per_batch, r = n - b * a.rows_per_batch;
     return a.X + b * a.batch_stride + r * a.row_stride + (long)(tap - (a.taps >> 1)) * a.tap_stride + kc;
@@ -37,12 +38,21 @@ __device__ __forceinline__ const float* row_ptr(const GemmF32Args& a, long n, in
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
     __shared__ float As[2][BK][PITCH];
     __shared__ float Bs[2][BK][PITCH];
+    if (a.groups > 1) {                      // grouped conv: this workgroup's group = blockIdx.z
+        const int g = blockIdx.z;
+        a.A += (size_t)g * a.taps * a.M * a.K;
+        a.X += (size_t)g * a.K;
+        a.C += (size_t)g * a.M;
+        if (a.scale) a.scale += (size_t)g * a.M;
+        if (a.shift) a.shift += (size_t)g * a.M;
+        if (a.res) a.res += (size_t)g * a.M;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1, q = lane >> 4, r16 = lane & 15;
     const long n0 = (long)blockIdx.x * BN;
     const int m0 = blockIdx.y * BM;
     const int ksteps_per_tap = a.K / BK, nks_all = a.taps * ksteps_per_tap;
-    const int S = a.splits > 1 ? a.splits : 1, z = blockIdx.z;
+    const int S = a.splits > 1 ? a.splits : 1, z = a.groups > 1 ? 0 : blockIdx.z;
     const int ks_begin = (int)((long)nks_all * z / S), nks = (int)((long)nks_all * (z + 1) / S);
 
     f32x4 acc[4][4];
@@ -132,6 +142,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float t = a.scale ? acc[i][j][r] * sc[r] + sh[r] : acc[i][j][r] + sh[r];
+                if (a.res && m + r < a.M) t += a.res[n * a.ldc + m + r];
                 v[r] = a.relu ? fmaxf(t, 0.f) : t;
             }
             float* dst = a.C + n * a.ldc + m;
@@ -155,6 +166,7 @@ __global__ void gemm_f32_reduce_kernel(GemmF32Args a) {
     float s = 0.f;
     for (int z = 0; z < a.splits; ++z) s += a.slab[((long)z * a.N + n) * a.ldc + m];
     float t = a.scale ? s * a.scale[m] + (a.shift ? a.shift[m] : 0.f) : s + (a.shift ? a.shift[m] : 0.f);
+    if (a.res) t += a.res[n * a.ldc + m];
     a.C[n * a.ldc + m] = a.relu ? fmaxf(t, 0.f) : t;
 }
 
@@ -163,6 +175,12 @@ void launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long sla
     const unsigned gx = (unsigned)((a.N + BN - 1) / BN), gy = (unsigned)((a.M + BM - 1) / BM);
     const int nks = a.taps * (a.K / BK);
     int S = 1;
+    if (a.groups > 1) {
+        a.splits = 1;
+        a.slab = nullptr;
+        hipLaunchKernelGGL(gemm_f32_kernel, dim3(gx, gy, (unsigned)a.groups), dim3(256), 0, s, a);
+        return;
+    }
     if (slab) {
         // The split count is derived from the REFERENCE row count n_ref (the engine's max batch), not from the
         // rows of this launch, so that a sample's result does not depend on the batch it was computed in.

@@ -83,6 +83,36 @@ def fold_vgg19_bn_state_dict(sd: Dict[str, object], eps: float = 1e-5) -> Dict[s
     return {k: _as_np(v) for k, v in out.items()}
 
 
+def fold_resnext29_state_dict(sd: Dict[str, object], eps: float = 1e-5) -> Dict[str, np.ndarray]:
+    """models/resnext.py CifarResNeXt (8x64d, depth 29) state dict -> conv weights + eval-mode BatchNorm folded to
+    scale/shift per conv (float64 on the host, rounded once); bottleneck i = 3 * (stage - 1) + k."""
+    def A(k):
+        v = sd[k]
+        return (v.detach().cpu().double().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, dtype=np.float64))
+
+    def bn(prefix):
+        scale = A(prefix + '.weight') / np.sqrt(A(prefix + '.running_var') + eps)
+        return scale, A(prefix + '.bias') - A(prefix + '.running_mean') * scale
+
+    out = {'rx.conv1.w': A('conv_1_3x3.weight')}
+    out['rx.conv1.scale'], out['rx.conv1.shift'] = bn('bn_1')
+    for st in (1, 2, 3):
+        for k in range(3):
+            src = 'stage_%d.stage_%d_bottleneck_%d.' % (st, st, k)
+            dst = 'rx.b%d.' % (3 * (st - 1) + k)
+            for conv, norm, name in (('conv_reduce', 'bn_reduce', 'reduce'), ('conv_conv', 'bn', 'conv'), ('conv_expand', 'bn_expand', 'expand')):
+                w = A(src + conv + '.weight')
+                out[dst + name + '.w'] = w.reshape(w.shape[0], w.shape[1]) if name != 'conv' else w
+                out[dst + name + '.scale'], out[dst + name + '.shift'] = bn(src + norm)
+            if src + 'shortcut.shortcut_conv.weight' in sd:
+                w = A(src + 'shortcut.shortcut_conv.weight')
+                out[dst + 'short.w'] = w.reshape(w.shape[0], w.shape[1])
+                out[dst + 'short.scale'], out[dst + 'short.shift'] = bn(src + 'shortcut.shortcut_bn')
+    out['rx.fc.w'] = A('classifier.weight')
+    out['rx.fc.b'] = A('classifier.bias')
+    return {k: _as_np(v) for k, v in out.items()}
+
+
 class Engine:
     """One libdmad_hip engine bound to the current CUDA(HIP) device."""
 
@@ -139,6 +169,12 @@ class Engine:
         if self.has_classifier:
             raise DmadError('classifier weights are already loaded into this engine')
         self._load(fold_vgg19_bn_state_dict(state_dict))
+        self.has_classifier = True
+
+    def load_resnext29(self, state_dict):
+        if self.has_classifier:
+            raise DmadError('classifier weights are already loaded into this engine')
+        self._load(fold_resnext29_state_dict(state_dict))
         self.has_classifier = True
 
     # ------------------------------------------------------------------ helpers

@@ -135,3 +135,48 @@ def synthetic_clip(seed: int = 0, length: int = 16000) -> np.ndarray:
     x += 0.01 * rng.standard_normal(length)
     x = 0.5 * x / np.abs(x).max()
     return _f32(x[None, :])
+
+
+def resnext29_state_dict(seed: int = 2929, num_classes: int = 10, in_channels: int = 1):
+    """fp32 numpy state dict for models/resnext.py CifarResNeXt(nlabels=10, cardinality=8, depth=29, base_width=64,
+    widen_factor=4, in_channels=1): kaiming (fan_out) conv weights, BatchNorm affine/statistics drawn so that the
+    29-layer stack stays O(1) on dB-scaled mel images (first BN sized for inputs around -20 dB +- 12, like the VGG's)."""
+    rng = np.random.default_rng(seed)
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def conv(name, cout, cin_g, k):
+        w = rng.standard_normal((cout, cin_g, k, k)) * np.sqrt(2.0 / (cout * k * k))      # fan_out mode
+        sd[name + '.weight'] = _f32(w)
+        return w
+
+    def bn(name, c, gamma=(0.6, 1.4), mean=None, var=None):
+        sd[name + '.weight'] = _f32(rng.uniform(*gamma, size=c))
+        sd[name + '.bias'] = _f32(rng.standard_normal(c) * 0.1)
+        sd[name + '.running_mean'] = _f32(rng.standard_normal(c) * 0.2 if mean is None else mean)
+        sd[name + '.running_var'] = _f32(rng.uniform(0.5, 1.5, size=c) if var is None else var)
+        sd[name + '.num_batches_tracked'] = np.asarray(1000, dtype=np.int64)
+
+    w = conv('conv_1_3x3', 64, in_channels, 3)
+    wsum = w.reshape(64, -1).sum(1)
+    wl2 = np.sqrt((w.reshape(64, -1) ** 2).sum(1))
+    bn('bn_1', 64, mean=wsum * (-20.0), var=(wl2 * 12.0) ** 2 + 1.0)
+    stages = [64, 256, 512, 1024]
+    for st in (1, 2, 3):
+        for k in range(3):
+            cin = stages[st - 1] if k == 0 else stages[st]
+            cout = stages[st]
+            D = 8 * (64 * cout // 256)
+            p = 'stage_%d.stage_%d_bottleneck_%d.' % (st, st, k)
+            # a conv's output variance under this init is ~ 2 * fan_in / fan_out of its input's: the BN statistics follow it
+            conv(p + 'conv_reduce', D, cin, 1)
+            bn(p + 'bn_reduce', D, var=rng.uniform(0.5, 1.5, size=D) * (2.0 * cin / D))
+            conv(p + 'conv_conv', D, D // 8, 3)
+            bn(p + 'bn', D, var=rng.uniform(0.5, 1.5, size=D) * (2.0 / 8))
+            conv(p + 'conv_expand', cout, D, 1)
+            bn(p + 'bn_expand', cout, gamma=(0.3, 0.7), var=rng.uniform(0.5, 1.5, size=cout) * (2.0 * D / cout))
+            if cin != cout:
+                conv(p + 'shortcut.shortcut_conv', cout, cin, 1)
+                bn(p + 'shortcut.shortcut_bn', cout, gamma=(0.5, 0.9), var=rng.uniform(0.5, 1.5, size=cout) * (2.0 * cin / cout))
+    sd['classifier.weight'] = _f32(rng.standard_normal((num_classes, 1024)) * np.sqrt(2.0 / 1024))
+    sd['classifier.bias'] = _f32(rng.standard_normal(num_classes) * 0.1)
+    return sd

@@ -63,6 +63,9 @@ const char* dmad_version(void);
  *   skip.{n}.w[256,256] skip.{n}.b   f0.w[256,256] f0.b   f2.w[256] f2.b[1]
  *   vgg.conv{i}.w[cout,cin,3,3] vgg.conv{i}.scale[cout] vgg.conv{i}.shift[cout]  (i = 0..15)
  *   vgg.fc{j}.w[out,in] vgg.fc{j}.b   (j = 0..2)
+ * or, instead of the vgg.* set, ResNeXt29 8x64d (models/resnext.py:23-142; bottleneck i = 3 * stage + k, i = 0..8):
+ *   rx.conv1.w[64,1,3,3]  rx.b{i}.reduce.w[D,cin]  rx.b{i}.conv.w[D,D/8,3,3]  rx.b{i}.expand.w[cout,D]
+ *   rx.b{i}.short.w[cout,cin] (where cin != cout), each with .scale[M] .shift[M];  rx.fc.w[classes,1024] rx.fc.b
  * dmad_finalize_weights() packs whichever complete set (WaveNet, classifier) has been loaded and is not
  * packed yet into the MFMA/LDS layouts and uploads it; it may be called once per set. */
 int dmad_load_weight(dmad_engine* e, const char* name, const float* host, const int64_t* shape, int32_t ndim);
@@ -98,7 +101,8 @@ int dmad_mel_db(dmad_engine* e, const float* x, int32_t B, float* spec, dmad_str
 int dmad_mel_power(dmad_engine* e, const float* x, int32_t B, float* mel, dmad_stream s);
 int dmad_power_to_db(dmad_engine* e, const float* x, int64_t n, float* y, dmad_stream s);
 
-/* logits = VGG19_bn(spec)  — VGG.forward, audio_models/ConvNets_SpeechCommands/models/vgg.py:48-52.
+/* logits = classifier(spec)  — VGG.forward, audio_models/ConvNets_SpeechCommands/models/vgg.py:48-52, or
+ * CifarResNeXt.forward, models/resnext.py:133-142, whichever weight set was loaded.
  * spec: [B][32][32] fp32, logits: [B][num_classes] fp32. */
 int dmad_classify(dmad_engine* e, const float* spec, int32_t B, float* logits, dmad_stream s);
 

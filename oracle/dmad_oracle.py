@@ -339,6 +339,30 @@ def vgg19_bn_forward(sd, x: torch.Tensor) -> torch.Tensor:
     return F.linear(x, _t(sd, 'classifier.6.weight'), _t(sd, 'classifier.6.bias'))
 
 
+def resnext29_forward(sd, x):
+    """audio_models/ConvNets_SpeechCommands/models/resnext.py:56-65,133-142: CifarResNeXt 8x64d depth 29 in eval mode,
+    functional restatement over its state dict.  x: [B,1,32,32] -> logits [B,nlabels]."""
+    T = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))) for k, v in sd.items()}
+
+    def bn(h, p):
+        return F.batch_norm(h, T[p + '.running_mean'], T[p + '.running_var'], T[p + '.weight'], T[p + '.bias'], False, 0.0, 1e-5)
+
+    h = F.relu(bn(F.conv2d(x, T['conv_1_3x3.weight'], None, 1, 1), 'bn_1'))
+    for st in (1, 2, 3):
+        for k in range(3):
+            p = 'stage_%d.stage_%d_bottleneck_%d.' % (st, st, k)
+            stride = 2 if (k == 0 and st > 1) else 1
+            b = F.relu(bn(F.conv2d(h, T[p + 'conv_reduce.weight']), p + 'bn_reduce'))
+            b = F.relu(bn(F.conv2d(b, T[p + 'conv_conv.weight'], None, stride, 1, 1, 8), p + 'bn'))
+            b = bn(F.conv2d(b, T[p + 'conv_expand.weight']), p + 'bn_expand')
+            r = h
+            if p + 'shortcut.shortcut_conv.weight' in T:
+                r = bn(F.conv2d(h, T[p + 'shortcut.shortcut_conv.weight'], None, stride), p + 'shortcut.shortcut_bn')
+            h = F.relu(r + b)
+    h = F.avg_pool2d(h, 8, 1).view(-1, 1024)
+    return F.linear(h, T['classifier.weight'], T['classifier.bias'])
+
+
 def m5_forward(sd, x: torch.Tensor, stride: int = 16) -> torch.Tensor:
     """audio_models/M5/M5Net.py:21-38 (eval mode)."""
     def bn(x, i):

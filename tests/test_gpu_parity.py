@@ -489,3 +489,42 @@ def test_eot_nes_query_path(engines, orc):
     mean_loss, g, adver_loss, adver_score, predict = nes(x, y)
     assert mean_loss.shape == (2,) and g.shape == x.shape and adver_loss.shape == (2,) and adver_score.shape == (2, 10)
     assert predict.shape == (2,) and bool(torch.isfinite(g).all()) and bool(torch.isfinite(mean_loss).all())
+
+
+# ------------------------------------------------------------------------------------------ ResNeXt29 (N4)
+def test_resnext29_vs_reference_fixture(golden_dir, orc):
+    """CifarResNeXt 8x64d (the certification script's default classifier) on the fp32 matrix cores vs logits of the
+    imported reference class on the same seeded weights; batch-size invariance; the fused Monte Carlo loop with it."""
+    from audio_models.ConvNets_SpeechCommands.models.resnext import CifarResNeXt
+    from dmad_hip import engine as E
+    from dmad_hip.transforms import MelSpectrogramDB
+    from diffusion_models.diffwave_ddpm import DiffWave, WaveNetHIP
+    from diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    from robustness_eval.certified_robust import RobustCertificate
+    z = G(golden_dir, 'resnext29.npz')
+    sd = synth.resnext29_state_dict(int(z['seed']))
+    eng = E.Engine(max_batch=8, precision=E.BF16)
+    eng.load_wavenet(synth.wavenet_state_dict(1234))
+    net = CifarResNeXt(nlabels=10, in_channels=1)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    net.eval().bind_engine(eng)
+    spec = torch.from_numpy(z['spec_in']).cuda()
+    got = net(spec)
+    assert got.shape == (4, 10)
+    assert relmax(got.cpu().numpy(), z['logits']) < 2e-4
+    solo = net(spec[2:3])
+    assert torch.equal(solo, got[2:3])                                   # a sample's logits do not depend on its batch
+    big = net(spec.repeat(5, 1, 1, 1))                                    # 20 > max_batch: chunked
+    assert torch.equal(big[:4], got) and torch.equal(big[16:], got)
+    # random spectrograms against the oracle restatement
+    g = torch.Generator().manual_seed(3)
+    rs = (torch.randn(3, 1, 32, 32, generator=g) * 15 - 25)
+    ref = orc.resnext29_forward(sd, rs).numpy()
+    assert relmax(net(rs.cuda()).cpu().numpy(), ref) < 2e-4
+    # fused certified-smoothing loop with the ResNeXt classifier
+    den = DiffWave(WaveNetHIP(eng), calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG), reverse_timestep=66)
+    RC = RobustCertificate(classifier=net, transform=MelSpectrogramDB(eng), denoiser=den, seed=11)
+    assert RC._fused()
+    clip = torch.from_numpy(synth.synthetic_clip(0)).cuda()              # [1,16000], what certify() hands over
+    counts = RC.smooth_predict(clip, num_sampling=24, sigma=0.5, batch_size=8)
+    assert int(counts.sum()) == 24 and counts.shape == (10,)

@@ -297,3 +297,29 @@ def test_certification_records_format_and_resume(tmp_path):
     r2.append_batch([7], [7], [1.5]); r2.flush()
     assert [d['id'] for d in json.load(open(path))] == [0, 1, 2]
     assert len(CertificationRecords(str(tmp_path), 0.5, 1000)) == 0           # no resume: starts over
+
+
+def test_resnext29_mirror_layout_and_folding():
+    """The module mirror keeps the reference's parameter names (checkpoints load unchanged); folding yields one
+    scale/shift per conv with eval-BatchNorm semantics; no CPU forward exists."""
+    from audio_models.ConvNets_SpeechCommands.models import create_model as zoo_create
+    from audio_models.ConvNets_SpeechCommands.models.resnext import CifarResNeXt
+    from dmad_hip.engine import fold_resnext29_state_dict
+    sd = synth.resnext29_state_dict(2929)
+    net = CifarResNeXt(nlabels=10, in_channels=1)
+    assert isinstance(zoo_create('resnext29_8_64', 10, 1), CifarResNeXt)
+    assert set(net.state_dict().keys()) == set(sd.keys())
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    f = fold_resnext29_state_dict(net.state_dict())
+    assert f['rx.b0.reduce.w'].shape == (512, 64) and f['rx.b0.conv.w'].shape == (512, 64, 3, 3)
+    assert f['rx.b3.conv.w'].shape == (1024, 128, 3, 3) and f['rx.b6.short.w'].shape == (1024, 512)
+    assert 'rx.b1.short.w' not in f and f['rx.fc.w'].shape == (10, 1024)
+    g, b = sd['stage_2.stage_2_bottleneck_1.bn.weight'].astype(np.float64), sd['stage_2.stage_2_bottleneck_1.bn.bias'].astype(np.float64)
+    m, v = sd['stage_2.stage_2_bottleneck_1.bn.running_mean'].astype(np.float64), sd['stage_2.stage_2_bottleneck_1.bn.running_var'].astype(np.float64)
+    np.testing.assert_allclose(f['rx.b4.conv.scale'], g / np.sqrt(v + 1e-5), rtol=1e-6)
+    np.testing.assert_allclose(f['rx.b4.conv.shift'], b - m * g / np.sqrt(v + 1e-5), rtol=1e-5, atol=1e-7)
+    net.eval()
+    with pytest.raises(Exception):                      # no GPU here: binding the engine fails loudly, no CPU forward
+        net(torch.zeros(1, 1, 32, 32))
+    with pytest.raises(NotImplementedError):
+        CifarResNeXt(nlabels=10, cardinality=16, in_channels=1)

@@ -174,3 +174,12 @@ def test_smooth_predict_matches_reference_loop(golden_dir):
     np.testing.assert_allclose(logits.numpy(), z['m5_logits'][:4], rtol=1e-4, atol=1e-4)
     assert den.reverse_timestep == 66
     assert (logits.numpy().argmax(1) == z['m5_logits'][:4].argmax(1)).all()
+
+
+def test_resnext29(golden_dir):
+    """ResNeXt29 8x64d restatement vs the imported reference class on the same seeded weights
+    (tests/golden/make_golden_resnext.py)."""
+    z = _load(golden_dir, 'resnext29.npz')
+    sd = synth.resnext29_state_dict(int(z['seed']))
+    got = orc.resnext29_forward(sd, torch.from_numpy(z['spec_in'])).numpy()
+    np.testing.assert_allclose(got, z['logits'], rtol=1e-4, atol=1e-4)
