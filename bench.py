@@ -78,7 +78,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--samples-per-step', type=int, default=512)
-    ap.add_argument('--max-batch', type=int, default=128)
+    ap.add_argument('--max-batch', type=int, default=512,
+                    help='clips per engine launch; 512 = one launch chain per step (gate store 151 GB of the 288 GB HBM)')
     ap.add_argument('--sigma', type=float, default=0.5)
     ap.add_argument('--cpu-samples', type=int, default=6)
     ap.add_argument('--no-cpu-baseline', action='store_true')

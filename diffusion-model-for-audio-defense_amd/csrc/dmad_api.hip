@@ -584,7 +584,7 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     e->bf16 = cfg->precision == DMAD_BF16;
     if (e->bf16 && !wn_final_p_supported(cfg->num_res_layers)) {
         delete e;
-        return fail(DMAD_ERR_INVALID, "bf16 path needs num_res_layers to be a multiple of 3 (>= 3); got %d", cfg->num_res_layers);
+        return fail(DMAD_ERR_INVALID, "bf16 path does not support num_res_layers = %d", cfg->num_res_layers);
     }
     const size_t B = e->maxB, L = e->L, LP = e->LP, NL = e->NL;
     int r = 0;

@@ -7,12 +7,13 @@
 //
 // One workgroup (8 waves = 4 (M) x 2 (N), 1 per CU) walks over tiles of 256 consecutive (clip, time)
 // positions; wave tile 64 ch x 128 t = 32 accumulator tiles of 16x16 (same register budget as the layer
-// kernel).  K loop: k-steps of 32 through a 3-slot LDS ring (16 KiB of packed W_skip + 16 KiB of g rows per
-// slot), the 4 DMA pieces of k-step ks+3 and the 12 fragment reads of k-step ks+1 are spread between the
-// 32 MFMAs of k-step ks; counted vmcnt; one barrier per k-step.  Then y (bf16) -> LDS [256 t][256 ch],
+// kernel).  K loop: k-steps of 32 through a 4-slot LDS ring (16 KiB of packed W_skip + 16 KiB of g rows per
+// slot; three stages = 48 KiB of once-read gate rows in flight per CU to cover the HBM latency), the 4 DMA
+// pieces of k-step ks+4 and the 12 fragment reads of k-step ks+1 are spread between the 32 MFMAs of k-step ks;
+// counted vmcnt; one barrier per k-step.  Then y (bf16) -> LDS [256 t][256 ch],
 // the 256x256 final_conv.0 GEMM from LDS, ReLU, dot with w_z, reduce over channels (registers -> lanes ->
 // waves through LDS).
-// LDS map (160 KiB): ring slots at 0 / 32K / 64K; y tile [0,128K); final_conv.0 weight buffers 2 x 16 KiB
+// LDS map (160 KiB): ring slots at 0 / 32K / 64K / 96K; y tile [0,128K); final_conv.0 weight buffers 2 x 16 KiB
 // at [128K,160K).
 #include <type_traits>
 
@@ -95,10 +96,10 @@ __global__ void __launch_bounds__(512, 2) wn_final_bf16_p(WnFinalArgs a, long np
         }
         __builtin_amdgcn_s_waitcnt(0x0070);       // retire the bias loads before the first DMA (vmcnt(0))
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int p = 0; p < 4; ++p) stage_piece(s, s, p);
-        WNF_WAIT_BARRIER(8);                      // stage 0 landed
+        WNF_WAIT_BARRIER(12);                     // stage 0 landed
         bf16x8 af[2][4], bf[2][8];
         {
             const char* A = smem + wm * 4096 + frag_off;
@@ -108,21 +109,21 @@ __global__ void __launch_bounds__(512, 2) wn_final_bf16_p(WnFinalArgs a, long np
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) af[0][mt] = *(const bf16x8*)(A + mt * 1024);
         }
-        // ---------------- skip GEMM: nks k-steps, unrolled by 6 (2 fragment sets x 3 ring slots) ------------
-        // the last group of 6 is peeled (TAIL) so that the steady-state body carries no end-of-K conditions
+        // ---------------- skip GEMM: nks k-steps, unrolled by 4 (2 fragment sets, 4 ring slots) ---------------
+        // the last group of 4 is peeled (TAIL) so that the steady-state body carries no end-of-K conditions
         auto kgroup = [&](int ks0, auto tail_tag) {
             constexpr bool TAIL = decltype(tail_tag)::value;
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const int ks = ks0 + u;
                 const int cur = u & 1, nxt = cur ^ 1;
-                // stage ks+1 landed; stage ks+2 may still fly
-                if (!TAIL || u < 4) { WNF_WAIT_BARRIER(4); } else { WNF_WAIT_BARRIER(0); }
-                const char* Ar = smem + ((u + 1) % 3) * F_SLOT + wm * 4096 + frag_off;
-                const char* Br = smem + ((u + 1) % 3) * F_SLOT + F_BOFF + wn * 8192 + frag_off;
+                // stage ks+1 landed; stages ks+2, ks+3 may still fly (the tail issues nothing new)
+                if (!TAIL || u == 0) { WNF_WAIT_BARRIER(8); } else if (u == 1) { WNF_WAIT_BARRIER(4); } else { WNF_WAIT_BARRIER(0); }
+                const char* Ar = smem + ((u + 1) & 3) * F_SLOT + wm * 4096 + frag_off;
+                const char* Br = smem + ((u + 1) & 3) * F_SLOT + F_BOFF + wn * 8192 + frag_off;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {              // 4 x (1 DMA piece, 5 MFMAs)
-                    if (!TAIL || u < 3) stage_piece(ks + 3, u % 3, p);
+                    if (!TAIL) stage_piece(ks + 4, u, p);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 5 * p; i < 5 * p + 5; ++i)
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(512, 2) wn_final_bf16_p(WnFinalArgs a, long np
                 }
 #pragma unroll
                 for (int p = 0; p < 12; ++p) {             // 12 x (1 fragment read of k-step ks+1, 1 MFMA)
-                    if (!TAIL || u < 5) {
+                    if (!TAIL || u < 3) {
                         if (p < 8) bf[nxt][p] = *(const bf16x8*)(Br + p * 1024);
                         else af[nxt][p - 8] = *(const bf16x8*)(Ar + (p - 8) * 1024);
                     }
@@ -142,8 +143,8 @@ __global__ void __launch_bounds__(512, 2) wn_final_bf16_p(WnFinalArgs a, long np
                 }
             }
         };
-        for (int ks0 = 0; ks0 < nks - 6; ks0 += 6) kgroup(ks0, std::false_type{});
-        kgroup(nks - 6, std::true_type{});
+        for (int ks0 = 0; ks0 < nks - 4; ks0 += 4) kgroup(ks0, std::false_type{});
+        kgroup(nks - 4, std::true_type{});
         // ---------------- y = skip * sqrt(1/NL) -> bf16 -> LDS [256 t][256 ch] ------------------------------
         WNF_BARRIER_LGKM();                       // every wave holds its last fragments: the ring is free
         stage3(0, 0);
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(512, 2) wn_final_bf16_p(WnFinalArgs a, long np
 
 static int g_final_cus = 256;
 
-bool wn_final_p_supported(int num_res_layers) { return (num_res_layers * 8) % 6 == 0 && num_res_layers * 8 >= 12; }
+bool wn_final_p_supported(int num_res_layers) { return num_res_layers >= 1; }   // nks = 8 * layers: a multiple of 4, >= 8
 
 void launch_wn_final_bf16_p(const WnFinalArgs& a, hipStream_t s) {
     const long npos = (long)a.B * a.L;

@@ -3,6 +3,7 @@
 // which of them costs time beyond the MFMA-bound.  Build: hipcc -O3 --offload-arch=gfx950 gemm1_loop.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
@@ -25,7 +26,7 @@ __device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned
 // DMA: 0 none, 1 all five pieces.  READS: fragment reads on/off.  BAR: 0 none, 1 wait+barrier per k-step,
 // 2 wait only (no barrier).  ORDER: 0 = DMA pieces first (as shipped), 1 = fragment reads first.
 template <int DMA, int READS, int BAR, int ORDER>
-__global__ void __launch_bounds__(512, 2) k(const char* __restrict__ w, const char* __restrict__ h, float* __restrict__ out, int tiles) {
+__global__ void __launch_bounds__(512, 2) k(const char* __restrict__ w, const char* __restrict__ h, float* __restrict__ out, int tiles, int rnd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -34,7 +35,11 @@ __global__ void __launch_bounds__(512, 2) k(const char* __restrict__ w, const ch
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int frag_off = r16 * 64 + ((q ^ swz64(r16)) * 16);
     const int bfrag_off = q * 2048 + r16 * 16;
-    for (int i = tid; i < 163840 / 4; i += 512) ((unsigned*)smem)[i] = 0x3f803f80u;
+    for (int i = tid; i < 163840 / 4; i += 512) {
+        unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        // two bf16 with random sign/mantissa and exponent 2^-1..2^-4 (random data: realistic switching power), or ones
+        ((unsigned*)smem)[i] = rnd ? ((h & 0x807f807fu) | 0x3d003d00u | ((h >> 3) & 0x01800180u)) : 0x3f803f80u;
+    }
     __syncthreads();
     f32x4 acc[8][4];
 #pragma unroll
@@ -43,9 +48,9 @@ __global__ void __launch_bounds__(512, 2) k(const char* __restrict__ w, const ch
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af[2][8], bf[2][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { af[0][i] = af[1][i] = bf16x8{0x3f80, 0, 0, 0, 0, 0, 0, 0}; }
+    for (int i = 0; i < 8; ++i) { af[0][i] = af[1][i] = rnd ? *(const bf16x8*)(smem + ((tid * 16 + i * 8192) & 0x1fff0)) : bf16x8{0x3f80, 0, 0, 0, 0, 0, 0, 0}; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { bf[0][i] = bf[1][i] = bf16x8{0x3f80, 0, 0, 0, 0, 0, 0, 0}; }
+    for (int i = 0; i < 4; ++i) { bf[0][i] = bf[1][i] = rnd ? *(const bf16x8*)(smem + ((tid * 16 + i * 8192 + 4096) & 0x1fff0)) : bf16x8{0x3f80, 0, 0, 0, 0, 0, 0, 0}; }
     auto piece5 = [&](int tile, int ks, int p) {   // ks: weights stage for p < 4; activation stage for p == 4
         if (p < 4) dma16(w + ((size_t)(ks % 24) * 32768 + p * 8192), tid16, lds0 + (ks % 3) * 32768 + wv * 1024 + p * 8192);
         else dma16(h + ((size_t)(blockIdx.x * 64 + ((tile + ks / 24) & 63)) * 24 + (ks % 24)) * 8192, tid16, lds0 + 98304 + (ks & 3) * 8192 + wv * 1024);
@@ -177,17 +182,25 @@ __global__ void __launch_bounds__(512, 2) k(const char* __restrict__ w, const ch
     out[blockIdx.x * 512 + tid] = s;
 }
 
+__global__ void fill_rnd(unsigned* p, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = (h & 0x807f807fu) | 0x3d003d00u | ((h >> 3) & 0x01800180u);
+    }
+}
+
 template <int DMA, int READS, int BAR, int ORDER>
 void run(const char* name, const char* w, const char* h, float* out, double& base) {
-    const int tiles = 62;
+    const int rnd = getenv("RANDOM_DATA") ? 1 : 0;
+    const int tiles = getenv("TILES") ? atoi(getenv("TILES")) : 62;
     hipFuncSetAttribute((const void*)k<DMA, READS, BAR, ORDER>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<DMA, READS, BAR, ORDER>), dim3(256), dim3(512), 163840, 0, w, h, out, 4);
+    hipLaunchKernelGGL((k<DMA, READS, BAR, ORDER>), dim3(256), dim3(512), 163840, 0, w, h, out, 4, rnd);
     hipDeviceSynchronize();
     float best = 1e9;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<DMA, READS, BAR, ORDER>), dim3(256), dim3(512), 163840, 0, w, h, out, tiles);
+        hipLaunchKernelGGL((k<DMA, READS, BAR, ORDER>), dim3(256), dim3(512), 163840, 0, w, h, out, tiles, rnd);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
@@ -200,9 +213,14 @@ void run(const char* name, const char* w, const char* h, float* out, double& bas
 
 int main() {
     char *w, *h; float* out;
-    hipMalloc(&w, 24 * 32768); hipMemset(w, 0, 24 * 32768);
+    hipMalloc(&w, 24 * 32768); hipMemset(w, getenv("RANDOM_DATA") ? 0x3b : 0, 24 * 32768);
     const size_t hb = (size_t)256 * 64 * 24 * 8192;     // 3.2 GB of once-read activation slices
-    hipMalloc(&h, hb); hipMemset(h, 0, hb);
+    hipMalloc(&h, hb); hipMemset(h, getenv("RANDOM_DATA") ? 0xbc : 0, hb);
+    if (getenv("RANDOM_DATA")) {
+        hipLaunchKernelGGL(fill_rnd, dim3(1024), dim3(256), 0, 0, (unsigned*)w, (size_t)24 * 32768 / 4);
+        hipLaunchKernelGGL(fill_rnd, dim3(4096), dim3(256), 0, 0, (unsigned*)h, hb / 4);
+        hipDeviceSynchronize();
+    }
     hipMalloc(&out, 256 * 512 * 4);
     double base = 0;
     run<0, 0, 0, 0>("mfma only", w, h, out, base);
