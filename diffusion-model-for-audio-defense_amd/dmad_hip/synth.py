@@ -180,3 +180,91 @@ def resnext29_state_dict(seed: int = 2929, num_classes: int = 10, in_channels: i
     sd['classifier.weight'] = _f32(rng.standard_normal((num_classes, 1024)) * np.sqrt(2.0 / 1024))
     sd['classifier.bias'] = _f32(rng.standard_normal(num_classes) * 0.1)
     return sd
+
+
+UNET_CONFIG = dict(in_channels=1, model_channels=128, out_channels=1, num_res_blocks=3, attention_resolutions=(2, 4),
+                   channel_mult=(1, 2, 2, 2), num_heads=4, use_scale_shift_norm=True)
+
+
+def unet_layout(cfg=None):
+    """Block list of improved_diffusion.unet.UNetModel (unet.py:278-421) for `cfg`: a list of
+    (state-dict prefix, kind, cin, cout) with kind in conv_in / res / attn / down / up / out, in forward order of the
+    three containers.  Shared by the synthetic weights, the oracle restatement and the HIP engine's loader."""
+    c = dict(UNET_CONFIG)
+    c.update(cfg or {})
+    mc, nrb, mult, att = c['model_channels'], c['num_res_blocks'], c['channel_mult'], c['attention_resolutions']
+    inp, mid, outp = [[('input_blocks.0.0', 'conv_in', c['in_channels'], mc)]], [], []
+    chans, ch, ds = [mc], mc, 1
+    for level, m in enumerate(mult):
+        for _ in range(nrb):
+            i = len(inp)
+            blk = [('input_blocks.%d.0' % i, 'res', ch, m * mc)]
+            ch = m * mc
+            if ds in att:
+                blk.append(('input_blocks.%d.1' % i, 'attn', ch, ch))
+            inp.append(blk)
+            chans.append(ch)
+        if level != len(mult) - 1:
+            inp.append([('input_blocks.%d.0' % len(inp), 'down', ch, ch)])
+            chans.append(ch)
+            ds *= 2
+    mid = [('middle_block.0', 'res', ch, ch), ('middle_block.1', 'attn', ch, ch), ('middle_block.2', 'res', ch, ch)]
+    for level, m in list(enumerate(mult))[::-1]:
+        for i in range(nrb + 1):
+            j = len(outp)
+            blk = [('output_blocks.%d.0' % j, 'res', ch + chans.pop(), mc * m)]
+            ch = mc * m
+            if ds in att:
+                blk.append(('output_blocks.%d.1' % j, 'attn', ch, ch))
+            if level and i == nrb:
+                blk.append(('output_blocks.%d.%d' % (j, len(blk)), 'up', ch, ch))
+                ds //= 2
+            outp.append(blk)
+    return c, inp, mid, outp
+
+
+def unet_state_dict(seed: int = 5252, cfg=None):
+    """fp32 numpy state dict for improved_diffusion.unet.UNetModel with UNET_CONFIG (52.5 M parameters): the reference's
+    parameter names; conv / linear weights N(0, g / fan_in) with gains that keep the 35-block stack O(1); the
+    zero-initialised modules of the reference (out_layers.3, proj_out, out.2 — non-zero after training) get small
+    random weights so that every path contributes."""
+    c, inp, mid, outp = unet_layout(cfg)
+    rng = np.random.default_rng(seed)
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    mc = c['model_channels']
+    ted = 4 * mc
+
+    def dense(name, shape, gain):
+        fan_in = int(np.prod(shape[1:]))
+        sd[name + '.weight'] = _f32(rng.standard_normal(shape) * np.sqrt(gain / fan_in))
+        sd[name + '.bias'] = _f32(rng.standard_normal(shape[0]) * 0.02)
+
+    def gn(name, ch):
+        sd[name + '.weight'] = _f32(rng.uniform(0.7, 1.3, size=ch))
+        sd[name + '.bias'] = _f32(rng.standard_normal(ch) * 0.1)
+
+    dense('time_embed.0', (ted, mc), 1.0)
+    dense('time_embed.2', (ted, ted), 1.0)
+    for blk in inp + [mid] + outp:
+        for prefix, kind, cin, cout in blk:
+            if kind == 'conv_in':
+                dense(prefix, (cout, cin, 3, 3), 1.0)
+            elif kind == 'res':
+                gn(prefix + '.in_layers.0', cin)
+                dense(prefix + '.in_layers.2', (cout, cin, 3, 3), 2.0)
+                dense(prefix + '.emb_layers.1', (2 * cout, ted), 0.5)
+                gn(prefix + '.out_layers.0', cout)
+                dense(prefix + '.out_layers.3', (cout, cout, 3, 3), 0.3)
+                if cin != cout:
+                    dense(prefix + '.skip_connection', (cout, cin, 1, 1), 1.0)
+            elif kind == 'attn':
+                gn(prefix + '.norm', cin)
+                dense(prefix + '.qkv', (3 * cin, cin, 1), 1.0)
+                dense(prefix + '.proj_out', (cin, cin, 1), 0.3)
+            elif kind == 'down':
+                dense(prefix + '.op', (cout, cin, 3, 3), 1.0)
+            elif kind == 'up':
+                dense(prefix + '.conv', (cout, cin, 3, 3), 1.0)
+    gn('out.0', mc)
+    dense('out.2', (c['out_channels'], mc, 3, 3), 1.0)
+    return sd

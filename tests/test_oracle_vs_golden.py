@@ -183,3 +183,27 @@ def test_resnext29(golden_dir):
     sd = synth.resnext29_state_dict(int(z['seed']))
     got = orc.resnext29_forward(sd, torch.from_numpy(z['spec_in'])).numpy()
     np.testing.assert_allclose(got, z['logits'], rtol=1e-4, atol=1e-4)
+
+
+def test_unet_and_gaussian_diffusion(golden_dir):
+    """Improved-Diffusion UNet forward, q_sample, p_sample and the mel standardisation vs outputs
+    of the imported reference classes on the same seeded weights (tests/golden/make_golden_unet.py)."""
+    z = _load(golden_dir, 'unet.npz')
+    sd = synth.unet_state_dict(int(z['seed']))
+    lay = synth.unet_layout()
+    x0 = orc.melspec_standardize(torch.from_numpy(z['spec']))
+    np.testing.assert_allclose(x0.numpy(), z['x0'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(orc.melspec_inv_standardize(x0).numpy(), z['inv_std'], rtol=0, atol=2e-5)
+    gd = orc.GaussianDiffusionOracle(1000)
+    g = torch.Generator().manual_seed(31)
+    noise = torch.randn(x0.shape, generator=g)
+    for t in (3, 40):
+        x_t = gd.q_sample(torch.from_numpy(z['x0']), t, noise)
+        np.testing.assert_allclose(x_t.numpy(), z['x_t%d' % t], rtol=0, atol=1e-6)
+        eps = orc.unet_forward(sd, torch.from_numpy(z['x_t%d' % t]), torch.full((2,), t), lay)
+        assert np.abs(eps.numpy() - z['eps_t%d' % t]).max() <= 1e-4 * np.abs(z['eps_t%d' % t]).max()
+    model = lambda x, t: orc.unet_forward(sd, x, torch.full((x.shape[0],), t), lay)
+    for t in (3, 0):
+        smp, xs = gd.p_sample(model, torch.from_numpy(z['x_t3']), t, torch.from_numpy(z['p_noise_t%d' % t]))
+        np.testing.assert_allclose(xs.numpy(), z['p_xstart_t%d' % t], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(smp.numpy(), z['p_sample_t%d' % t], rtol=0, atol=2e-4)
