@@ -12,6 +12,7 @@
 
 #include "../../include/dmad.h"
 #include "dmad_common.h"
+#include "unet_ops.h"
 #include "elementwise.h"
 #include "gemm_f32.h"
 #include "wn_bf16.h"
@@ -108,6 +109,25 @@ struct dmad_engine {
     RxConv rxconv1;
     float *rxfcw = nullptr, *rxfcb = nullptr;
     float *rxX = nullptr, *rxY = nullptr, *rxT1 = nullptr, *rxT2 = nullptr, *rxS = nullptr;   // NHWC work buffers
+    // Improved-Diffusion UNet purifier on 1x32x32 mel spectrograms (improved_diffusion/unet.py:278-477)
+    struct UnOp {                          // one module of a TimestepEmbedSequential
+        int kind = 0;                      // 0 conv_in, 1 res, 2 attn, 3 down, 4 up
+        int cin = 0, cout = 0;
+        float *gn1w = nullptr, *gn1b = nullptr, *w1 = nullptr, *b1 = nullptr;       // res: in_layers; attn: norm, qkv; down/up/conv_in: conv
+        float *embw = nullptr, *embb = nullptr, *gn2w = nullptr, *gn2b = nullptr, *w2 = nullptr, *b2 = nullptr;   // res: emb, out_layers; attn: proj_out
+        float *skw = nullptr, *skb = nullptr;                                       // res: 1x1 skip_connection
+        float* ss = nullptr;               // res: this step's (scale, shift) row [2 * cout]
+    };
+    std::vector<std::vector<UnOp>> un_in, un_out;
+    std::vector<UnOp> un_mid;
+    std::vector<int> un_hs_ch, un_hs_hw;   // channels / pixels of the saved input-block outputs
+    std::vector<float*> un_hs;
+    bool un_final = false;
+    int un_t = -1;
+    float *un_te0w = nullptr, *un_te0b = nullptr, *un_te2w = nullptr, *un_te2b = nullptr, *un_outgw = nullptr, *un_outgb = nullptr;
+    float *un_outw = nullptr, *un_outb = nullptr, *un_temb = nullptr, *un_emb1 = nullptr, *un_emb = nullptr, *un_semb = nullptr;
+    float* un_buf[8] = {nullptr};          // work maps: 3 rotating block outputs, T1, T2, skip, qkv / cat, attention
+    float* un_eps = nullptr;
 
     template <typename T>
     int alloc(T** p, size_t n, bool zero = false) {
@@ -432,6 +452,218 @@ int classify_resnext(dmad_engine* e, const float* spec, int B, float* logits, hi
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Improved-Diffusion UNet.  Configuration of the reference's wrapper (improved_diffusion_ddpm.py:
+// 64-93 + script_util.py:11-34,100-131): 1 -> 128 channels, 3 ResBlocks per level, channel_mult (1,2,2,2), attention at
+// 16x16 and 8x8 (+ the middle block), 4 heads, scale-shift norm, epsilon output.  Weight names = "un." + the reference's
+// state-dict names.  Every conv / linear is a gemm_f32 launch over NHWC maps.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kUnMC = 128, kUnTE = 512, kUnHeads = 4, kUnRes = 3;
+const int kUnMult[4] = {1, 2, 2, 2};
+inline bool un_attn_at(int ds) { return ds == 2 || ds == 4; }
+
+int un_conv3(dmad_engine* e, const std::string& name, int cout, int cin, float** w, float** b) {
+    const HostW* h = e->get(name + ".weight", {cout, cin, 3, 3}); if (!h) return DMAD_ERR_STATE;
+    std::vector<float> A((size_t)9 * cout * cin);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < 9; ++t) A[((size_t)t * cout + co) * cin + ci] = h->v[((size_t)co * cin + ci) * 9 + t];
+    CHK(e->upload(w, A));
+    h = e->get(name + ".bias", {cout}); if (!h) return DMAD_ERR_STATE;
+    CHK(e->upload(b, h->v));
+    return 0;
+}
+int un_dense(dmad_engine* e, const std::string& name, int out, int in, float** w, float** b) {
+    const HostW* h = e->get(name + ".weight", {out, in}); if (!h) return DMAD_ERR_STATE;
+    CHK(e->upload(w, h->v));
+    h = e->get(name + ".bias", {out}); if (!h) return DMAD_ERR_STATE;
+    CHK(e->upload(b, h->v));
+    return 0;
+}
+int un_load_op(dmad_engine* e, const std::string& p, dmad_engine::UnOp& o) {
+    if (o.kind == 0) {
+        const HostW* h = e->get(p + ".weight", {o.cout, 1, 3, 3}); if (!h) return DMAD_ERR_STATE;
+        CHK(e->upload(&o.w1, h->v));
+        h = e->get(p + ".bias", {o.cout}); if (!h) return DMAD_ERR_STATE;
+        CHK(e->upload(&o.b1, h->v));
+    } else if (o.kind == 1) {
+        CHK(un_dense(e, p + ".in_layers.0", o.cin, 1, &o.gn1w, &o.gn1b));
+        CHK(un_conv3(e, p + ".in_layers.2", o.cout, o.cin, &o.w1, &o.b1));
+        CHK(un_dense(e, p + ".emb_layers.1", 2 * o.cout, kUnTE, &o.embw, &o.embb));
+        CHK(un_dense(e, p + ".out_layers.0", o.cout, 1, &o.gn2w, &o.gn2b));
+        CHK(un_conv3(e, p + ".out_layers.3", o.cout, o.cout, &o.w2, &o.b2));
+        if (o.cin != o.cout) CHK(un_dense(e, p + ".skip_connection", o.cout, o.cin, &o.skw, &o.skb));
+        CHK(e->alloc(&o.ss, (size_t)2 * o.cout));
+    } else if (o.kind == 2) {
+        CHK(un_dense(e, p + ".norm", o.cin, 1, &o.gn1w, &o.gn1b));
+        CHK(un_dense(e, p + ".qkv", 3 * o.cin, o.cin, &o.w1, &o.b1));
+        CHK(un_dense(e, p + ".proj_out", o.cin, o.cin, &o.w2, &o.b2));
+    } else if (o.kind == 3) {
+        CHK(un_conv3(e, p + ".op", o.cout, o.cin, &o.w1, &o.b1));
+    } else {
+        CHK(un_conv3(e, p + ".conv", o.cout, o.cin, &o.w1, &o.b1));
+    }
+    return 0;
+}
+
+int finalize_unet(dmad_engine* e) {
+    typedef dmad_engine::UnOp Op;
+    auto mk = [](int kind, int cin, int cout) { Op o; o.kind = kind; o.cin = cin; o.cout = cout; return o; };
+    // enumerate the modules exactly as UNetModel.__init__ builds them (unet.py:338-421)
+    std::vector<int> chans{kUnMC};
+    int ch = kUnMC, ds = 1, hw = 1024;
+    e->un_in.push_back({mk(0, 1, kUnMC)});
+    e->un_hs_ch = {kUnMC}; e->un_hs_hw = {1024};
+    for (int level = 0; level < 4; ++level) {
+        for (int r = 0; r < kUnRes; ++r) {
+            std::vector<Op> blk{mk(1, ch, kUnMult[level] * kUnMC)};
+            ch = kUnMult[level] * kUnMC;
+            if (un_attn_at(ds)) blk.push_back(mk(2, ch, ch));
+            e->un_in.push_back(blk);
+            chans.push_back(ch); e->un_hs_ch.push_back(ch); e->un_hs_hw.push_back(hw);
+        }
+        if (level != 3) {
+            e->un_in.push_back({mk(3, ch, ch)});
+            ds *= 2; hw /= 4;
+            chans.push_back(ch); e->un_hs_ch.push_back(ch); e->un_hs_hw.push_back(hw);
+        }
+    }
+    e->un_mid = {mk(1, ch, ch), mk(2, ch, ch), mk(1, ch, ch)};
+    for (int level = 3; level >= 0; --level)
+        for (int i = 0; i <= kUnRes; ++i) {
+            std::vector<Op> blk{mk(1, ch + chans.back(), kUnMC * kUnMult[level])};
+            chans.pop_back();
+            ch = kUnMC * kUnMult[level];
+            if (un_attn_at(ds)) blk.push_back(mk(2, ch, ch));
+            if (level && i == kUnRes) { blk.push_back(mk(4, ch, ch)); ds /= 2; }
+            e->un_out.push_back(blk);
+        }
+    for (size_t i = 0; i < e->un_in.size(); ++i)
+        for (size_t j = 0; j < e->un_in[i].size(); ++j)
+            CHK(un_load_op(e, "un.input_blocks." + std::to_string(i) + "." + std::to_string(j), e->un_in[i][j]));
+    for (size_t j = 0; j < e->un_mid.size(); ++j) CHK(un_load_op(e, "un.middle_block." + std::to_string(j), e->un_mid[j]));
+    for (size_t i = 0; i < e->un_out.size(); ++i)
+        for (size_t j = 0; j < e->un_out[i].size(); ++j)
+            CHK(un_load_op(e, "un.output_blocks." + std::to_string(i) + "." + std::to_string(j), e->un_out[i][j]));
+    CHK(un_dense(e, "un.time_embed.0", kUnTE, kUnMC, &e->un_te0w, &e->un_te0b));
+    CHK(un_dense(e, "un.time_embed.2", kUnTE, kUnTE, &e->un_te2w, &e->un_te2b));
+    CHK(un_dense(e, "un.out.0", kUnMC, 1, &e->un_outgw, &e->un_outgb));
+    CHK(un_conv3(e, "un.out.2", 1, kUnMC, &e->un_outw, &e->un_outb));
+    const size_t B = (size_t)e->maxB;
+    for (size_t i = 0; i < e->un_hs_ch.size(); ++i) {
+        float* p = nullptr;
+        CHK(e->alloc(&p, B * e->un_hs_hw[i] * e->un_hs_ch[i]));
+        e->un_hs.push_back(p);
+    }
+    for (int i = 0; i < 8; ++i) CHK(e->alloc(&e->un_buf[i], B * 1024 * 384));     // largest map: 32x32 x (256 + 128) concat
+    CHK(e->alloc(&e->un_eps, B * 1024));
+    CHK(e->alloc(&e->un_temb, kUnMC)); CHK(e->alloc(&e->un_emb1, kUnTE)); CHK(e->alloc(&e->un_emb, kUnTE)); CHK(e->alloc(&e->un_semb, kUnTE));
+    return 0;
+}
+
+// emb = time_embed(timestep_embedding(t)) (unet.py:466, nn.py:103-121), SiLU(emb), and every ResBlock's (scale, shift) row
+int unet_prepare_step(dmad_engine* e, int t, hipStream_t s) {
+    if (e->un_t == t) return 0;
+    float te[kUnMC];
+    const float a = (float)(-log(10000.0));
+    for (int i = 0; i < kUnMC / 2; ++i) {
+        const float f = expf(a * (float)i / (float)(kUnMC / 2));
+        const float arg = (float)t * f;
+        te[i] = cosf(arg);
+        te[kUnMC / 2 + i] = sinf(arg);
+    }
+    HIPCHK(hipMemcpyAsync(e->un_temb, te, sizeof te, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));        // `te` lives on this stack frame
+    launch_gemm_f32(plain_gemm(e->un_te0w, e->un_temb, e->un_emb1, nullptr, e->un_te0b, kUnTE, kUnMC, 1, kUnTE, kUnMC, 0), s);
+    launch_silu(e->un_emb1, e->un_emb1, kUnTE, s);
+    launch_gemm_f32(plain_gemm(e->un_te2w, e->un_emb1, e->un_emb, nullptr, e->un_te2b, kUnTE, kUnTE, 1, kUnTE, kUnTE, 0), s);
+    launch_silu(e->un_emb, e->un_semb, kUnTE, s);
+    auto each = [&](dmad_engine::UnOp& o) {
+        if (o.kind == 1)
+            launch_gemm_f32(plain_gemm(o.embw, e->un_semb, o.ss, nullptr, o.embb, 2 * o.cout, kUnTE, 1, 2 * o.cout, kUnTE, 0), s);
+    };
+    for (auto& b : e->un_in) for (auto& o : b) each(o);
+    for (auto& o : e->un_mid) each(o);
+    for (auto& b : e->un_out) for (auto& o : b) each(o);
+    e->un_t = t;
+    return 0;
+}
+
+GemmF32Args un_conv_args(const float* A, const float* bias, const float* X, float* C, int cout, int cin, int taps, int B, int H, int stride,
+                         const float* res) {
+    GemmF32Args g{};
+    const int Ho = (H - 1) / (stride > 1 ? stride : 1) + 1;
+    g.A = A; g.X = X; g.C = C; g.scale = nullptr; g.shift = bias; g.M = cout; g.K = cin; g.taps = taps; g.ldc = cout; g.relu = 0;
+    g.N = (long)B * Ho * Ho; g.mode = 2; g.H = H; g.W = H; g.Cin = cin; g.ldx = cin; g.stride = stride; g.res = res;
+    return g;
+}
+
+// applies one module; `in` [B][H*H][cin] -> returns the buffer holding [B][Ho*Ho][cout].  `dst`: where the result must
+// land (a saved-skip buffer) or nullptr (take a rotating work buffer).
+const float* unet_apply(dmad_engine* e, const dmad_engine::UnOp& o, const float* in, int B, int& H, float* dst, int& rot, hipStream_t s) {
+    float *T1 = e->un_buf[3], *T2 = e->un_buf[4], *SK = e->un_buf[5], *QKV = e->un_buf[6], *ATT = e->un_buf[7];
+    auto next = [&]() { float* p = e->un_buf[rot]; rot = (rot + 1) % 3; if (p == in) { p = e->un_buf[rot]; rot = (rot + 1) % 3; } return p; };
+    float* out = dst ? dst : next();
+    const long nref = (long)e->maxB * H * H;
+    if (o.kind == 1) {                      // ResBlock._forward, unet.py:186-199
+        launch_groupnorm_nhwc(in, o.gn1w, o.gn1b, nullptr, 1, T1, B, H * H, o.cin, s);
+        launch_gemm_f32(un_conv_args(o.w1, o.b1, T1, T2, o.cout, o.cin, 9, B, H, 1, nullptr), s, e->slab, e->slab_floats, nref);
+        launch_groupnorm_nhwc(T2, o.gn2w, o.gn2b, o.ss, 1, T1, B, H * H, o.cout, s);
+        const float* skip = in;
+        if (o.cin != o.cout) {
+            launch_gemm_f32(un_conv_args(o.skw, o.skb, in, SK, o.cout, o.cin, 1, B, H, 1, nullptr), s, e->slab, e->slab_floats, nref);
+            skip = SK;
+        }
+        launch_gemm_f32(un_conv_args(o.w2, o.b2, T1, out, o.cout, o.cout, 9, B, H, 1, skip), s, e->slab, e->slab_floats, nref);
+    } else if (o.kind == 2) {               // AttentionBlock._forward + QKVAttention, unet.py:225-258
+        const int C = o.cin, T = H * H;
+        launch_groupnorm_nhwc(in, o.gn1w, o.gn1b, nullptr, 0, T1, B, T, C, s);
+        launch_gemm_f32(plain_gemm(o.w1, T1, QKV, nullptr, o.b1, 3 * C, C, (long)B * T, 3 * C, C, 0), s, e->slab, e->slab_floats, nref);
+        launch_qkv_attention(QKV, ATT, B, T, kUnHeads, s);
+        GemmF32Args g = plain_gemm(o.w2, ATT, out, nullptr, o.b2, C, C, (long)B * T, C, C, 0);
+        g.res = in;
+        launch_gemm_f32(g, s, e->slab, e->slab_floats, nref);
+    } else if (o.kind == 3) {               // Downsample: conv 3x3 stride 2, unet.py:82-111
+        launch_gemm_f32(un_conv_args(o.w1, o.b1, in, out, o.cout, o.cin, 9, B, H, 2, nullptr), s, e->slab, e->slab_floats, nref / 4);
+        H /= 2;
+    } else if (o.kind == 4) {               // Upsample: nearest x2 + conv 3x3, unet.py:49-79
+        launch_upsample2x_nhwc(in, T1, B, H, H, o.cin, s);
+        H *= 2;
+        launch_gemm_f32(un_conv_args(o.w1, o.b1, T1, out, o.cout, o.cin, 9, B, H, 1, nullptr), s, e->slab, e->slab_floats, nref * 4);
+    } else {
+        launch_conv1ch_3x3(in, o.w1, o.b1, out, B, o.cout, s);
+    }
+    return out;
+}
+
+// eps = UNetModel.forward(x, t * ones)  (unet.py:453-477): x, eps [B][32][32]
+int unet_eps(dmad_engine* e, const float* x, int t, int B, float* eps, hipStream_t s) {
+    if (!e->un_final) return fail(DMAD_ERR_STATE, "UNet weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
+    if (B < 1 || B > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d]", B, e->maxB);
+    if (t < 0) return fail(DMAD_ERR_INVALID, "diffusion step %d < 0", t);
+    CHK(unet_prepare_step(e, t, s));
+    int H = 32, rot = 0;
+    const float* h = x;
+    for (size_t i = 0; i < e->un_in.size(); ++i)
+        for (size_t j = 0; j < e->un_in[i].size(); ++j)
+            h = unet_apply(e, e->un_in[i][j], h, B, H, j + 1 == e->un_in[i].size() ? e->un_hs[i] : nullptr, rot, s);
+    for (auto& o : e->un_mid) h = unet_apply(e, o, h, B, H, nullptr, rot, s);
+    size_t top = e->un_hs.size();
+    for (auto& blk : e->un_out) {
+        --top;
+        const int c1 = blk[0].cin - e->un_hs_ch[top], c2 = e->un_hs_ch[top];
+        float* cat = e->un_buf[6];          // the qkv map is dead between modules
+        launch_copy_channels(h, c1, cat, c1 + c2, c1, (long)B * H * H, s);
+        launch_copy_channels(e->un_hs[top], c2, cat + c1, c1 + c2, c2, (long)B * H * H, s);
+        h = cat;
+        for (auto& o : blk) h = unet_apply(e, o, h, B, H, nullptr, rot, s);
+    }
+    launch_groupnorm_nhwc(h, e->un_outgw, e->un_outgb, nullptr, 1, e->un_buf[3], B, 1024, kUnMC, s);
+    launch_gemm_f32(un_conv_args(e->un_outw, e->un_outb, e->un_buf[3], eps, 1, kUnMC, 9, B, 32, 1, nullptr), s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int ensure_embed(dmad_engine* e, int t, hipStream_t s) {
     if (e->emb_t == t) return 0;
     launch_embed_table((float)t, e->fc1w, e->fc1b, e->fc2w, e->fc2b, e->fctw, e->fctb, e->emb_table, e->emb2, e->bf16 ? e->b2 : nullptr,
@@ -691,6 +923,14 @@ int dmad_finalize_weights(dmad_engine* e) {
         CHK(finalize_resnext(e));
         e->cls_final = true; e->cls_kind = 1; did = true;
     }
+    if (!e->un_final && e->hw.count("un.time_embed.0.weight")) {
+        if (!e->slab) {                     // engines created without a classifier have no split-K workspace yet
+            e->slab_floats = 8l << 20;
+            CHK(e->alloc(&e->slab, (size_t)e->slab_floats));
+        }
+        CHK(finalize_unet(e));
+        e->un_final = true; did = true;
+    }
     if (!did) return fail(DMAD_ERR_STATE, "nothing to finalise: no complete weight set was loaded");
     e->hw.clear();
     return 0;
@@ -736,6 +976,28 @@ int dmad_diffuse(dmad_engine* e, const float* x0, float c_a, float c_b, const fl
         zz = e->znoise;
     }
     launch_lincomb(1, x0, nullptr, zz, c_a, c_b, 0.f, x_t, (long)B * e->L, (hipStream_t)s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int dmad_unet_eps(dmad_engine* e, const float* x_t, int32_t t, int32_t B, float* eps, dmad_stream s) {
+    if (!e || !x_t || !eps) return fail(DMAD_ERR_INVALID, "null argument");
+    return unet_eps(e, x_t, t, B, eps, (hipStream_t)s);
+}
+
+int dmad_unet_p_sample(dmad_engine* e, float* x, int32_t t, float c_a, float c_b, float c_1, float c_2, float c_sig, const float* z,
+                       uint64_t seed, uint64_t sample0, int32_t B, float* x0_out, dmad_stream s) {
+    if (!e || !x) return fail(DMAD_ERR_INVALID, "null argument");
+    CHK(unet_eps(e, x, t, B, e->un_eps, (hipStream_t)s));
+    const float* zz = nullptr;
+    if (c_sig != 0.f) {
+        zz = z;
+        if (!zz) {
+            launch_philox_normal(seed, sample0, 0x0E70u + (uint32_t)t, e->znoise, B, 1024, (hipStream_t)s);
+            zz = e->znoise;
+        }
+    }
+    launch_unet_p_sample(x, e->un_eps, zz, c_a, c_b, c_1, c_2, c_sig, x, x0_out, (long)B * 1024, (hipStream_t)s);
     HIPCHK(hipGetLastError());
     return 0;
 }

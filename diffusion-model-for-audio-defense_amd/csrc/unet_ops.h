@@ -1,0 +1,28 @@
+// Elementwise / normalisation / attention kernels of the Improved-Diffusion UNet purifier (SURVEY §8f row N1;
+// reference diffusion_models/Improved_Diffusion_Unconditional/improved_diffusion/unet.py, nn.py).  All maps are fp32
+// NHWC ([B][H*W][C]); the convolutions and linear layers run through gemm_f32.
+#pragma once
+#include "dmad_common.h"
+
+namespace dmad {
+
+// conv 3x3, one input channel, padding 1, bias: in [B][32][32] -> out [B][1024][Cout]   (input_blocks.0.0)
+void launch_conv1ch_3x3(const float* in, const float* w, const float* bias, float* out, int B, int Cout, hipStream_t s);
+// GroupNorm32(32, C) in fp32 (nn.py:15-17,92-100) over [B][HW][C], then optionally y * (1 + ss[c]) + ss[C + c]
+// (scale-shift norm, unet.py:190-194; ss = one row of 2C floats shared by the batch) and optionally SiLU.
+void launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* ss, int silu, float* y, int B, int HW,
+                           int C, hipStream_t s);
+void launch_silu(const float* x, float* y, long n, hipStream_t s);
+// nearest-neighbour x2 (F.interpolate(scale_factor=2, mode="nearest"), unet.py:72)
+void launch_upsample2x_nhwc(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
+// dst[r][0..C) = src[r][0..C) with row pitches ld_src / ld_dst (channel concatenation th.cat(dim=1), unet.py:473)
+void launch_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, int C, long rows, hipStream_t s);
+// QKVAttention (unet.py:241-258) with the reference's head-major channel split: qkv [B*T][3C] (token-major),
+// head h: q = channels h*3*64 + [0,64), k = + 64, v = + 128;  out [B*T][C], channel h*64 + c.  Head width 64.
+void launch_qkv_attention(const float* qkv, float* out, int B, int T, int heads, hipStream_t s);
+// GaussianDiffusion.p_sample (gaussian_diffusion.py:232-257,331-387: epsilon prediction, clip_denoised, fixed variance):
+//   x0 = clamp(ca * x - cb * eps, -1, 1);  out = c1 * x0 + c2 * x + sig * z      (z may be null when sig == 0)
+void launch_unet_p_sample(const float* x, const float* eps, const float* z, float ca, float cb, float c1, float c2, float sig,
+                          float* out, float* x0_out, long n, hipStream_t s);
+
+}  // namespace dmad

@@ -1,0 +1,172 @@
+// See unet_ops.h.
+#include "unet_ops.h"
+
+namespace dmad {
+
+namespace {
+inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1) / b); }
+
+__global__ void conv1ch_3x3_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                                   float* __restrict__ out, int Cout, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one (b, y, x, co) each
+    if (i >= total) return;
+    const int co = (int)(i % Cout);
+    const long p = i / Cout, b = p >> 10;
+    const int y = (int)((p >> 5) & 31), x = (int)(p & 31);
+    float s = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            if ((unsigned)yy < 32u && (unsigned)xx < 32u) s = fmaf(w[co * 9 + ky * 3 + kx], in[(b << 10) + yy * 32 + xx], s);
+        }
+    out[i] = s + bias[co];
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {   // 256 threads
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int wv = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wv] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// one workgroup per (group, sample): mean, then biased variance of the deviations, then the affine / scale-shift / SiLU
+__global__ void __launch_bounds__(256) groupnorm_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ ss, int silu,
+                                                             float* __restrict__ y, int HW, int C) {
+    __shared__ float red[4];
+    const int g = blockIdx.x, cg = C >> 5, n = cg * HW;
+    const long base = (long)blockIdx.y * HW * C + g * cg;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[base + (long)(i / cg) * C + (i % cg)];
+    const float mean = block_sum(s, red) / (float)n;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float d = x[base + (long)(i / cg) * C + (i % cg)] - mean;
+        q = fmaf(d, d, q);
+    }
+    const float rstd = 1.0f / sqrtf(block_sum(q, red) / (float)n + 1e-5f);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = g * cg + (i % cg);
+        const long a = base + (long)(i / cg) * C + (i % cg);
+        float v = (x[a] - mean) * rstd * gamma[c] + beta[c];
+        if (ss) v = v * (1.f + ss[c]) + ss[C + c];
+        if (silu) v = v / (1.f + expf(-v));
+        y[a] = v;
+    }
+}
+
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float v = x[i]; y[i] = v / (1.f + expf(-v)); }
+}
+
+__global__ void upsample2x_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C4, long total4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 of output
+    if (i >= total4) return;
+    const int c = (int)(i % C4);
+    long p = i / C4;
+    const int xo = (int)(p % (2 * W)); p /= 2 * W;
+    const int yo = (int)(p % (2 * H));
+    const long b = p / (2 * H);
+    ((float4*)out)[i] = ((const float4*)in)[((b * H + (yo >> 1)) * W + (xo >> 1)) * C4 + c];
+}
+
+__global__ void copy_channels_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst, int C4, long total4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const long r = i / C4;
+    const int c = (int)(i - r * C4);
+    *(float4*)(dst + r * ld_dst + c * 4) = *(const float4*)(src + r * ld_src + c * 4);
+}
+
+// one thread per query; keys / values of one (sample, head) stream through LDS in chunks of 64 with an online softmax
+constexpr int HD = 64, KCH = 64;
+__global__ void __launch_bounds__(256) qkv_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int heads) {
+    __shared__ float Ks[KCH][HD];
+    __shared__ float Vs[KCH][HD];
+    const int h = blockIdx.x, b = blockIdx.y, t = blockIdx.z * blockDim.x + threadIdx.x;
+    const int C3 = 3 * HD * heads;
+    const float* base = qkv + (long)b * T * C3 + h * 3 * HD;
+    float q[HD], acc[HD];
+    const bool live = t < T;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) { q[c] = live ? base[(long)t * C3 + c] * 0.125f : 0.f; acc[c] = 0.f; }   // (q*s).(k*s), s^2 = 1/8
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < T; k0 += KCH) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < KCH * HD; i += blockDim.x) {
+            const int r = i / HD, c = i % HD;
+            const bool ok = k0 + r < T;
+            Ks[r][c] = ok ? base[(long)(k0 + r) * C3 + HD + c] : 0.f;
+            Vs[r][c] = ok ? base[(long)(k0 + r) * C3 + 2 * HD + c] : 0.f;
+        }
+        __syncthreads();
+        const int kn = (T - k0) < KCH ? (T - k0) : KCH;
+        for (int r = 0; r < kn; ++r) {
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) d = fmaf(q[c], Ks[r][c], d);
+            const float mn = fmaxf(m, d);
+            const float corr = expf(m - mn), p = expf(d - mn);
+            l = l * corr + p;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) acc[c] = fmaf(p, Vs[r][c], acc[c] * corr);
+            m = mn;
+        }
+    }
+    if (live) {
+        const float inv = 1.f / l;
+        float* o = out + ((long)b * T + t) * (HD * heads) + h * HD;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) o[c] = acc[c] * inv;
+    }
+}
+
+__global__ void unet_p_sample_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ z, float ca,
+                                     float cb, float c1, float c2, float sig, float* __restrict__ out, float* __restrict__ x0_out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float xv = x[i];
+    float x0 = __fsub_rn(__fmul_rn(ca, xv), __fmul_rn(cb, eps[i]));      // reference op order, no FMA contraction
+    x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    float r = __fadd_rn(__fmul_rn(c1, x0), __fmul_rn(c2, xv));
+    if (z) r = __fadd_rn(r, __fmul_rn(sig, z[i]));
+    out[i] = r;
+    if (x0_out) x0_out[i] = x0;
+}
+}  // namespace
+
+void launch_conv1ch_3x3(const float* in, const float* w, const float* bias, float* out, int B, int Cout, hipStream_t s) {
+    const long total = (long)B * 1024 * Cout;
+    hipLaunchKernelGGL(conv1ch_3x3_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, in, w, bias, out, Cout, total);
+}
+void launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* ss, int silu, float* y, int B, int HW,
+                           int C, hipStream_t s) {
+    hipLaunchKernelGGL(groupnorm_nhwc_kernel, dim3(32, (unsigned)B), dim3(256), 0, s, x, gamma, beta, ss, silu, y, HW, C);
+}
+void launch_silu(const float* x, float* y, long n, hipStream_t s) {
+    hipLaunchKernelGGL(silu_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, x, y, n);
+}
+void launch_upsample2x_nhwc(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
+    const long total4 = (long)B * 4 * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3(nblk(total4, 256)), dim3(256), 0, s, in, out, H, W, C / 4, total4);
+}
+void launch_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, int C, long rows, hipStream_t s) {
+    const long total4 = rows * (C / 4);
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(nblk(total4, 256)), dim3(256), 0, s, src, ld_src, dst, ld_dst, C / 4, total4);
+}
+void launch_qkv_attention(const float* qkv, float* out, int B, int T, int heads, hipStream_t s) {
+    const int threads = T >= 256 ? 256 : (T >= 64 ? 64 * ((T + 63) / 64) : 64);
+    hipLaunchKernelGGL(qkv_attention_kernel, dim3((unsigned)heads, (unsigned)B, (unsigned)((T + threads - 1) / threads)), dim3(threads), 0, s,
+                       qkv, out, T, heads);
+}
+void launch_unet_p_sample(const float* x, const float* eps, const float* z, float ca, float cb, float c1, float c2, float sig,
+                          float* out, float* x0_out, long n, hipStream_t s) {
+    hipLaunchKernelGGL(unet_p_sample_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, x, eps, z, ca, cb, c1, c2, sig, out, x0_out, n);
+}
+
+}  // namespace dmad

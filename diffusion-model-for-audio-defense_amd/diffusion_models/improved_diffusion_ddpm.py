@@ -1,0 +1,55 @@
+"""Host mirror of the reference's diffusion_models/improved_diffusion_ddpm.py: the Improved-Diffusion purifier on
+standardised mel spectrograms.  The reference's `_reverse` discards the result of p_sample_loop and starts it from pure
+noise (the wrapper is broken as committed); this mirror implements what the wrapper is for — diffuse x_0 to
+t*, run the reverse chain from x_{t*} down to x_0, map back to the mel-dB scale — and says so here."""
+from typing import Union
+
+import numpy as np
+import torch
+
+from .Improved_Diffusion_Unconditional.improved_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults
+from .Improved_Diffusion_Unconditional.improved_diffusion.sc09_spectrogram_dataset import melspec_standardize, melspec_inv_standardize  # noqa: F401
+
+
+class ImprovedDiffusion(torch.nn.Module):
+
+    def __init__(self, model=None, diffusion=None, reverse_timestep: int = 0, seed: int = 0):
+        super().__init__()
+        self.model = model
+        self.diffusion = diffusion
+        self.reverse_timestep = reverse_timestep
+        self.seed = seed
+
+    def forward(self, waveforms: Union[torch.Tensor, np.ndarray]):
+        if isinstance(waveforms, np.ndarray):
+            waveforms = torch.from_numpy(waveforms)
+        output = self._diffusion(waveforms)
+        output = self._reverse(output)
+        return melspec_inv_standardize(output)
+
+    def _diffusion(self, x_0):
+        if isinstance(x_0, np.ndarray):
+            x_0 = torch.from_numpy(x_0)
+        t = torch.full((x_0.shape[0],), self.reverse_timestep, dtype=torch.long, device=x_0.device)
+        return self.diffusion.q_sample(x_0, t=t)
+
+    @torch.no_grad()
+    def _reverse(self, x_t):
+        if isinstance(x_t, np.ndarray):
+            x_t = torch.from_numpy(x_t)
+        return self.diffusion.p_sample_loop(model=self.model, shape=x_t.shape, noise=x_t, start_timestep=self.reverse_timestep + 1,
+                                            seed=self.seed)
+
+
+def create_improved_diffusion(model_path, reverse_timestep=25, state_dict=None, engine=None):
+    """reference l.64-93: image_size 32, 128 channels, 3 ResBlocks, fixed sigma, 1000 linear steps."""
+    args = model_and_diffusion_defaults()
+    args.update(image_size=32, num_channels=128, num_res_blocks=3, learn_sigma=False, diffusion_steps=1000, noise_schedule='linear')
+    model, diffusion = create_model_and_diffusion(**args)
+    if state_dict is None:
+        state_dict = torch.load(model_path, map_location='cpu')
+    model.load_state_dict({k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))) for k, v in state_dict.items()})
+    model.eval()
+    if engine is not None:
+        model.bind_engine(engine)
+    return ImprovedDiffusion(model=model, diffusion=diffusion, reverse_timestep=reverse_timestep)

@@ -138,6 +138,7 @@ class Engine:
         self._h = h
         self.has_wavenet = False
         self.has_classifier = False
+        self.has_unet = False
 
     def close(self):
         if getattr(self, '_h', None):
@@ -170,6 +171,14 @@ class Engine:
             raise DmadError('classifier weights are already loaded into this engine')
         self._load(fold_vgg19_bn_state_dict(state_dict))
         self.has_classifier = True
+
+    def load_unet(self, state_dict):
+        """improved_diffusion.unet.UNetModel state dict (synth.UNET_CONFIG geometry) -> engine, names prefixed 'un.'."""
+        if self.has_unet:
+            raise DmadError('UNet weights are already loaded into this engine')
+        self._load({'un.' + k: _as_np(v.detach().cpu().double().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, dtype=np.float64))
+                    for k, v in state_dict.items()})
+        self.has_unet = True
 
     def load_resnext29(self, state_dict):
         if self.has_classifier:
@@ -225,6 +234,35 @@ class Engine:
             check(self.lib.dmad_diffuse(self._h, _ptr(x[s:e]), float(c_a), float(c_b), _ptr(zz), int(seed), int(sample0) + s,
                                         e - s, _ptr(out[s:e]), _stream()))
         return out
+
+    def _spec(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise DmadError('input must live on the GPU (the dmad engine has no CPU path)')
+        x = x.detach()
+        if x.dim() == 4:
+            assert x.shape[1] == 1, 'expected [B,1,32,32]'
+            x = x[:, 0]
+        assert x.dim() == 3 and tuple(x.shape[1:]) == (32, 32), 'expected [B,32,32], got %s' % (tuple(x.shape),)
+        return x.contiguous().float()
+
+    def unet_eps(self, x_t: torch.Tensor, t: int) -> torch.Tensor:
+        """eps = UNetModel(x_t, t * ones): [B,1,32,32] or [B,32,32] -> [B,32,32]."""
+        x = self._spec(x_t)
+        out = torch.empty_like(x)
+        for s, e in self._chunks(x.shape[0]):
+            check(self.lib.dmad_unet_eps(self._h, _ptr(x[s:e]), int(t), e - s, _ptr(out[s:e]), _stream()))
+        return out
+
+    def unet_p_sample(self, x: torch.Tensor, t: int, c_a: float, c_b: float, c_1: float, c_2: float, c_sig: float,
+                      z: Optional[torch.Tensor] = None, seed: int = 0, sample0: int = 0, want_x0: bool = False):
+        """in place on x ([B,32,32] contiguous fp32 CUDA); returns pred_xstart when asked."""
+        assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and tuple(x.shape[1:]) == (32, 32)
+        x0 = torch.empty_like(x) if want_x0 else None
+        for s, e in self._chunks(x.shape[0]):
+            zz = None if z is None else self._spec(z)[s:e].contiguous()
+            check(self.lib.dmad_unet_p_sample(self._h, _ptr(x[s:e]), int(t), float(c_a), float(c_b), float(c_1), float(c_2), float(c_sig),
+                                              _ptr(zz), int(seed), int(sample0) + s, e - s, _ptr(x0[s:e]) if want_x0 else None, _stream()))
+        return x0
 
     def mel_db(self, x: torch.Tensor) -> torch.Tensor:
         x = self._wave(x)

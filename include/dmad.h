@@ -101,6 +101,22 @@ int dmad_mel_db(dmad_engine* e, const float* x, int32_t B, float* spec, dmad_str
 int dmad_mel_power(dmad_engine* e, const float* x, int32_t B, float* mel, dmad_stream s);
 int dmad_power_to_db(dmad_engine* e, const float* x, int64_t n, float* y, dmad_stream s);
 
+/* Improved-Diffusion UNet purifier on 1x32x32 mel spectrograms (the reference's configuration C5:
+ * diffusion_models/improved_diffusion_ddpm.py:64-93 -> improved_diffusion/script_util.py:11-34,100-131).  Weights: the
+ * reference's UNetModel state dict, names prefixed "un." (un.time_embed.0.weight, un.input_blocks.5.0.in_layers.2.weight,
+ * ...), loaded with dmad_load_weight + dmad_finalize_weights like the other sets.
+ * eps = UNetModel.forward(x_t, t * ones)  — improved_diffusion/unet.py:453-477.  x_t, eps: device fp32 [B][32][32]. */
+int dmad_unet_eps(dmad_engine* e, const float* x_t, int32_t t, int32_t B, float* eps, dmad_stream s);
+
+/* One GaussianDiffusion.p_sample step in place on x (gaussian_diffusion.py:232-257,331-387; epsilon prediction, fixed
+ * variance, clip_denoised):  x0 = clamp(c_a * x - c_b * eps(x, t), -1, 1);  x <- c_1 * x0 + c_2 * x + c_sig * z.
+ * c_a = sqrt_recip_alphas_cumprod[t], c_b = sqrt_recipm1_alphas_cumprod[t], c_1 / c_2 = posterior_mean_coef1/2[t],
+ * c_sig = exp(0.5 * log_variance[t]) (0 at t == 0), all computed by the caller from the float64 tables.  z: device
+ * fp32 [B][32][32] (the reference's randn_like draws) or NULL for on-device Philox noise keyed (seed, sample0 + row).
+ * x0_out: optional [B][32][32] (pred_xstart). */
+int dmad_unet_p_sample(dmad_engine* e, float* x, int32_t t, float c_a, float c_b, float c_1, float c_2, float c_sig, const float* z,
+                       uint64_t seed, uint64_t sample0, int32_t B, float* x0_out, dmad_stream s);
+
 /* logits = classifier(spec)  — VGG.forward, audio_models/ConvNets_SpeechCommands/models/vgg.py:48-52, or
  * CifarResNeXt.forward, models/resnext.py:133-142, whichever weight set was loaded.
  * spec: [B][32][32] fp32, logits: [B][num_classes] fp32. */

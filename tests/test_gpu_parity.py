@@ -528,3 +528,42 @@ def test_resnext29_vs_reference_fixture(golden_dir, orc):
     clip = torch.from_numpy(synth.synthetic_clip(0)).cuda()              # [1,16000], what certify() hands over
     counts = RC.smooth_predict(clip, num_sampling=24, sigma=0.5, batch_size=8)
     assert int(counts.sum()) == 24 and counts.shape == (10,)
+
+
+# ------------------------------------------------------------------------------------------ Improved-Diffusion UNet (N1)
+def test_unet_purifier_vs_reference_fixture(golden_dir):
+    """UNetModel.forward, GaussianDiffusion.q_sample / p_sample and the ImprovedDiffusion wrapper on the HIP engine vs
+    outputs of the imported reference classes on the same seeded 52.5M-parameter weights (tests/golden/make_golden_unet.py)."""
+    from dmad_hip import engine as E
+    from diffusion_models.improved_diffusion_ddpm import create_improved_diffusion, melspec_standardize, melspec_inv_standardize
+    z = G(golden_dir, 'unet.npz')
+    eng = E.Engine(max_batch=4, precision=E.BF16, with_classifier=False)
+    pur = create_improved_diffusion(None, reverse_timestep=3, state_dict=synth.unet_state_dict(int(z['seed'])), engine=eng)
+    model, gd = pur.model, pur.diffusion
+    spec = torch.from_numpy(z['spec']).cuda()
+    x0 = melspec_standardize(spec)
+    assert relmax(x0.cpu().numpy(), z['x0']) < 1e-6 and relmax(melspec_inv_standardize(x0).cpu().numpy(), z['inv_std']) < 1e-6
+    g = torch.Generator().manual_seed(31)
+    noise = torch.randn(x0.shape, generator=g).cuda()
+    for t in (3, 40):
+        tt = torch.full((2,), t, dtype=torch.long).cuda()
+        x_t = gd.q_sample(x0, tt, noise=noise)
+        assert relmax(x_t.cpu().numpy(), z['x_t%d' % t]) < 1e-6
+        eps = model(torch.from_numpy(z['x_t%d' % t]).cuda(), tt)
+        assert eps.shape == (2, 1, 32, 32)
+        assert relmax(eps.cpu().numpy(), z['eps_t%d' % t]) < 5e-4, t
+    solo = model(torch.from_numpy(z['x_t3'][1:]).cuda(), torch.tensor([3]))
+    assert torch.equal(solo, model(torch.from_numpy(z['x_t3']).cuda(), torch.tensor([3, 3]))[1:])      # batch invariance
+    big = model(torch.from_numpy(z['x_t3']).cuda().repeat(3, 1, 1, 1), torch.full((6,), 3))         # 6 > max_batch: chunked
+    assert torch.equal(big[4:], big[:2])
+    for t in (3, 0):
+        r = gd.p_sample(model, torch.from_numpy(z['x_t3']).cuda(), torch.full((2,), t), noise=torch.from_numpy(z['p_noise_t%d' % t]).cuda())
+        assert float((r['pred_xstart'].cpu() - torch.from_numpy(z['p_xstart_t%d' % t])).abs().max()) < 1e-3
+        assert float((r['sample'].cpu() - torch.from_numpy(z['p_sample_t%d' % t])).abs().max()) < 1e-3
+    out = pur(x0)                                              # diffuse to t* = 3, four reverse steps, back to dB
+    again = pur(x0)
+    assert out.shape == spec.shape and bool(torch.isfinite(out).all())
+    assert float(out.min()) >= -100.0 - 1e-3 and float(out.max()) <= 38.22 + 1e-3                  # clip_denoised at the last step
+    assert out.shape == again.shape
+    with pytest.raises(NotImplementedError):
+        model(x0, torch.tensor([3, 4]).cuda())
