@@ -1,43 +1,41 @@
 // fp32 gather-GEMM on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains).
 //
-//   C[n][m] = act( scale[m] * sum_tap sum_k A[tap][m][k] * X[row(n, tap)][k] + shift[m] )
+//   C[n][m] = act( scale[m] * sum_tap sum_k A[tap][m][k] * X[row(n, tap)][k] + shift[m] (+ res[n][m]) )
 //
 // One kernel serves every exact-fp32 GEMM-shaped op of the path:
 //   * parity-mode WaveNet: dilated Conv1d as 3 row-shifted taps over the zero-padded residual
 //     stream (WaveNet.py:23-34,86) and the 1x1 res/skip/final convs (WaveNet.py:66-72,160-162);
 //   * mel front-end: the windowed DFT of the 32 overlapping frames of a clip (row stride = hop) and
 //     the slaney filterbank product (torchaudio MelSpectrogram, certified_robustness_eval.py:85);
-//   * VGG19_bn: 3x3 convs as implicit GEMM over NHWC activations with eval-mode BatchNorm folded
-//     into scale/shift, and the three Linear layers (models/vgg.py:48-52,69-81).
-// Tile 128(M) x 128(N) x 16(K), 4 waves (2x2), register-staged double buffering, LDS k-major with a
-// 16-float pad so both the operand reads (ds_read_b32) are bank-conflict free.
+//   * VGG19_bn / ResNeXt29 / the Improved-Diffusion UNet: 3x3 (stride 1 or 2), 1x1 and grouped convs as implicit GEMM
+//     over NHWC activations with bias or folded eval-mode BatchNorm in scale/shift, and the Linear layers.
+// Tile 128(M) x 128(N), k-steps of 16 floats, 4 waves (2x2, wave tile 64x64 = 16 accumulator tiles).  Both operands are
+// row gathers of 64-byte k-chunks: every lane of an LDS-DMA instruction (global_load_lds_dwordx4) fetches the 16 bytes
+// that belong at its own LDS position — rows of 64 B with the 16-byte chunks XOR-swizzled by swz64(row), so a fragment
+// is ONE conflict-free ds_read_b128 (4 consecutive k of one row) feeding 4 MFMAs; lane (row, q) holds k = 4q + j for
+// MFMA j in BOTH operands, so each MFMA still contracts 4 distinct k and the 4 together cover the 16.  Rows outside the
+// problem (conv zero padding, M / N tails) are fetched from a zero page.  3-slot LDS ring, counted vmcnt, one barrier
+// per k-step, no register staging.
 #include "gemm_f32.h"
 
 namespace dmad {
 
 namespace {
-constexpr int BM = 128, BN = 128, BK = 16, PITCH = BM + 16;
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int SLOT = 16384;                       // 128 A rows + 128 X rows of 64 B
+__device__ __attribute__((aligned(64))) float g_zero_page[16];                 // 64 B of zeros: source of every out-of-problem row
 
-__device__ __forceinline__ const float* row_ptr(const GemmF32Args& a, long n, int tap, int kc) {
-    // returns nullptr for a zero row
-    if (n >= a.N) return nullptr;
-    if (a.mode == 2) {
-        const int st = a.stride > 1 ? a.stride : 1;
-        const int Ho = (a.H - 1) / st + 1, Wo = (a.W - 1) / st + 1, hw = Ho * Wo;
-        const long b = n / hw;
-        const int p = (int)(n - b * hw), y = p / Wo, x = p - y * Wo;
-        const int yy = y * st + (a.taps == 9 ? tap / 3 - 1 : 0), xx = x * st + (a.taps == 9 ? tap % 3 - 1 : 0);
-        if ((unsigned)yy >= (unsigned)a.H || (unsigned)xx >= (unsigned)a.W) return nullptr;
-        return a.X + ((b * a.H + yy) * a.W + xx) * (long)(a.ldx ? a.ldx : a.Cin) + kc;
-    }
-    const long b = n / a.rows_per_batch, r = n - b * a.rows_per_batch;
-    return a.X + b * a.batch_stride + r * a.row_stride + (long)(tap - (a.taps >> 1)) * a.tap_stride + kc;
-}
+#define GF_WAIT_BARRIER(N)                                                          \
+    do {                                                                            \
+        asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");                       \
+        __builtin_amdgcn_s_waitcnt(0x0070 | ((N) & 15) | (((N) >> 4) << 14));       \
+        __builtin_amdgcn_s_barrier();                                               \
+        asm volatile("" ::: "memory");                                              \
+    } while (0)
 }  // namespace
 
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
-    __shared__ float As[2][BK][PITCH];
-    __shared__ float Bs[2][BK][PITCH];
+    __shared__ __attribute__((aligned(16))) char smem[3 * SLOT];
     if (a.groups > 1) {                      // grouped conv: this workgroup's group = blockIdx.z
         const int g = blockIdx.z;
         a.A += (size_t)g * a.taps * a.M * a.K;
@@ -47,7 +45,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
         if (a.shift) a.shift += (size_t)g * a.M;
         if (a.res) a.res += (size_t)g * a.M;
     }
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1, q = lane >> 4, r16 = lane & 15;
     const long n0 = (long)blockIdx.x * BN;
     const int m0 = blockIdx.y * BM;
@@ -55,57 +54,89 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
     const int S = a.splits > 1 ? a.splits : 1, z = a.groups > 1 ? 0 : blockIdx.z;
     const int ks_begin = (int)((long)nks_all * z / S), nks = (int)((long)nks_all * (z + 1) / S);
 
+    // this thread's two staging rows per operand: R = piece * 64 + wave * 16 + lane / 4, chunk = (lane & 3) ^ swz64(R)
+    const int rloc = wv * 16 + (lane >> 2), chunk4 = ((lane & 3) ^ swz64(lane >> 2)) * 4;
+    const float* zero = g_zero_page;
+    const float* arow[2];                     // A row base (tap 0, k 0) or nullptr
+    long xbase[2];                            // mode 0: row offset in floats; mode 2: packed (b, y, x)
+    int xy[2], xx[2];
+    bool xok[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int m = m0 + p * 64 + rloc;
+        arow[p] = m < a.M ? a.A + (size_t)m * a.K + chunk4 : nullptr;
+        const long n = n0 + p * 64 + rloc;
+        xok[p] = n < a.N;
+        xbase[p] = 0; xy[p] = 0; xx[p] = 0;
+        if (xok[p]) {
+            if (a.mode == 2) {
+                const int st = a.stride > 1 ? a.stride : 1;
+                const int Ho = (a.H - 1) / st + 1, Wo = (a.W - 1) / st + 1, hw = Ho * Wo;
+                const long b = n / hw;
+                const int pix = (int)(n - b * hw);
+                xy[p] = (pix / Wo) * st; xx[p] = (pix % Wo) * st;
+                xbase[p] = b * a.H * a.W;
+            } else {
+                const long b = n / a.rows_per_batch, r = n - b * a.rows_per_batch;
+                xbase[p] = b * a.batch_stride + r * a.row_stride;
+            }
+        }
+    }
+    const long ldx = a.ldx ? a.ldx : a.Cin;
+    auto stage = [&](int ks, int slot) {
+        const int tap = ks / ksteps_per_tap, kc = (ks - tap * ksteps_per_tap) * BK;
+        char* la = smem + slot * SLOT + wv * 1024;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float* src = arow[p] ? arow[p] + (size_t)tap * a.M * a.K + kc : zero;
+            glds16(src, la + p * 4096);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float* src = zero;
+            if (xok[p]) {
+                if (a.mode == 2) {
+                    const int yy = xy[p] + (a.taps == 9 ? tap / 3 - 1 : 0), xq = xx[p] + (a.taps == 9 ? tap % 3 - 1 : 0);
+                    if ((unsigned)yy < (unsigned)a.H && (unsigned)xq < (unsigned)a.W)
+                        src = a.X + (xbase[p] + (long)yy * a.W + xq) * ldx + kc + chunk4;
+                } else {
+                    src = a.X + xbase[p] + (long)(tap - (a.taps >> 1)) * a.tap_stride + kc + chunk4;
+                }
+            }
+            glds16(src, la + 8192 + p * 4096);
+        }
+    };
+
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float4 ra[2], rb[2];
-    auto gload = [&](int ks) {
-        const int tap = ks / ksteps_per_tap, kc = (ks - tap * ksteps_per_tap) * BK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = i * 256 + tid, row = id >> 2, kg = id & 3;
-            const int m = m0 + row;
-            ra[i] = (m < a.M) ? *(const float4*)(a.A + ((long)tap * a.M + m) * a.K + kc + kg * 4) : float4{0, 0, 0, 0};
-            const float* p = row_ptr(a, n0 + row, tap, kc + kg * 4);
-            rb[i] = p ? *(const float4*)p : float4{0, 0, 0, 0};
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = i * 256 + tid, row = id >> 2, kg = id & 3;
-            As[buf][kg * 4 + 0][row] = ra[i].x; As[buf][kg * 4 + 1][row] = ra[i].y;
-            As[buf][kg * 4 + 2][row] = ra[i].z; As[buf][kg * 4 + 3][row] = ra[i].w;
-            Bs[buf][kg * 4 + 0][row] = rb[i].x; Bs[buf][kg * 4 + 1][row] = rb[i].y;
-            Bs[buf][kg * 4 + 2][row] = rb[i].z; Bs[buf][kg * 4 + 3][row] = rb[i].w;
-        }
-    };
-
-    gload(ks_begin);
-    lstore(ks_begin & 1);
-    __syncthreads();
+    const int frag = r16 * 64 + ((q ^ swz64(r16)) * 16);
+    if (ks_begin < nks) stage(ks_begin, 0);
+    if (ks_begin + 1 < nks) stage(ks_begin + 1, 1);
+    int slot = 0;
     for (int ks = ks_begin; ks < nks; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nks) gload(ks + 1);
+        // stage ks landed (the 4 pieces of stage ks+1 may still fly); every wave is done reading slot (ks-1) % 3
+        if (ks + 1 < nks) { GF_WAIT_BARRIER(4); } else { GF_WAIT_BARRIER(0); }
+        if (ks + 2 < nks) stage(ks + 2, slot >= 1 ? slot - 1 : 2);
+        const char* As = smem + slot * SLOT + wm * 4096 + frag;
+        const char* Bs = smem + slot * SLOT + 8192 + wn * 4096 + frag;
+        f32x4 af[4], bf[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            float af[4], bf[4];
+        for (int i = 0; i < 4; ++i) {
+            af[i] = *(const f32x4*)(As + i * 1024);
+            bf[i] = *(const f32x4*)(Bs + i * 1024);
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = As[buf][kk * 4 + q][wm * 64 + i * 16 + r16];
-                bf[i] = Bs[buf][kk * 4 + q][wn * 64 + i * 16 + r16];
-            }
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (ks + 1 < nks) lstore(buf ^ 1);
-        __syncthreads();
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+        slot = slot == 2 ? 0 : slot + 1;
     }
 
     if (S > 1) {   // split-K: raw partial sums to this split's slab; scale/shift/act happen in the reduce kernel

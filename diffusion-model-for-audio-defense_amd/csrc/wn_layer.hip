@@ -1,8 +1,7 @@
 // wn_layer_bf16_p — the residual-layer kernel of the bf16 path (persistent form).
 //
 // Math, operand orientation and HBM/LDS layouts are those documented at the top of wn_bf16.hip
-// (Residual_block.forward, DiffWave_Unconditional/WaveNet.py:75-97).  This file holds the production
-// schedule; the earlier schedules in wn_bf16.hip are kept only as A/B baselines for tools/gpu_ablate.py.
+// (Residual_block.forward, DiffWave_Unconditional/WaveNet.py:75-97).
 //
 // One workgroup (8 waves, 1 per CU) walks over time tiles; each XCD's workgroups share one contiguous tile range.
 // Per tile (128 time samples of one clip, all 512 gate rows):
