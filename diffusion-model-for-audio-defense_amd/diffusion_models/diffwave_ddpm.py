@@ -86,7 +86,9 @@ class DiffWave(torch.nn.Module):
     # -- reference API ---------------------------------------------------------------------------
     def forward(self, waveforms: Union[torch.Tensor, np.ndarray]):
         waveforms = self._to_tensor(waveforms)
-        output = self._diffusion(waveforms)
+        base = self._draws                    # device noise: row i of this call is sample base + i in BOTH phases
+        output = self._diffusion(waveforms)   # (different Philox streams), so a clip's purification does not depend on
+        self._draws = base                    # the batch it is in
         output = self._reverse(output)
         return output
 

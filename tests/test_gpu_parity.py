@@ -567,3 +567,87 @@ def test_unet_purifier_vs_reference_fixture(golden_dir):
     assert out.shape == again.shape
     with pytest.raises(NotImplementedError):
         model(x0, torch.tensor([3, 4]).cuda())
+
+
+# ------------------------------------------------------------------------------------------ BASELINE.json configs at full size
+@pytest.fixture(scope='module')
+def big_engine(weights):
+    from dmad_hip import engine as E
+    eng = E.Engine(max_batch=256, precision=E.BF16)
+    eng.load_wavenet(weights[0])
+    eng.load_vgg19_bn(weights[1])
+    yield eng
+    eng.close()
+
+
+def test_config2_ddpm_batch256_vgg(big_engine):
+    """BASELINE config 2 — DiffWave DDPM t* = 5, batch 256, VGG19_bn forward, bf16 — through AcousticSystem, checked by
+    size-independent properties: a row of the batch equals the same clip run alone with the same noise key, the
+    result does not depend on the engine's chunking, repeats with the same seed are identical."""
+    from acoustic_system import AcousticSystem
+    from audio_models.ConvNets_SpeechCommands.models.vgg import vgg19_bn
+    from diffusion_models.diffwave_ddpm import DiffWave, WaveNetHIP
+    from diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    from dmad_hip.transforms import MelSpectrogramDB
+    eng = big_engine
+    hp = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    net = vgg19_bn(num_classes=10, in_channels=1)
+    net.eval().bind_engine(eng)
+    den = DiffWave(WaveNetHIP(eng), hp, reverse_timestep=5, seed=123)
+    model = AcousticSystem(classifier=net, transform=MelSpectrogramDB(eng), defender=den, defense_type='wave')
+    x = torch.from_numpy(np.stack([synth.synthetic_clip(i % 10) for i in range(256)])).cuda()       # [256,1,16000]
+    den._draws = 0
+    logits = model(x)
+    assert logits.shape == (256, 10) and bool(torch.isfinite(logits).all())
+    den._draws = 0
+    assert torch.equal(model(x), logits)                                       # same seed, same sample counters
+    for i in (0, 97, 255):                                                     # row i alone, noise keyed by sample index i
+        den._draws = i
+        assert torch.equal(model(x[i:i + 1]), logits[i:i + 1]), i
+    den._draws = 0
+    pur = den(x)                                                               # the purified waveforms themselves
+    assert pur.shape == (256, 1, 16000) and float(pur.abs().max()) < 50.0
+    den._draws = 128
+    assert torch.equal(den(x[128:]), pur[128:])                                # second half alone == second half of the batch
+    assert torch.equal(model(x, defend=False), net(MelSpectrogramDB(eng)(x)))  # defend=False bypasses the purifier
+
+
+def test_config3_certify_n1000(big_engine):
+    """BASELINE config 3 — certified smoothing N = 1000, sigma = 0.5, DiffWave + VGG19_bn: vote conservation, the shard
+    property (counts of [0, N) = sum of the counts of any partition of the sample range, which is what the
+    multi-GPU path relies on), independence of the batch size, and certify()'s contract on top of the counts."""
+    from audio_models.ConvNets_SpeechCommands.models.vgg import vgg19_bn
+    from diffusion_models.diffwave_ddpm import DiffWave, WaveNetHIP
+    from diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    from dmad_hip.transforms import MelSpectrogramDB
+    from robustness_eval.certified_robust import RobustCertificate
+    from scipy.stats import beta, norm
+    eng = big_engine
+    hp = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    ab = hp['Alpha_bar']
+    t = int(torch.abs(ab - 1 / 1.25).min(0, keepdim=True)[1].item())
+    assert t + 1 == 66                                                         # sigma = 0.5 -> t* = 66
+    ca, cb = float((1 / ab).sqrt()[t]), float((1 / ab - 1).sqrt()[t])
+    sc = float(torch.tensor((1 / 1.25) ** 0.5))
+    clip = torch.from_numpy(synth.synthetic_clip(4)).cuda()
+    whole, _, _ = eng.smooth_votes(clip, 0.5, sc, t, ca, cb, 1000, seed=77, sample0=0)
+    assert int(whole.sum()) == 1000
+    parts = torch.zeros_like(whole)
+    for lo, hi, b in ((0, 125, 125), (125, 500, 256), (500, 1000, 64)):        # uneven "ranks", different batch sizes
+        c, _, _ = eng.smooth_votes(clip, 0.5, sc, t, ca, cb, hi - lo, batch=b, seed=77, sample0=lo)
+        parts += c
+    assert torch.equal(whole, parts)
+    net = vgg19_bn(num_classes=10, in_channels=1)
+    net.eval().bind_engine(eng)
+    RC = RobustCertificate(classifier=net, transform=MelSpectrogramDB(eng), denoiser=DiffWave(WaveNetHIP(eng), hp), seed=5)
+    assert RC._fused()
+    y_pred, radius = RC.certify(clip[None], torch.tensor([0]).cuda(), sigma=0.5, n_0=100, n=1000, batch_size=256)
+    RC2 = RobustCertificate(classifier=net, transform=MelSpectrogramDB(eng), denoiser=DiffWave(WaveNetHIP(eng), hp), seed=5)
+    c0 = RC2.smooth_predict(clip, num_sampling=100, sigma=0.5, batch_size=50)
+    c1 = RC2.smooth_predict(clip, num_sampling=1000, sigma=0.5, batch_size=100)
+    cA = int(c0.argmax())
+    pa = float(beta.ppf(0.001, int(c1[cA]), 1000 - int(c1[cA]) + 1)) if int(c1[cA]) > 0 else 0.0
+    if pa > 0.5:
+        assert int(y_pred[0]) == cA and abs(float(radius[0]) - 0.5 * norm.ppf(pa)) < 1e-5
+    else:
+        assert int(y_pred[0]) == -1 and float(radius[0]) == 0.0
