@@ -83,6 +83,8 @@ def main():
     ap.add_argument('--sigma', type=float, default=0.5)
     ap.add_argument('--cpu-samples', type=int, default=6)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--classifier', choices=['vgg19_bn', 'resnext29'], default='vgg19_bn',
+                    help='vgg19_bn = the configuration BASELINE.json names; resnext29 = the reference script\'s default classifier')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -102,7 +104,10 @@ def main():
     from diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
     eng = E.Engine(max_batch=args.max_batch, precision=E.BF16)
     eng.load_wavenet(synth.wavenet_state_dict(1234))
-    eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321))
+    if args.classifier == 'resnext29':
+        eng.load_resnext29(synth.resnext29_state_dict(2929))
+    else:
+        eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321))
     hp = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
     ab = hp['Alpha_bar']
     sigma = args.sigma
@@ -159,10 +164,10 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "certified smoothing N=100000 sigma=%.2f (t*=%d): DiffWave one-shot purify (36x256 WaveNet) "
-                                   "+ mel-dB + VGG19_bn + votes; step = %d Monte Carlo samples per GPU, %d steps = one "
-                                   "N=100000 clip" % (sigma, t + 1, S, -(-100000 // S)),
+                                   "+ mel-dB + %s + votes; step = %d Monte Carlo samples per GPU, %d steps = one "
+                                   "N=100000 clip" % (sigma, t + 1, 'VGG19_bn' if args.classifier == 'vgg19_bn' else 'ResNeXt29', S, -(-100000 // S)),
                        "samples_per_step_per_gpu": S, "engine_batch": args.max_batch, "sigma": sigma, "t_star": t + 1,
-                       "noise": "device Philox4x32-10", "classifier": "VGG19_bn (synthetic seed 4321)",
+                       "noise": "device Philox4x32-10", "classifier": "VGG19_bn (synthetic seed 4321)" if args.classifier == 'vgg19_bn' else "ResNeXt29 8x64d (synthetic seed 2929)",
                        "parallelism": "mc-samples sharded x%d, one int64[10] all-reduce per step" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS,
@@ -174,7 +179,7 @@ def main():
             "end_to_end_tflops": clips / dt / world * 606.94e9 / 1e12,
             "votes": votes,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.classifier == 'vgg19_bn':
             out["cpu_baseline"] = cpu_baseline(args.cpu_samples)
         print(json.dumps(out), flush=True)
     eng.close()
