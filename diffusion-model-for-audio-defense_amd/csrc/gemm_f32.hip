@@ -9,7 +9,8 @@
 //     the slaney filterbank product (torchaudio MelSpectrogram, certified_robustness_eval.py:85);
 //   * VGG19_bn / ResNeXt29 / the Improved-Diffusion UNet: 3x3 (stride 1 or 2), 1x1 and grouped convs as implicit GEMM
 //     over NHWC activations with bias or folded eval-mode BatchNorm in scale/shift, and the Linear layers.
-// Tile 128(M) x 128(N), k-steps of 16 floats, 4 waves (2x2, wave tile 64x64 = 16 accumulator tiles).  Both operands are
+// Tile 128(M) x 128(N) — 64(M) x 128(N) for layers / conv groups with at most 64 output channels —, k-steps of 16 floats,
+// 4 waves (2x2, wave tile 64x64 = 16 accumulator tiles).  Both operands are
 // row gathers of 64-byte k-chunks: every lane of an LDS-DMA instruction (global_load_lds_dwordx4) fetches the 16 bytes
 // that belong at its own LDS position — rows of 64 B with the 16-byte chunks XOR-swizzled by swz64(row), so a fragment
 // is ONE conflict-free ds_read_b128 (4 consecutive k of one row) feeding 4 MFMAs; lane (row, q) holds k = 4q + j for
@@ -21,7 +22,7 @@
 namespace dmad {
 
 namespace {
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BN = 128, BK = 16;          // BM = 128, or 64 for layers / conv groups with at most 64 output channels
 constexpr int SLOT = 16384;                       // 128 A rows + 128 X rows of 64 B
 __device__ __attribute__((aligned(64))) float g_zero_page[16];                 // 64 B of zeros: source of every out-of-problem row
 
@@ -34,7 +35,9 @@ __device__ __attribute__((aligned(64))) float g_zero_page[16];                 /
     } while (0)
 }  // namespace
 
+template <int BM>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
+    constexpr int MT = BM / 32;            // 16-row accumulator tiles per wave along M (2 M-waves)
     __shared__ __attribute__((aligned(16))) char smem[3 * SLOT];
     if (a.groups > 1) {                      // grouped conv: this workgroup's group = blockIdx.z
         const int g = blockIdx.z;
@@ -64,7 +67,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int m = m0 + p * 64 + rloc;
-        arow[p] = m < a.M ? a.A + (size_t)m * a.K + chunk4 : nullptr;
+        arow[p] = (p * 64 < BM && m < a.M) ? a.A + (size_t)m * a.K + chunk4 : nullptr;
         const long n = n0 + p * 64 + rloc;
         xok[p] = n < a.N;
         xbase[p] = 0; xy[p] = 0; xx[p] = 0;
@@ -87,7 +90,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
         const int tap = ks / ksteps_per_tap, kc = (ks - tap * ksteps_per_tap) * BK;
         char* la = smem + slot * SLOT + wv * 1024;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < BM / 64; ++p) {
             const float* src = arow[p] ? arow[p] + (size_t)tap * a.M * a.K + kc : zero;
             glds16(src, la + p * 4096);
         }
@@ -107,9 +110,9 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -119,20 +122,20 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
     int slot = 0;
     for (int ks = ks_begin; ks < nks; ++ks) {
         // stage ks landed (the 4 pieces of stage ks+1 may still fly); every wave is done reading slot (ks-1) % 3
-        if (ks + 1 < nks) { GF_WAIT_BARRIER(4); } else { GF_WAIT_BARRIER(0); }
+        if (ks + 1 < nks) { if (BM == 128) { GF_WAIT_BARRIER(4); } else { GF_WAIT_BARRIER(3); } } else { GF_WAIT_BARRIER(0); }
         if (ks + 2 < nks) stage(ks + 2, slot >= 1 ? slot - 1 : 2);
-        const char* As = smem + slot * SLOT + wm * 4096 + frag;
+        const char* As = smem + slot * SLOT + wm * (BM * 32) + frag;
         const char* Bs = smem + slot * SLOT + 8192 + wn * 4096 + frag;
-        f32x4 af[4], bf[4];
+        f32x4 af[MT], bf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            af[i] = *(const f32x4*)(As + i * 1024);
+            if (i < MT) af[i] = *(const f32x4*)(As + i * 1024);
             bf[i] = *(const f32x4*)(Bs + i * 1024);
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
@@ -141,8 +144,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
 
     if (S > 1) {   // split-K: raw partial sums to this split's slab; scale/shift/act happen in the reduce kernel
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + q * 4;
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + q * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const long n = n0 + wn * 64 + j * 16 + r16;
@@ -157,8 +160,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
     }
     const bool vec = ((a.ldc & 3) == 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + q * 4;
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + q * 4;
         float sc[4], sh[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -203,13 +206,18 @@ __global__ void gemm_f32_reduce_kernel(GemmF32Args a) {
 
 void launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab_floats, long n_ref) {
     GemmF32Args a = a0;
+    const int BM = a.M <= 64 ? 64 : 128;          // 64-row tiles where a 128-row tile would be half empty
     const unsigned gx = (unsigned)((a.N + BN - 1) / BN), gy = (unsigned)((a.M + BM - 1) / BM);
     const int nks = a.taps * (a.K / BK);
     int S = 1;
+    auto launch = [&](dim3 grid) {
+        if (BM == 64) hipLaunchKernelGGL(gemm_f32_kernel<64>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(gemm_f32_kernel<128>, grid, dim3(256), 0, s, a);
+    };
     if (a.groups > 1) {
         a.splits = 1;
         a.slab = nullptr;
-        hipLaunchKernelGGL(gemm_f32_kernel, dim3(gx, gy, (unsigned)a.groups), dim3(256), 0, s, a);
+        launch(dim3(gx, gy, (unsigned)a.groups));
         return;
     }
     if (slab) {
@@ -226,7 +234,7 @@ void launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long sla
     }
     a.splits = S;
     a.slab = slab;
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(gx, gy, S), dim3(256), 0, s, a);
+    launch(dim3(gx, gy, S));
     if (S > 1) {
         const long total = a.N * a.M;
         hipLaunchKernelGGL(gemm_f32_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
