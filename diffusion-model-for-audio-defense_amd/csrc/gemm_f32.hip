@@ -225,8 +225,8 @@ void launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long sla
         // rows of this launch, so that a sample's result does not depend on the batch it was computed in.
         const long nr = n_ref > 0 ? n_ref : a.N;
         const long wgs_ref = ((nr + BN - 1) / BN) * gy;
-        if (wgs_ref < 128) {                       // fewer than half a wave of workgroups: split K
-            S = (int)(256 / wgs_ref);
+        if (wgs_ref < 384) {                       // fewer than half the resident workgroups (3 per CU): split K
+            S = (int)(768 / wgs_ref);
             if (S > nks / 4) S = nks / 4;          // keep >= 4 k-steps per split
             while (S > 1 && (long)S * nr * a.ldc > slab_floats) --S;
             if (S < 2 || a.N > nr) S = 1;
