@@ -46,6 +46,10 @@ constexpr int F_W3 = 131072;                  // two final_conv.0 weight buffers
 __device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
+// the gate store is read exactly once: non-temporal, it must not displace the (re-read) weight slabs in L2
+__device__ __forceinline__ void dma16_stream(const void* sbase, unsigned voff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
@@ -79,7 +83,7 @@ __global__ void __launch_bounds__(512, 2) wn_final_bf16_p(WnFinalArgs a, long np
         auto stage_piece = [&](int ks, int slot, int p) {   // p: 0,1 = weights, 2,3 = activation rows
             const unsigned la = lds0 + slot * F_SLOT + wv * 1024;
             if (p < 2) dma16(wb + ((size_t)ks * 16384 + p * 8192), tid16, la + p * 8192);
-            else dma16(gb + (size_t)ks * kc_bytes, p == 2 ? voff0 : voff1, la + F_BOFF + (p - 2) * 8192);   // plane ks = layer*8 + kc
+            else dma16_stream(gb + (size_t)ks * kc_bytes, p == 2 ? voff0 : voff1, la + F_BOFF + (p - 2) * 8192);   // plane ks = layer*8 + kc
         };
         auto stage3 = [&](int ks3, int buf) {
             const unsigned la = lds0 + F_W3 + buf * 16384 + wv * 1024;

@@ -260,7 +260,11 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int idx = it * 512 + tidv, t = idx >> 5, c = idx & 31;
-                *(uint4*)(gdst + (size_t)(c >> 2) * gkc + (size_t)t * 64 + (c & 3) * 16) = *(const uint4*)(smem + t * 512 + ((c ^ (t & 15)) * 16));
+                typedef __attribute__((ext_vector_type(4))) unsigned g_u32x4;
+                const g_u32x4 gv4 = *(const g_u32x4*)(smem + t * 512 + ((c ^ (t & 15)) * 16));
+                // written once, read by another launch much later: non-temporal, so that the stream does not push the
+                // centre rows (re-read by the epilogue) out of the XCD's L2
+                __builtin_nontemporal_store(gv4, (g_u32x4*)(gdst + (size_t)(c >> 2) * gkc + (size_t)t * 64 + (c & 3) * 16));
             }
         };
         // ---------------- gate: g[ch][t] -> LDS [t][ch] bf16 at [0, 64K) -------------------------------------
@@ -430,7 +434,7 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
                     const auto s1 = __builtin_amdgcn_permlane16_swap(oxu[1], oyu[1], false, false);
                     const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};
                     const unsigned row = (unsigned)(hin_c.row0 + wn * 64 + (2 * p2 + (qv & 1)) * 16 + r16v);
-                    *(u32x4*)(hout_clip + h16_off(row, (unsigned)(wm * 8 + mt * 2 + (qv >> 1)))) = chunk;
+                    __builtin_nontemporal_store(chunk, (u32x4*)(hout_clip + h16_off(row, (unsigned)(wm * 8 + mt * 2 + (qv >> 1)))));
                 }
             stamp(7);
             if (!has_next) { flush(); return; }
