@@ -33,29 +33,43 @@ __device__ __forceinline__ float block_sum(float v, float* red) {   // 256 threa
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// one workgroup per (group, sample): mean, then biased variance of the deviations, then the affine / scale-shift / SiLU
+// one workgroup per (group, sample): the group's C/32 channels x HW pixels (at most 12288 floats in this network) are read
+// once into LDS as float4 (C/32 is a multiple of 4), then mean, biased variance of the deviations, and the affine /
+// scale-shift / SiLU pass run from LDS
+constexpr int GN_MAX = 12288;
 __global__ void __launch_bounds__(256) groupnorm_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ ss, int silu,
                                                              float* __restrict__ y, int HW, int C) {
     __shared__ float red[4];
-    const int g = blockIdx.x, cg = C >> 5, n = cg * HW;
+    __shared__ __attribute__((aligned(16))) float buf[GN_MAX];
+    const int g = blockIdx.x, cg = C >> 5, c4 = cg >> 2, n4 = c4 * HW, n = cg * HW;
     const long base = (long)blockIdx.y * HW * C + g * cg;
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += x[base + (long)(i / cg) * C + (i % cg)];
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = *(const float4*)(x + base + (long)(i / c4) * C + (i % c4) * 4);
+        ((float4*)buf)[i] = v;
+        s += (v.x + v.y) + (v.z + v.w);
+    }
     const float mean = block_sum(s, red) / (float)n;
     float q = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float d = x[base + (long)(i / cg) * C + (i % cg)] - mean;
-        q = fmaf(d, d, q);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = ((const float4*)buf)[i];
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
     }
     const float rstd = 1.0f / sqrtf(block_sum(q, red) / (float)n + 1e-5f);
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int c = g * cg + (i % cg);
-        const long a = base + (long)(i / cg) * C + (i % cg);
-        float v = (x[a] - mean) * rstd * gamma[c] + beta[c];
-        if (ss) v = v * (1.f + ss[c]) + ss[C + c];
-        if (silu) v = v / (1.f + expf(-v));
-        y[a] = v;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const int c = g * cg + (i % c4) * 4;
+        const float4 v = ((const float4*)buf)[i];
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = (o[r] - mean) * rstd * gamma[c + r] + beta[c + r];
+            if (ss) t = t * (1.f + ss[c + r]) + ss[C + c + r];
+            if (silu) t = t / (1.f + expf(-t));
+            o[r] = t;
+        }
+        *(float4*)(y + base + (long)(i / c4) * C + (i % c4) * 4) = float4{o[0], o[1], o[2], o[3]};
     }
 }
 
@@ -146,6 +160,7 @@ void launch_conv1ch_3x3(const float* in, const float* w, const float* bias, floa
 }
 void launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* ss, int silu, float* y, int B, int HW,
                            int C, hipStream_t s) {
+    // C is a multiple of 128 and (C / 32) * HW <= GN_MAX for every map of this network (checked by the caller's shapes)
     hipLaunchKernelGGL(groupnorm_nhwc_kernel, dim3(32, (unsigned)B), dim3(256), 0, s, x, gamma, beta, ss, silu, y, HW, C);
 }
 void launch_silu(const float* x, float* y, long n, hipStream_t s) {
