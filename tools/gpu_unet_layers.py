@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Development: one UNet eps evaluation of B spectrograms (after a warm-up at the same step) for a rocprofv3 kernel
+trace; with --analyse DIR prints per-launch TFLOP/s of the gemm_f32 launches of the LAST forward in launch order."""
+import csv, glob, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'diffusion-model-for-audio-defense_amd')]
+B = int(os.environ.get('B', 128))
+
+
+def launches():
+    from dmad_hip import synth
+    _, inp, mid, outp = synth.unet_layout()
+    out, H = [], 32
+
+    def ops(blk):
+        nonlocal H
+        for p, kind, cin, cout in blk:
+            n = B * H * H
+            if kind == 'res':
+                out.append(('%s conv1 %d->%d @%d' % (p, cin, cout, H), 2.0 * n * cin * cout * 9))
+                if cin != cout:
+                    out.append(('%s skip %d->%d @%d' % (p, cin, cout, H), 2.0 * n * cin * cout))
+                out.append(('%s conv2 %d->%d @%d' % (p, cout, cout, H), 2.0 * n * cout * cout * 9))
+            elif kind == 'attn':
+                out.append(('%s qkv %d @%d' % (p, cin, H), 2.0 * n * cin * 3 * cin))
+                out.append(('%s proj %d @%d' % (p, cin, H), 2.0 * n * cin * cin))
+            elif kind == 'down':
+                H //= 2
+                out.append(('%s down %d @%d' % (p, cin, H), 2.0 * B * H * H * cin * cout * 9))
+            elif kind == 'up':
+                H *= 2
+                out.append(('%s up %d @%d' % (p, cin, H), 2.0 * B * H * H * cin * cout * 9))
+    for b in inp:
+        ops(b)
+    ops(mid)
+    for b in outp:
+        ops(b)
+    out.append(('out conv 128->1', 2.0 * B * 1024 * 128 * 9))
+    return out
+
+
+if len(sys.argv) > 2 and sys.argv[1] == '--analyse':
+    path = glob.glob(os.path.join(sys.argv[2], '**', '*kernel_trace.csv'), recursive=True)[0]
+    rows = [r for r in csv.DictReader(open(path)) if 'gemm_f32_kernel' in r['Kernel_Name']]
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    L = launches()
+    rows = rows[-len(L):]
+    tot, worst = 0.0, []
+    for (name, fl), r in zip(L, rows):
+        us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+        tot += us
+        worst.append((us, fl / us / 1e6, name))
+    for us, tf, name in sorted(worst, reverse=True)[:25]:
+        print('%-52s %9.1f us  %6.1f TFLOP/s' % (name, us, tf))
+    print('total gemm %.1f us over %d launches; flops %.2f T -> %.1f TFLOP/s' % (tot, len(L), sum(f for _, f in L) / 1e12, sum(f for _, f in L) / tot / 1e6))
+else:
+    import torch
+    from dmad_hip import engine as E, synth
+    eng = E.Engine(max_batch=B, precision=E.BF16, with_classifier=False)
+    eng.load_unet(synth.unet_state_dict(5252))
+    x = torch.randn(B, 32, 32, device='cuda') * 0.5
+    eng.unet_eps(x, 40); torch.cuda.synchronize()
+    eng.unet_eps(x, 40); torch.cuda.synchronize()
