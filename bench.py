@@ -92,12 +92,20 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    # DMAD_BENCH_BACKEND=gloo is a rehearsal switch only (several ranks sharing one GPU of a 1-GPU box); the measured
+    # configuration is one rank per GPU over RCCL
+    backend = os.environ.get('DMAD_BENCH_BACKEND', 'nccl')
+    if backend == 'gloo':
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'gloo':
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     from dmad_hip import engine as E, synth
@@ -124,7 +132,12 @@ def main():
         base = (i * world + rank) * S
         counts, _, _ = eng.smooth_votes(clip, sigma, sc, t, c_a, c_b, S, seed=2024, sample0=base)
         if dist is not None:
-            dist.all_reduce(counts)
+            if backend == 'gloo':
+                c = counts.cpu()
+                dist.all_reduce(c)
+                counts = c.cuda()
+            else:
+                dist.all_reduce(counts)
         total.add_(counts)
 
     def fence():
@@ -146,7 +159,7 @@ def main():
     dt = time.perf_counter() - t0
     layer_ms, launches = eng.profile_read()
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        tmax = torch.tensor([dt], dtype=torch.float64, device='cpu' if backend == 'gloo' else 'cuda')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     votes = total.cpu().tolist()
