@@ -707,3 +707,21 @@ def test_two_ranks_on_the_hip_path(engines, tmp_path):
     y, r = rc.certify(clip[None], torch.tensor([2]).cuda(), sigma=0.5, n_0=10, n=20, batch_size=6)
     assert int(got['counts'].sum()) == 30 and got['counts'].tolist() == counts.tolist()
     assert got['y'].tolist() == y.cpu().tolist() and torch.equal(got['r'], r.cpu())
+
+
+def test_other_wavenet_geometry(orc):
+    """A 5-layer, dilation-cycle-4 WaveNet (not a multiple of 3 layers, d up to 8): the persistent kernels are not tied to
+    the 36 x 12 geometry of the shipped checkpoint; fp32 and bf16 engines against the oracle restatement."""
+    from dmad_hip import engine as E
+    cfg = dict(synth.WAVENET_CONFIG)
+    cfg.update(num_res_layers=5, dilation_cycle=4)
+    sd = synth.wavenet_state_dict(77, cfg)
+    w = orc.folded_weights(sd, 5)
+    x = torch.from_numpy(np.stack([synth.synthetic_clip(0), synth.synthetic_clip(7)])) * 0.8
+    ref = orc.wavenet_forward(w, x, 12 * torch.ones((2, 1)), 5, 4).numpy()[:, 0]
+    for prec, tol in ((E.FP32, FP32_TOL), (E.BF16, BF16_MAX_TOL)):
+        eng = E.Engine(wavenet_config=cfg, max_batch=3, precision=prec, with_classifier=False)
+        eng.load_wavenet(sd)
+        got = eng.wavenet_eps(x.cuda(), 12).cpu().numpy()
+        assert relmax(got, ref) < tol, prec
+        eng.close()
