@@ -110,7 +110,16 @@ def main():
 
     from dmad_hip import engine as E, synth
     from diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
-    eng = E.Engine(max_batch=args.max_batch, precision=E.BF16)
+    eng = None
+    for mb in sorted({args.max_batch, min(args.max_batch, 256), min(args.max_batch, 128)}, reverse=True):
+        try:                                   # 512 clips per launch chain needs ~165 GB of HBM: step down if it is not free
+            eng = E.Engine(max_batch=mb, precision=E.BF16)
+            args.max_batch = mb
+            break
+        except E.DmadError as exc:
+            print('bench: engine batch %d not available (%s)' % (mb, exc), file=sys.stderr, flush=True)
+    if eng is None:
+        raise SystemExit('bench.py: could not create the engine')
     eng.load_wavenet(synth.wavenet_state_dict(1234))
     if args.classifier == 'resnext29':
         eng.load_resnext29(synth.resnext29_state_dict(2929))
