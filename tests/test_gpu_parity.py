@@ -85,6 +85,21 @@ def test_error_behaviour(engines):
         eng.wavenet_eps(torch.zeros(1, 15999, device='cuda'), 3)
     with pytest.raises(DmadError):
         eng.wavenet_eps(torch.zeros(1, 16000, device='cuda'), -1)
+    with pytest.raises(DmadError):
+        eng.unet_eps(torch.zeros(1, 32, 32, device='cuda'), 3)          # UNet weights were never loaded into this engine
+    with pytest.raises(DmadError):
+        eng.load_resnext29(synth.resnext29_state_dict(2929))            # a classifier (VGG19_bn) is already resident
+    with pytest.raises(DmadError):
+        eng.load_wavenet(synth.wavenet_state_dict(1234))
+    from dmad_hip import engine as E
+    bare = E.Engine(max_batch=2, precision=E.BF16, with_classifier=False)
+    with pytest.raises(DmadError):
+        bare.wavenet_eps(torch.zeros(1, 16000, device='cuda'), 3)       # nothing loaded yet
+    with pytest.raises(DmadError):
+        bare.classify(torch.zeros(1, 1, 32, 32, device='cuda'))         # created without the classifier stage
+    with pytest.raises(DmadError):
+        E.Engine(wavenet_config=dict(res_channels=128), max_batch=2)    # only the 256-channel WaveNet is built
+    bare.close()
 
 
 # ------------------------------------------------------------------------------------------ noise
