@@ -235,7 +235,8 @@ int finalize_wavenet(dmad_engine* e) {
             snprintf(nm, sizeof nm, "skip.%d.b", n); GETW(sb, nm, 256)
             for (int tap = 0; tap < 3; ++tap) {
                 for (int oc = 0; oc < 512; ++oc)
-                    for (int ci = 0; ci < 256; ++ci) tapw[(size_t)oc * 256 + ci] = dw[((size_t)oc * 256 + ci) * 3 + tap];
+                    for (int ci = 0; ci < 256; ++ci)     // rows pre-scaled to exp2 arguments: tanh half by -2*log2(e), sigmoid half by -log2(e)
+                        tapw[(size_t)oc * 256 + ci] = dw[((size_t)oc * 256 + ci) * 3 + tap] * (oc < 256 ? -2.8853900817779268f : -1.4426950408889634f);
                 pack_rows(tapw.data(), 512, 256, 256, rmap, w1p, (size_t)n * 24 * 512 * 32, 3, tap);   // stage = 3 * kchunk + tap
             }
             for (int R = 0; R < 512; ++R) b1p[(size_t)n * 512 + R] = db[rmap[R]];

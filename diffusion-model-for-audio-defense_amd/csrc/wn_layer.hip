@@ -24,8 +24,8 @@
 //
 // LDS map (160 KiB): ring slot A = [80K,120K), B = [120K,160K), C = [0,40K); gate tile [0,64K);
 // GEMM2 weight buffers 5 x 16 KiB at [80K,160K); stage-0 activation slice 8 KiB at [68K,76K); pre-scaled dilated-conv
-// bias (2 KiB) at [65K, 67K) — written once per kernel, never overwritten: the accumulators start from
-// zero and the bias enters as the addend of the gate's exp2-argument FMA.
+// bias, scaled like its weight rows (2 KiB) at [65K, 67K) — written once per kernel, never overwritten: the accumulators
+// of every tile start from it, so the gate needs no affine step.
 // The DMA pieces are issued from inline asm (saddr form) and waited for with explicit counted s_waitcnt;
 // hipcc does not count them.  The few ordinary loads of the tile loop (bias, residual rows, epilogue
 // constant) are therefore issued only where NO DMA is in flight (right after a vmcnt(0) barrier) and are
@@ -76,14 +76,14 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// g = tanh(a + ba) * sigmoid(b + bb) for two values at a time with packed fp32 math (v_pk_fma/add/mul):
-//   u = 2^min(kt*a + bta, 30) = e^{-2(a+ba)},  v = 2^(ks*b + bsb) = e^{-(b+bb)},  g = (1-u) / ((1+u)(1+v))
-// 2 v_exp + 1 v_rcp per value; bta = kt*ba and bsb = ks*bb come pre-scaled from LDS.  Only the tanh side
-// needs the clamp: v = inf gives (1+u)(1+v) = inf -> rcp = 0 -> g = 0, the correct limit.
+// g = tanh(A) * sigmoid(B) for two values at a time with packed fp32 math, on accumulators that already hold the
+// exp2 arguments: the host scales the tanh rows of the dilated-conv weights by -2*log2(e) and the sigmoid rows by
+// -log2(e), and the accumulators start from the equally scaled bias, so
+//   u = 2^min(at, 30) = e^{-2A},  v = 2^as = e^{-B},  g = (1-u) / ((1+u)(1+v))
+// 2 v_exp + 1 v_rcp per value and no affine step.  Only the tanh side needs the clamp: v = inf gives
+// (1+u)(1+v) = inf -> rcp = 0 -> g = 0, the correct limit.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-__device__ __forceinline__ f32x2 gate2(f32x2 a, f32x2 b, f32x2 bta, f32x2 bsb) {
-    f32x2 at = a * f32x2{kGateKt, kGateKt} + bta;
-    const f32x2 as = b * f32x2{kGateKs, kGateKs} + bsb;
+__device__ __forceinline__ f32x2 gate2(f32x2 at, f32x2 as) {
     at[0] = fminf(at[0], 30.f);
     at[1] = fminf(at[1], 30.f);
     const f32x2 u = {fast_exp2(at[0]), fast_exp2(at[1])};
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = *(const f32x4*)(smem + CONST_OFF + (wm * 128 + mt * 16 + q * 4) * 4);
         bf16x8 af[2][8], bf[2][4];
         {
             const char* A = smem + slot_base(0) + wm * 8192 + frag_off;
@@ -271,29 +271,23 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
         // Channel ownership is interleaved over the waves: tile (wm, mt) holds gate channels mt*64 + wm*16 + [0,16),
         // so after every wave has gated its tiles `mt`, channels [64 mt, 64 mt + 64) — GEMM2 k-steps 2mt, 2mt+1 —
         // are complete and their MFMAs run under the gate math (VALU) of tiles mt+1.
-        auto gate_tile = [&](int mt, int nt, const f32x4& bt, const f32x4& bs) {
+        auto gate_tile = [&](int mt, int nt) {
             const f32x4 ha = acc[mt][nt], hb = acc[mt + 4][nt];
-            const f32x2 g01 = gate2(f32x2{ha[0], ha[1]}, f32x2{hb[0], hb[1]}, f32x2{bt[0], bt[1]}, f32x2{bs[0], bs[1]});
-            const f32x2 g23 = gate2(f32x2{ha[2], ha[3]}, f32x2{hb[2], hb[3]}, f32x2{bt[2], bt[3]}, f32x2{bs[2], bs[3]});
+            const f32x2 g01 = gate2(f32x2{ha[0], ha[1]}, f32x2{hb[0], hb[1]});
+            const f32x2 g23 = gate2(f32x2{ha[2], ha[3]}, f32x2{hb[2], hb[3]});
             const bf16x4 gv = {(bf16_t)g01[0], (bf16_t)g01[1], (bf16_t)g23[0], (bf16_t)g23[1]};
             const int t = wn * 64 + nt * 16 + r16v;
             const int chunk = mt * 8 + wm * 2 + (qv >> 1);
             *(bf16x4*)(smem + t * 512 + ((chunk ^ r16v) * 16) + (qv & 1) * 8) = gv;
-        };
-        auto gate_bias = [&](int mt, f32x4& bt, f32x4& bs) {
-            bt = *(const f32x4*)(smem + CONST_OFF + (wm * 128 + mt * 16 + qv * 4) * 4);
-            bs = *(const f32x4*)(smem + CONST_OFF + (wm * 128 + 64 + mt * 16 + qv * 4) * 4);
         };
 
         if constexpr (LAST) {
             // the last layer's residual output is never consumed (WaveNet.py:131-135): only g leaves
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                f32x4 bt, bs;
-                gate_bias(mt, bt, bs);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    gate_tile(mt, nt, bt, bs);
+                    gate_tile(mt, nt);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -307,11 +301,9 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
             stage1(hin_n, 2);
         } else {
             {
-                f32x4 bt, bs;
-                gate_bias(0, bt, bs);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    gate_tile(0, nt, bt, bs);
+                    gate_tile(0, nt);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -344,25 +336,23 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
             };
             // one phase: gate tiles (mt, 0..3) interleaved with the 2 x 16 MFMAs of k-steps ka (buffer bufa), kb (bufb)
             auto phase = [&](int mt, int ka, int bufa, int kb, int bufb) {
-                f32x4 bt, bs;
-                gate_bias(mt, bt, bs);
                 read2(ka, bufa);
                 __builtin_amdgcn_sched_barrier(0);
-                gate_tile(mt, 0, bt, bs);
+                gate_tile(mt, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma2(0, 2);
                 __builtin_amdgcn_sched_barrier(0);
-                gate_tile(mt, 1, bt, bs);
+                gate_tile(mt, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma2(2, 4);
                 __builtin_amdgcn_sched_barrier(0);
                 read2(kb, bufb);
                 __builtin_amdgcn_sched_barrier(0);
-                gate_tile(mt, 2, bt, bs);
+                gate_tile(mt, 2);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma2(0, 2);
                 __builtin_amdgcn_sched_barrier(0);
-                gate_tile(mt, 3, bt, bs);
+                gate_tile(mt, 3);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma2(2, 4);
                 __builtin_amdgcn_sched_barrier(0);
