@@ -91,7 +91,7 @@ __device__ __forceinline__ f32x2 gate2(f32x2 at, f32x2 as) {
     const f32x2 p = u + f32x2{1.f, 1.f};
     const f32x2 d = p * v + p;
     const f32x2 r = {fast_rcp(d[0]), fast_rcp(d[1])};
-    return (f32x2{1.f, 1.f} - u) * r;
+    return r - u * r;                     // (1 - u) * r as one packed FMA
 }
 
 }  // namespace
