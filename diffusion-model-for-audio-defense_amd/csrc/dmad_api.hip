@@ -240,7 +240,9 @@ int finalize_wavenet(dmad_engine* e) {
                 pack_rows(tapw.data(), 512, 256, 256, rmap, w1p, (size_t)n * 24 * 512 * 32, 3, tap);   // stage = 3 * kchunk + tap
             }
             for (int R = 0; R < 512; ++R) b1p[(size_t)n * 512 + R] = db[rmap[R]];
-            pack_rows(rw.data(), 256, 256, 256, nullptr, w2p, (size_t)n * 8 * 256 * 32);
+            std::vector<float> rws(rw.size());                      // res conv pre-scaled by sqrt(1/2): h' = h*sqrt(1/2) + (W_res' g + c)
+            for (size_t i = 0; i < rw.size(); ++i) rws[i] = rw[i] * 0.70710678118654752440f;
+            pack_rows(rws.data(), 256, 256, 256, nullptr, w2p, (size_t)n * 8 * 256 * 32);
             pack_rows(sw.data(), 256, 256, 256, nullptr, wsp, (size_t)n * 8 * 256 * 32);
             for (int c = 0; c < 256; ++c) { b2[(size_t)n * 256 + c] = rb[c]; bsum[c] += sb[c]; }
         }

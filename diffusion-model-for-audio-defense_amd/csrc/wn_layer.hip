@@ -16,7 +16,7 @@
 //   GEMM2   res conv, 8 weight stages through five 16 KiB buffers.  Gate channels are interleaved over the
 //           waves so that GEMM2 k-steps 2mt, 2mt+1 only need the gate tiles `mt`: their MFMAs run under the
 //           VALU-bound gate math of tiles mt+1 (the matrix pipe would otherwise idle through the gate).
-//   epi     h' = (h + res) * sqrt(1/2) + emb_{n+1} straight from the accumulators: the residual stream is kept in the
+//   epi     h' = h * sqrt(1/2) + acc2, acc2 = W_res*sqrt(1/2) g + (b_res*sqrt(1/2) + emb_{n+1}) (its start value), from the accumulators: the residual stream is kept in the
 //           blocked "H16" order (dmad_common.h) so that lane pairs (v_permlane16_swap) assemble 16-byte chunks and a
 //           wave-store writes 256-byte contiguous runs; no LDS round trip, no barrier.
 //   While the epilogue runs, stages 0-2 of the NEXT tile are already in flight into the ring, so the next
@@ -41,6 +41,7 @@ namespace {
 constexpr int SLOT_BOFF = 32768;
 constexpr int GEMM2_BUF = 81920;
 constexpr int CONST_OFF = 66560;
+constexpr int EC_OFF = 65536;                 // 1 KiB: epilogue constant b_res*sqrt(1/2) + emb_{n+1} per output channel
 constexpr int B0_OFF = 69632;                 // 8 KiB: activation part of a tile's stage 0 (issued a whole phase early)
 constexpr float kGateKt = -2.8853900817779268f, kGateKs = -1.4426950408889634f;   // -2*log2(e), -log2(e)
 __device__ __forceinline__ constexpr int slot_base(int i) { return i == 0 ? 81920 : (i == 1 ? 122880 : 0); }
@@ -177,6 +178,7 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
 
     // pre-scaled dilated-conv bias -> LDS (one float per thread = one per gate row), retired before any DMA
     ((float*)(smem + CONST_OFF))[tid] = a.b1[tid] * (((tid & 127) < 64) ? kGateKt : kGateKs);
+    if (!LAST && tid < 256) ((float*)(smem + EC_OFF))[tid] = a.epi_c[tid];      // GEMM2's accumulators start from it
     __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0)
     f32x4 acc[8][4];
     stage1(hin_c, 0);
@@ -318,7 +320,7 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = *(const f32x4*)(smem + EC_OFF + (wm * 64 + mt * 16 + qv * 4) * 4);
             bf16x8 b2[4], a2[4];
             auto read2 = [&](int ks2, int buf) {
                 const char* A = smem + GEMM2_BUF + buf * 16384 + wm * 4096 + r16v * 64 + ((qv ^ swz64(r16v)) * 16);
@@ -364,12 +366,10 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
             phase(2, 2, 2, 3, 3);
             WNL_WAIT_BARRIER(0);           // g channels [128,192) complete; stages 5-6 landed; buffers 2-3 free
             // ordinary loads, issued right behind a vmcnt(0) barrier and retired by the next one (see the header):
-            // epilogue constant b_res * sqrt(1/2) + emb_{n+1} of this thread's 8 channels, residual rows
-            f32x4 ec[4];                   // ... of this lane's output channels wm*64 + mt*16 + 4q + [0,4)
+            // the residual rows of this lane's output channels wm*64 + mt*16 + 4q + [0,4)
             bf16x8 hc16[4][2];             // residual h: the 16-byte chunk this lane will overwrite (tile 2p + (q&1), see epilogue)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                ec[mt] = *(const f32x4*)(a.epi_c + wm * 64 + mt * 16 + qv * 4);
 #pragma unroll
                 for (int p2 = 0; p2 < 2; ++p2) {
                     const unsigned row = (unsigned)(hin_c.row0 + wn * 64 + (2 * p2 + (qv & 1)) * 16 + r16v);
@@ -416,8 +416,8 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
                     bf16x4 ox, oy;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        ox[r] = (bf16_t)(((float)hx[r] + acc2[mt][2 * p2][r]) * 0.70710678118654752440f + ec[mt][r]);
-                        oy[r] = (bf16_t)(((float)hy[r] + acc2[mt][2 * p2 + 1][r]) * 0.70710678118654752440f + ec[mt][r]);
+                        ox[r] = (bf16_t)__builtin_fmaf((float)hx[r], 0.70710678118654752440f, acc2[mt][2 * p2][r]);
+                        oy[r] = (bf16_t)__builtin_fmaf((float)hy[r], 0.70710678118654752440f, acc2[mt][2 * p2 + 1][r]);
                     }
                     const u32x2 oxu = __builtin_bit_cast(u32x2, ox), oyu = __builtin_bit_cast(u32x2, oy);
                     const auto s0 = __builtin_amdgcn_permlane16_swap(oxu[0], oyu[0], false, false);
