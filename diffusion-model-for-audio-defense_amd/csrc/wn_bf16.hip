@@ -33,11 +33,13 @@ namespace dmad {
 __global__ void __launch_bounds__(256) wn_init_bf16(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ bias, const float* __restrict__ emb0,
                                                     bf16_t* __restrict__ h, int L, int LP, long total_chunks) {
-    // one thread per 8-channel chunk of one time position
+    // one thread per 8-channel chunk of one time position, in the order of the H16 layout: 16 consecutive lanes write the
+    // 16 rows of one chunk column (256 contiguous bytes), a wave 1 KiB, a 16-row block 8 KiB (L is a multiple of 16, so
+    // a block never straddles two clips)
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_chunks;
          idx += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(idx & 31);
-        const long pos = idx >> 5;                 // b * L + t
+        const int cg = (int)((idx >> 4) & 31);
+        const long pos = (idx >> 9) * 16 + (idx & 15);      // b * L + t
         const long bb = pos / L, t = pos - bb * L;
         const float xv = x[pos];
         bf16x8 o;
