@@ -32,9 +32,9 @@ import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0
 # HBM-side bytes per clip per wn_layer_bf16_p launch from the rocprofv3 PMC passes committed under profiles/
-# (FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, see profiles/r01g_kernel_stats.md); None if the file is absent
+# (FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, see profiles/r01h_kernel_stats.md); None if the file is absent
 try:
-    with open(os.path.join(ROOT, 'profiles', 'r01g_layer_traffic.json')) as _f:
+    with open(os.path.join(ROOT, 'profiles', 'r01h_layer_traffic.json')) as _f:
         LAYER_TRAFFIC_PER_CLIP = float(json.load(_f)['layer_traffic_bytes_per_clip'])
 except Exception:
     LAYER_TRAFFIC_PER_CLIP = None
@@ -194,7 +194,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS,
                          "traffic": (LAYER_TRAFFIC_PER_CLIP * clips_per_launch if LAYER_TRAFFIC_PER_CLIP else None),
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r01g_kernel_stats.md "
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r01h_kernel_stats.md "
                                            "(2 x FETCH_SIZE + WRITE_SIZE, bytes per launch)",
                          "kernel": "wn_layer_bf16", "avg_launch_ms": avg_ms, "launches_timed": launches,
                          "flop_per_launch": LAYER_FLOP_PER_CLIP * clips_per_launch},
