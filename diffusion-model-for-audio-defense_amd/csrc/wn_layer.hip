@@ -85,8 +85,8 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 // (1+u)(1+v) = inf -> rcp = 0 -> g = 0, the correct limit.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ f32x2 gate2(f32x2 at, f32x2 as) {
-    at[0] = fminf(at[0], 30.f);
-    at[1] = fminf(at[1], 30.f);
+    at[0] = __builtin_amdgcn_fmed3f(at[0], 30.f, -3.0e38f);     // min(at, 30) as one v_med3 (fminf on an MFMA result costs
+    at[1] = __builtin_amdgcn_fmed3f(at[1], 30.f, -3.0e38f);     // an extra canonicalising v_max)
     const f32x2 u = {fast_exp2(at[0]), fast_exp2(at[1])};
     const f32x2 v = {fast_exp2(as[0]), fast_exp2(as[1])};
     const f32x2 p = u + f32x2{1.f, 1.f};
