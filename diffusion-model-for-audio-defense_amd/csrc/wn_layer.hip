@@ -259,14 +259,18 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
         char* gdst = (char*)a.gout + ((size_t)b * a.L + t0) * 64;
         const size_t gkc = (size_t)a.npos * 64;
         auto store_g = [&]() {
+            // thread -> (row t = 16 it + tr, chunk c): one LDS address and one global address per thread, the eight
+            // iterations are immediate offsets (8 KiB in LDS, 1 KiB in the gate store) of them
+            typedef __attribute__((ext_vector_type(4))) unsigned g_u32x4;
+            const int tr = tidv >> 5, c = tidv & 31;
+            const char* lsrc = smem + tr * 512 + ((c ^ (tr & 15)) * 16);
+            char* gb = gdst + (size_t)(c >> 2) * gkc + (size_t)(tr * 64 + (c & 3) * 16);
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const int idx = it * 512 + tidv, t = idx >> 5, c = idx & 31;
-                typedef __attribute__((ext_vector_type(4))) unsigned g_u32x4;
-                const g_u32x4 gv4 = *(const g_u32x4*)(smem + t * 512 + ((c ^ (t & 15)) * 16));
+                const g_u32x4 gv4 = *(const g_u32x4*)(lsrc + it * 8192);
                 // written once, read by another launch much later: non-temporal, so that the stream does not push the
                 // centre rows (re-read by the epilogue) out of the XCD's L2
-                __builtin_nontemporal_store(gv4, (g_u32x4*)(gdst + (size_t)(c >> 2) * gkc + (size_t)t * 64 + (c & 3) * 16));
+                __builtin_nontemporal_store(gv4, (g_u32x4*)(gb + it * 1024));
             }
         };
         // ---------------- gate: g[ch][t] -> LDS [t][ch] bf16 at [0, 64K) -------------------------------------
@@ -368,13 +372,14 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
             // ordinary loads, issued right behind a vmcnt(0) barrier and retired by the next one (see the header):
             // the residual rows of this lane's output channels wm*64 + mt*16 + 4q + [0,4)
             bf16x8 hc16[4][2];             // residual h: the 16-byte chunk this lane will overwrite (tile 2p + (q&1), see epilogue)
+            // H16 offset of this lane's chunk (mt, p2): one per-lane base + p2 * 16 KiB (two 16-row blocks on) + mt * 512 B
+            // (two chunk columns on); row0 is a multiple of 16, so the row's block index and in-block row separate
+            const unsigned h16_lane = (unsigned)((hin_c.row0 >> 4) + wn * 4 + (qv & 1)) * 8192u + (unsigned)(wm * 8 + (qv >> 1)) * 256u + (unsigned)r16v * 16u;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const char* hp = hin_c.clip + h16_lane + p2 * 16384;
 #pragma unroll
-                for (int p2 = 0; p2 < 2; ++p2) {
-                    const unsigned row = (unsigned)(hin_c.row0 + wn * 64 + (2 * p2 + (qv & 1)) * 16 + r16v);
-                    hc16[mt][p2] = *(const bf16x8*)(hin_c.clip + h16_off(row, (unsigned)(wm * 8 + mt * 2 + (qv >> 1))));
-                }
+                for (int mt = 0; mt < 4; ++mt) hc16[mt][p2] = *(const bf16x8*)(hp + mt * 512);
             }
             stage2(7, 2);
             phase(3, 4, 4, 5, 0);
@@ -423,8 +428,7 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
                     const auto s0 = __builtin_amdgcn_permlane16_swap(oxu[0], oyu[0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(oxu[1], oyu[1], false, false);
                     const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};
-                    const unsigned row = (unsigned)(hin_c.row0 + wn * 64 + (2 * p2 + (qv & 1)) * 16 + r16v);
-                    __builtin_nontemporal_store(chunk, (u32x4*)(hout_clip + h16_off(row, (unsigned)(wm * 8 + mt * 2 + (qv >> 1)))));
+                    __builtin_nontemporal_store(chunk, (u32x4*)(hout_clip + h16_lane + p2 * 16384 + mt * 512));
                 }
             stamp(7);
             if (!has_next) { flush(); return; }
