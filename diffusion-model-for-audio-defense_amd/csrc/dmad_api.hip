@@ -1005,6 +1005,16 @@ int dmad_unet_p_sample(dmad_engine* e, float* x, int32_t t, float c_a, float c_b
     return 0;
 }
 
+int dmad_ddpm_purify(dmad_engine* e, const float* x0, int32_t t_star, float c_a, float c_b, const float* c_eps, const float* c_div,
+                     const float* c_sig, uint64_t seed, uint64_t sample0, int32_t B, float* out, dmad_stream s) {
+    if (!e || !x0 || !out || !c_eps || !c_div || !c_sig) return fail(DMAD_ERR_INVALID, "null argument");
+    if (t_star < 1) return fail(DMAD_ERR_INVALID, "t_star %d < 1", t_star);
+    CHK(dmad_diffuse(e, x0, c_a, c_b, nullptr, seed, sample0, B, out, s));
+    for (int t = t_star - 1; t >= 0; --t)
+        CHK(dmad_ddpm_step(e, out, t, c_eps[t], c_div[t], t > 0 ? c_sig[t] : 0.f, nullptr, seed, sample0, B, s));
+    return 0;
+}
+
 int dmad_mel_db(dmad_engine* e, const float* x, int32_t B, float* spec, dmad_stream s) {
     if (!e || !x || !spec) return fail(DMAD_ERR_INVALID, "null argument");
     return mel_db(e, x, B, spec, (hipStream_t)s);

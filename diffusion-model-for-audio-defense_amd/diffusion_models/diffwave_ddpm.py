@@ -86,6 +86,16 @@ class DiffWave(torch.nn.Module):
     # -- reference API ---------------------------------------------------------------------------
     def forward(self, waveforms: Union[torch.Tensor, np.ndarray]):
         waveforms = self._to_tensor(waveforms)
+        if self.noise_source == 'device':     # the whole chain in one library call (dmad_ddpm_purify)
+            _, Alpha, Alpha_bar, Sigma = self._tables()
+            assert waveforms.ndim == 3
+            ts = self.reverse_timestep
+            out = self.engine.ddpm_purify(waveforms, ts, float(torch.sqrt(Alpha_bar[ts - 1])), float(torch.sqrt(1 - Alpha_bar[ts - 1])),
+                                          [float((1 - Alpha[t]) / torch.sqrt(1 - Alpha_bar[t])) for t in range(ts)],
+                                          [float(torch.sqrt(Alpha[t])) for t in range(ts)], [float(Sigma[t]) for t in range(ts)],
+                                          seed=self.seed, sample0=self._draws)
+            self._draws += waveforms.shape[0]
+            return out.unsqueeze(1)
         base = self._draws                    # device noise: row i of this call is sample base + i in BOTH phases
         output = self._diffusion(waveforms)   # (different Philox streams), so a clip's purification does not depend on
         self._draws = base                    # the batch it is in

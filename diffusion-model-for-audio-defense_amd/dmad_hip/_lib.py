@@ -33,6 +33,7 @@ _SIGNATURES = {
     'dmad_one_shot': (C.c_int, [_P, _P, C.c_int32, C.c_float, C.c_float, C.c_int32, _P, _P]),
     'dmad_ddpm_step': (C.c_int, [_P, _P, C.c_int32, C.c_float, C.c_float, C.c_float, _P, C.c_uint64, C.c_uint64, C.c_int32, _P]),
     'dmad_diffuse': (C.c_int, [_P, _P, C.c_float, C.c_float, _P, C.c_uint64, C.c_uint64, C.c_int32, _P, _P]),
+    'dmad_ddpm_purify': (C.c_int, [_P, _P, C.c_int32, C.c_float, C.c_float, _P, _P, _P, C.c_uint64, C.c_uint64, C.c_int32, _P, _P]),
     'dmad_unet_eps': (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     'dmad_unet_p_sample': (C.c_int, [_P, _P, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_uint64, C.c_uint64,
                                      C.c_int32, _P, _P]),

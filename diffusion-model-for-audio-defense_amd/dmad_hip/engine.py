@@ -235,6 +235,16 @@ class Engine:
                                         e - s, _ptr(out[s:e]), _stream()))
         return out
 
+    def ddpm_purify(self, x0: torch.Tensor, t_star: int, c_a: float, c_b: float, c_eps, c_div, c_sig, seed: int = 0, sample0: int = 0):
+        """DiffWave.forward with device noise in one library call per chunk; c_eps / c_div / c_sig: t_star floats each."""
+        x = self._wave(x0)
+        out = torch.empty_like(x)
+        arrs = [(C.c_float * t_star)(*[float(v) for v in a]) for a in (c_eps, c_div, c_sig)]
+        for s, e in self._chunks(x.shape[0]):
+            check(self.lib.dmad_ddpm_purify(self._h, _ptr(x[s:e]), int(t_star), float(c_a), float(c_b), arrs[0], arrs[1], arrs[2],
+                                            int(seed), int(sample0) + s, e - s, _ptr(out[s:e]), _stream()))
+        return out
+
     def _spec(self, x: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:
             raise DmadError('input must live on the GPU (the dmad engine has no CPU path)')

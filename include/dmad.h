@@ -101,6 +101,15 @@ int dmad_mel_db(dmad_engine* e, const float* x, int32_t B, float* spec, dmad_str
 int dmad_mel_power(dmad_engine* e, const float* x, int32_t B, float* mel, dmad_stream s);
 int dmad_power_to_db(dmad_engine* e, const float* x, int64_t n, float* y, dmad_stream s);
 
+/* DiffWave.forward = _diffusion + _reverse in one call (diffwave_ddpm.py:36-104) with on-device Philox noise keyed
+ * (seed, sample0 + row; stream 0xD1FF for the diffusion draw, 1 + t for reverse step t):
+ *   x <- c_a * x0 + c_b * z;  for t = t_star-1 .. 0:  x <- (x - c_eps[t] * eps(x, t)) / c_div[t] (+ c_sig[t] * z_t, t > 0).
+ * c_a = sqrt(Alpha_bar[t*-1]), c_b = sqrt(1 - Alpha_bar[t*-1]); c_eps / c_div / c_sig: HOST fp32 arrays of t_star
+ * entries ((1 - Alpha[t]) / sqrt(1 - Alpha_bar[t]), sqrt(Alpha[t]), Sigma[t]), computed by the caller from the fp32
+ * tables as the reference does.  x0, out: device fp32 [B][clip_len] (may alias). */
+int dmad_ddpm_purify(dmad_engine* e, const float* x0, int32_t t_star, float c_a, float c_b, const float* c_eps, const float* c_div,
+                     const float* c_sig, uint64_t seed, uint64_t sample0, int32_t B, float* out, dmad_stream s);
+
 /* Improved-Diffusion UNet purifier on 1x32x32 mel spectrograms (the reference's configuration C5:
  * diffusion_models/improved_diffusion_ddpm.py:64-93 -> improved_diffusion/script_util.py:11-34,100-131).  Weights: the
  * reference's UNetModel state dict, names prefixed "un." (un.time_embed.0.weight, un.input_blocks.5.0.in_layers.2.weight,

@@ -625,6 +625,10 @@ def test_config2_ddpm_batch256_vgg(big_engine):
     den._draws = 128
     assert torch.equal(den(x[128:]), pur[128:])                                # second half alone == second half of the batch
     assert torch.equal(model(x, defend=False), net(MelSpectrogramDB(eng)(x)))  # defend=False bypasses the purifier
+    den._draws = 40                                                            # the one-call chain (dmad_ddpm_purify) == the
+    x_t = den._diffusion(x[40:44])                                             # step-by-step surfaces with the same noise keys
+    den._draws = 40
+    assert torch.equal(den._reverse(x_t), pur[40:44])
 
 
 def test_config3_certify_n1000(big_engine):
