@@ -744,3 +744,29 @@ def test_other_wavenet_geometry(orc):
         got = eng.wavenet_eps(x.cuda(), 12).cpu().numpy()
         assert relmax(got, ref) < tol, prec
         eng.close()
+
+
+def test_bench_contract():
+    """bench.py prints ONE JSON line with the driver's keys; `metric` is BASELINE.json's; roofline and (at N = 1) cpu_baseline
+    objects are present and consistent (tiny run: 1 step of 8 samples, 2-sample CPU leg)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--samples-per-step', '8',
+                        '--max-batch', '8', '--cpu-samples', '2'], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    base = json.load(open(os.path.join(root, 'BASELINE.json')))
+    assert j['metric'] == base['metric'] and j['unit'] == 'clips/s' and j['n_gpus'] == 1 and j['steps'] == 1 and j['warmup'] == 1
+    assert j['higher_is_better'] is True and j['scaling'] == 'weak' and j['vs_baseline'] is None and j['dtype'] == 'bf16' and j['data'] == 'synthetic'
+    assert 'workload' in j['config'] and 'model' not in j['config']
+    assert abs(j['value'] - 8 / (j['ms_per_step'] * 1e-3)) < 1e-6 * j['value']
+    rf = j['roofline']
+    assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and rf['peak'] == 2500.0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12
+    assert rf['launches_timed'] == 35 and rf['achieved'] > 0 and (rf['traffic'] is None or rf['traffic'] > 0)
+    cb = j['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['unit'] == 'clips/s' and cb['value'] > 0 and 1 <= cb['cores'] <= 16 and 'sample' in cb
+    assert sum(j['votes']) == 8
