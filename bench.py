@@ -2,48 +2,68 @@
 """bench.py — certified-smoothing throughput of the HIP path on N MI355X GPUs of one node.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+One process per GPU over RCCL.  Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(WORLD_SIZE set) this process is one rank.  Started plainly with --gpus N > 1 (WORLD_SIZE unset) the parent — before any
+HIP call — starts the N ranks itself as a CHILD `python -m torch.distributed.run` process, forwards rank 0's single
+JSON line and exits with the child's code; fewer than N visible GPUs is an error, never a silent single-rank run.
 
 Workload (BASELINE.json `metric`): purified+classified 1 s clips/s of the Monte Carlo loop of
-RobustCertificate.smooth_predict at sigma = 0.5 (t* = 66): Philox noise -> sqrt(alpha_bar*) scale ->
-DiffWave one-shot purification (36-layer WaveNet, bf16 MFMA) -> mel dB -> VGG19_bn -> arg-max votes,
-N = 100 000 samples per certified clip.  One STEP = `--samples-per-step` (default 512) Monte Carlo
-samples per GPU through dmad_smooth_votes + the vote all-reduce (RCCL int64[10]) — weak scaling: every
-rank works on its own shard of the sample index range; steps = 196 at 512 samples/step is one full
-N = 100 000 certification on one GPU.  Inputs (clip, weights) are resident in HBM before the timed region.
+RobustCertificate.smooth_predict at sigma = 0.5 (t* = 66): Philox noise -> sqrt(alpha_bar*) scale -> DiffWave one-shot
+purification (36-layer WaveNet) -> mel dB -> VGG19_bn -> arg-max votes, N = 100 000 samples per certified clip.
+One STEP = `--samples-per-step` (default 512) Monte Carlo samples per GPU through dmad_smooth_votes + the vote
+all-reduce (RCCL int64[10]) — weak scaling: every rank works on its own shard of the sample index range; 196 steps of
+512 samples are one full N = 100 000 certification on one GPU.  Clip and weights are resident in HBM before the timed region.
 
-The JSON line also carries
-  roofline     — the dominant kernel (wn_layer_bf16): algorithmic FLOPs per launch / average launch
-                 duration measured live with HIP event pairs on the launch stream over the timed steps,
-                 against the dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s);
-  cpu_baseline — the CPU oracle (a restatement of the reference's arithmetic, kind "port") timed on the
-                 host cores of the same box on a bounded sample (rank 0, N = 1 only).
+`value` is measured in the engine's EXACT-VOTE mode (the drop-in default): f16-operand MFMA WaveNet, and every sample
+whose top-2 logit margin is below the recheck bound is re-evaluated on the exact-fp32 WaveNet from the same Philox key,
+so the vote counts equal the fp32 path's.  The line also carries
+  fast_mode / fp32_mode — the same step with the recheck off (16-bit path alone) and on the exact-fp32 path alone;
+  roofline       — the dominant kernel (wn_layer_p): algorithmic FLOPs per launch / average launch duration measured
+                   live with HIP event pairs on the launch stream over the timed steps, against the dense 16-bit MFMA peak
+                   (MI355X_MICROARCH.md: ~2.5 PFLOP/s);
+  roofline_final — the tail kernel (wn_final_p, HBM-bound: reads the 295 MB/clip gate store once) against 8 TB/s;
+  cpu_baseline   — the CPU oracle (a restatement of the reference's arithmetic, kind "port") timed on the host cores of
+                   the same box on a bounded sample (rank 0, N = 1 only);
+  certify_full   — with --full: RobustCertificate.certify(x, n_0=100, n=100000, sigma) through the host mirror (the
+                   surface the reference's driver calls, scripts/certified_robust_eval.sh:3-6), timed end to end.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(ROOT, 'diffusion-model-for-audio-defense_amd'), ROOT]
 
-import torch  # noqa: E402
-
-PEAK_BF16_TFLOPS = 2500.0
-# HBM-side bytes per clip per wn_layer_bf16_p launch from the rocprofv3 PMC passes committed under profiles/
-# (FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, see profiles/r01h_kernel_stats.md); None if the file is absent
-try:
-    with open(os.path.join(ROOT, 'profiles', 'r01h_layer_traffic.json')) as _f:
-        LAYER_TRAFFIC_PER_CLIP = float(json.load(_f)['layer_traffic_bytes_per_clip'])
-except Exception:
-    LAYER_TRAFFIC_PER_CLIP = None
+PEAK_MFMA16_TFLOPS = 2500.0
+PEAK_FP32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
 L = 16000
 LAYER_FLOP_PER_CLIP = 2.0 * L * (512 * 768 + 256 * 256)       # dilated conv + res conv of one layer (see DESIGN.md)
+FINAL_BYTES_PER_CLIP = 36 * 256 * 2.0 * L + 4.0 * L            # gate store read once + eps written (see DESIGN.md)
+CLIP_FLOP = 606.94e9
+
+
+def layer_traffic_per_clip():
+    """HBM-side bytes per clip per wn_layer launch from the newest rocprofv3 PMC passes committed under profiles/
+    (2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE); (None, None) if no such file exists."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_layer_traffic.json')), reverse=True):
+        try:
+            with open(path) as f:
+                return float(json.load(f)['layer_traffic_bytes_per_clip']), os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline(n_samples: int):
     """oracle/dmad_oracle.py timed on the host cores: the checker's leg, never the measured product."""
+    import torch
     from dmad_hip import synth
     from oracle import dmad_oracle as orc
     threads = os.cpu_count() or 1
@@ -72,6 +92,29 @@ def cpu_baseline(n_samples: int):
                       "(torch CPU fp32), %.1f s" % (n_samples, min(4, n_samples), dt)}
 
 
+def spawn_ranks(n: int) -> int:
+    """Parent of a plain `python bench.py --gpus N`: start the N ranks as a child torch.distributed.run process."""
+    import torch
+    have = torch.cuda.device_count()          # counts devices without initialising HIP in this process
+    if have < n:
+        sys.stderr.write('bench.py: --gpus %d but only %d GPU(s) are visible; refusing to run fewer ranks than asked\n' % (n, have))
+        return 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{')]
+    if lines:
+        print(lines[-1], flush=True)
+    else:
+        sys.stderr.write(proc.stdout)
+    return proc.returncode if proc.returncode else (0 if lines else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -81,15 +124,31 @@ def main():
     ap.add_argument('--max-batch', type=int, default=512,
                     help='clips per engine launch; 512 = one launch chain per step (gate store 151 GB of the 288 GB HBM)')
     ap.add_argument('--sigma', type=float, default=0.5)
+    ap.add_argument('--mode', choices=['exact', 'fast', 'fp32'], default='exact',
+                    help='what `value` measures: exact = 16-bit path + fp32 recheck of the close votes (the drop-in default), '
+                         'fast = 16-bit path alone, fp32 = the exact-fp32 path alone')
+    ap.add_argument('--half', choices=['f16', 'bf16'], default='f16', help='operand format of the 16-bit MFMA path')
+    ap.add_argument('--recheck-margin', type=float, default=None, help='override the engine default recheck bound')
+    ap.add_argument('--recheck-batch', type=int, default=64)
+    ap.add_argument('--side-steps', type=int, default=None, help='steps of the two side measurements (fast / exact, fp32); 0 = skip')
     ap.add_argument('--cpu-samples', type=int, default=6)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--full', action='store_true', help='also time certify(n_0=100, n=100000) through the host mirror (about 80 s)')
+    ap.add_argument('--full-n', type=int, default=100000)
     ap.add_argument('--classifier', choices=['vgg19_bn', 'resnext29'], default='vgg19_bn',
                     help='vgg19_bn = the configuration BASELINE.json names; resnext29 = the reference script\'s default classifier')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))      # nothing in this process has touched the GPU
+
+    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)'
+                         % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
     # DMAD_BENCH_BACKEND=gloo is a rehearsal switch only (several ranks sharing one GPU of a 1-GPU box); the measured
@@ -97,6 +156,8 @@ def main():
     backend = os.environ.get('DMAD_BENCH_BACKEND', 'nccl')
     if backend == 'gloo':
         local_rank %= torch.cuda.device_count()
+    elif torch.cuda.device_count() < world:
+        raise SystemExit('bench.py: %d ranks but %d visible GPU(s)' % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -106,25 +167,25 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     from dmad_hip import engine as E, synth
     from diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    half = E.HALF_F16 if args.half == 'f16' else E.HALF_BF16
     eng = None
     for mb in sorted({args.max_batch, min(args.max_batch, 256), min(args.max_batch, 128)}, reverse=True):
-        try:                                   # 512 clips per launch chain needs ~165 GB of HBM: step down if it is not free
-            eng = E.Engine(max_batch=mb, precision=E.BF16)
+        try:                                   # 512 clips per launch chain needs ~170 GB of HBM: step down if it is not free
+            eng = E.Engine(max_batch=mb, precision=E.EXACT, half_type=half, recheck_batch=min(args.recheck_batch, mb),
+                           recheck_margin=args.recheck_margin)
             args.max_batch = mb
             break
         except E.DmadError as exc:
             print('bench: engine batch %d not available (%s)' % (mb, exc), file=sys.stderr, flush=True)
     if eng is None:
         raise SystemExit('bench.py: could not create the engine')
-    eng.load_wavenet(synth.wavenet_state_dict(1234))
-    if args.classifier == 'resnext29':
-        eng.load_resnext29(synth.resnext29_state_dict(2929))
-    else:
-        eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321))
+    wsd = synth.wavenet_state_dict(1234)
+    eng.load_wavenet(wsd)
+    csd = synth.resnext29_state_dict(2929) if args.classifier == 'resnext29' else synth.vgg19_bn_state_dict(4321)
+    (eng.load_resnext29 if args.classifier == 'resnext29' else eng.load_vgg19_bn)(csd)
     hp = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
     ab = hp['Alpha_bar']
     sigma = args.sigma
@@ -135,6 +196,7 @@ def main():
     clip = torch.from_numpy(synth.synthetic_clip(0)).cuda()
     S = args.samples_per_step
     total = torch.zeros(10, dtype=torch.int64, device='cuda')
+    MODES = {'exact': E.MODE_EXACT_VOTES, 'fast': E.MODE_FAST, 'fp32': E.MODE_FP32}
 
     def step(i):
         # global sample index range of this step: [i*S*world, (i+1)*S*world), rank r takes its slice
@@ -154,53 +216,130 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    chunks_per_step = (S + args.max_batch - 1) // args.max_batch
-    fence()
-    eng.profile_layers(args.steps * chunks_per_step * 35)
-    total.zero_()
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    layer_ms, launches = eng.profile_read()
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device='cpu' if backend == 'gloo' else 'cuda')
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    votes = total.cpu().tolist()
-    assert sum(votes) == args.steps * S * world, 'vote conservation violated: %s' % votes
+    def timed(mode, steps, warmup, first_step, profile=False):
+        """`steps` timed steps in `mode`; -> (seconds (max over ranks), votes, recheck fraction, layer/final timings)."""
+        eng.set_mode(MODES[mode])
+        for i in range(warmup):
+            step(first_step + i)
+        fence()
+        chunks_per_step = (S + args.max_batch - 1) // args.max_batch
+        if profile:
+            eng.profile_layers(steps * chunks_per_step * 35)
+        eng.recheck_stats(reset=True)
+        total.zero_()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(first_step + warmup + i)
+        fence()
+        dt = time.perf_counter() - t0
+        prof = None
+        if profile:
+            fin = eng.profile_read_final()
+            prof = (eng.profile_read(), fin)
+        if dist is not None:
+            tmax = torch.tensor([dt], dtype=torch.float64, device='cpu' if backend == 'gloo' else 'cuda')
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        votes = total.cpu().tolist()
+        assert sum(votes) == steps * S * world, 'vote conservation violated: %s' % votes
+        voted, rechecked = eng.recheck_stats()
+        return dt, votes, (rechecked / voted if voted else 0.0), prof
+
+    # ---- the measured region: exactly --steps steps after --warmup untimed ones, in --mode --------------------------
+    dt, votes, recheck_frac, prof = timed(args.mode, args.steps, args.warmup, 0, profile=(args.mode != 'fp32'))
+    clips = args.steps * S * world
+    # ---- side measurements on the same engine (outside the timed region) -----------------------------------------
+    side = {}
+    side_steps = args.side_steps if args.side_steps is not None else (4 if world == 1 else 0)
+    first = args.warmup + args.steps
+    if side_steps > 0:
+        for mode, k in (('fast', side_steps), ('exact', side_steps), ('fp32', max(1, side_steps // 4))):
+            if mode == args.mode:
+                continue
+            sdt, svotes, sfrac, _ = timed(mode, k, 1, first)
+            first += k + 1
+            side[mode] = {"clips_per_s": k * S * world / sdt, "steps": k, "votes": svotes}
+            if mode == 'exact':
+                side[mode]["recheck_frac"] = sfrac
+            if mode == 'fp32':
+                side[mode]["tflops"] = k * S / sdt * CLIP_FLOP / 1e12
+                side[mode]["frac_of_fp32_matrix_peak"] = side[mode]["tflops"] / PEAK_FP32_TFLOPS
+
+    full = None
+    if args.full and args.classifier == 'vgg19_bn':
+        # the surface the reference's driver calls: RobustCertificate.certify through the host mirror, n_0 pass included
+        from audio_models.ConvNets_SpeechCommands.models.vgg import vgg19_bn
+        from diffusion_models.diffwave_ddpm import DiffWave, WaveNetHIP
+        from dmad_hip.transforms import MelSpectrogramDB
+        from robustness_eval.certified_robust import RobustCertificate
+        eng.set_mode(MODES[args.mode])
+        den = DiffWave(WaveNetHIP(eng), hp)
+        clf = vgg19_bn(num_classes=10, in_channels=1).eval()
+        clf.load_state_dict({k: torch.from_numpy(v) for k, v in csd.items()})
+        clf.bind_engine(eng)
+        rc = RobustCertificate(classifier=clf, transform=MelSpectrogramDB(eng), denoiser=den, seed=2024)
+        assert rc._fused()
+        x = clip.reshape(1, 1, L)
+        rc.certify(x, torch.tensor([0], device='cuda'), sigma=sigma, n_0=100, n=1024, batch_size=args.max_batch)   # warm-up
+        eng.recheck_stats(reset=True)
+        fence()
+        t0 = time.perf_counter()
+        y_pred, radius = rc.certify(x, torch.tensor([0], device='cuda'), sigma=sigma, n_0=100, n=args.full_n, batch_size=args.max_batch)
+        fence()
+        fdt = time.perf_counter() - t0
+        voted, rechecked = eng.recheck_stats()
+        full = {"seconds": fdt, "clips_per_s": (100 + args.full_n) * 1.0 / fdt, "n_0": 100, "n": args.full_n, "n_gpus": world,
+                "y_pred": int(y_pred[0]), "radius": float(radius[0]), "recheck_frac": rechecked / max(voted, 1),
+                "vs_steady_state": ((100 + args.full_n) / fdt) / (clips / dt)}
 
     if rank == 0:
-        clips = args.steps * S * world
-        # launches of a step's last (possibly smaller) chunk carry fewer clips: weight by clips
-        clips_per_launch = (args.steps * S) / (launches / 35.0) if launches else 0.0
-        avg_ms = layer_ms / launches if launches else float('nan')
-        achieved = LAYER_FLOP_PER_CLIP * clips_per_launch / (avg_ms * 1e-3) / 1e12 if launches else float('nan')
         out = {
             "metric": "purified+classified 1s clips/sec at N=100k sigma=0.5; 1/2/4/8 GPUs",
             "value": clips / dt, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": {"exact": args.half, "fast": args.half, "fp32": "f32"}[args.mode], "data": "synthetic",
             "config": {"workload": "certified smoothing N=100000 sigma=%.2f (t*=%d): DiffWave one-shot purify (36x256 WaveNet) "
                                    "+ mel-dB + %s + votes; step = %d Monte Carlo samples per GPU, %d steps = one "
                                    "N=100000 clip" % (sigma, t + 1, 'VGG19_bn' if args.classifier == 'vgg19_bn' else 'ResNeXt29', S, -(-100000 // S)),
                        "samples_per_step_per_gpu": S, "engine_batch": args.max_batch, "sigma": sigma, "t_star": t + 1,
+                       "mode": {"exact": "exact-vote: %s MFMA WaveNet + exact-fp32 re-evaluation of samples with top-2 logit margin < %.3g "
+                                         "(counts equal the fp32 path's)" % (args.half, eng.recheck_margin),
+                                "fast": "%s MFMA WaveNet alone (no recheck)" % args.half, "fp32": "exact-fp32 WaveNet alone"}[args.mode],
                        "noise": "device Philox4x32-10", "classifier": "VGG19_bn (synthetic seed 4321)" if args.classifier == 'vgg19_bn' else "ResNeXt29 8x64d (synthetic seed 2929)",
                        "parallelism": "mc-samples sharded x%d, one int64[10] all-reduce per step" % world},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS,
-                         "traffic": (LAYER_TRAFFIC_PER_CLIP * clips_per_launch if LAYER_TRAFFIC_PER_CLIP else None),
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r01h_kernel_stats.md "
-                                           "(2 x FETCH_SIZE + WRITE_SIZE, bytes per launch)",
-                         "kernel": "wn_layer_bf16", "avg_launch_ms": avg_ms, "launches_timed": launches,
-                         "flop_per_launch": LAYER_FLOP_PER_CLIP * clips_per_launch},
-            "end_to_end_tflops": clips / dt / world * 606.94e9 / 1e12,
+            "end_to_end_tflops": clips / dt / world * CLIP_FLOP / 1e12,
             "votes": votes,
         }
+        if args.mode == 'exact':
+            out["recheck"] = {"margin": eng.recheck_margin, "frac": recheck_frac, "fp32_batch": min(args.recheck_batch, args.max_batch)}
+        if prof is not None:
+            (layer_ms, launches), (final_ms, flaunches) = prof
+            # launches of a step's last (possibly smaller) chunk and of the recheck passes carry fewer clips; the recheck
+            # passes run on the fp32 path and are not bracketed, so every bracketed launch belongs to a 16-bit chunk
+            clips_per_launch = (args.steps * S) / (launches / 35.0) if launches else 0.0
+            avg_ms = layer_ms / launches if launches else float('nan')
+            achieved = LAYER_FLOP_PER_CLIP * clips_per_launch / (avg_ms * 1e-3) / 1e12 if launches else float('nan')
+            traffic, traffic_file = layer_traffic_per_clip()
+            out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_MFMA16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": achieved / PEAK_MFMA16_TFLOPS,
+                               "traffic": (traffic * clips_per_launch if traffic else None),
+                               "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/%s "
+                                                  "(2 x FETCH_SIZE + WRITE_SIZE, bytes per launch)" % traffic_file) if traffic else None,
+                               "kernel": "wn_layer_p<%s>" % ('_Float16' if args.half == 'f16' else '__bf16'), "avg_launch_ms": avg_ms,
+                               "launches_timed": launches, "flop_per_launch": LAYER_FLOP_PER_CLIP * clips_per_launch}
+            if flaunches:
+                fclips = (args.steps * S) / flaunches
+                favg = final_ms / flaunches
+                fach = FINAL_BYTES_PER_CLIP * fclips / (favg * 1e-3) / 1e9
+                out["roofline_final"] = {"bound": "hbm", "achieved": fach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": fach / PEAK_HBM_GBS,
+                                         "traffic": None, "kernel": "wn_final_p", "avg_launch_ms": favg, "launches_timed": flaunches,
+                                         "bytes_per_launch": FINAL_BYTES_PER_CLIP * fclips,
+                                         "matrix_tflops_same_launch": 2.0 * L * 256 * (36 * 256 + 256) * fclips / (favg * 1e-3) / 1e12}
+        for mode, rec in side.items():
+            out[mode + "_mode"] = rec
+        if full is not None:
+            out["certify_full"] = full
         if world == 1 and not args.no_cpu_baseline and args.classifier == 'vgg19_bn':
             out["cpu_baseline"] = cpu_baseline(args.cpu_samples)
         print(json.dumps(out), flush=True)

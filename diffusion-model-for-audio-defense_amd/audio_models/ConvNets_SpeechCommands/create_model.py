@@ -19,11 +19,15 @@ for _p in (os.path.join(os.path.dirname(_HERE), 'M5'), _HERE):
 
 
 def _allowed_globals():
+    """Everything a pickled M5 / DataParallel(VGG) / DataParallel(CifarResNeXt) module references: the model classes of
+    this package (same module paths as the reference's: `M5Net`, `models.vgg`, `models.resnext`) and the torch.nn layers
+    they are built from.  certified_robustness_eval.py:57-59 loads the ResNeXt29 checkpoint by default."""
     import M5Net
-    from models import vgg
+    from models import resnext, vgg
     nn = torch.nn
-    return [M5Net.M5, vgg.VGG, nn.DataParallel, nn.Sequential, nn.Conv1d, nn.Conv2d, nn.BatchNorm1d, nn.BatchNorm2d,
-            nn.MaxPool1d, nn.MaxPool2d, nn.ReLU, nn.Dropout, nn.Linear, set, collections.OrderedDict]
+    return [M5Net.M5, vgg.VGG, resnext.CifarResNeXt, resnext.ResNeXtBottleneck, nn.DataParallel, nn.Sequential, nn.ModuleList,
+            nn.Conv1d, nn.Conv2d, nn.BatchNorm1d, nn.BatchNorm2d, nn.MaxPool1d, nn.MaxPool2d, nn.AvgPool2d, nn.AdaptiveAvgPool2d,
+            nn.ReLU, nn.Dropout, nn.Linear, nn.Identity, set, collections.OrderedDict, torch.device]
 
 
 def create_model(path):

@@ -43,11 +43,11 @@ class VGG(nn.Module):
 
     # -- HIP engine binding ---------------------------------------------------------------------
     def bind_engine(self, engine=None):
-        """Fold BatchNorm (eval statistics) and upload the weights into the engine (once)."""
+        """Fold BatchNorm (eval statistics) and upload the weights into the engine (once).  An explicit `engine` that
+        already holds ANOTHER classifier is refused (DmadError); the shared engine in that case is left alone and this
+        module gets an engine of its own."""
         from dmad_hip import engine as _eng
-        eng = engine or _eng.get_engine()
-        if not eng.has_classifier:
-            eng.load_vgg19_bn(self.state_dict())
+        eng = _eng.bind_classifier(self.state_dict(), 'load_vgg19_bn', engine)
         self.__dict__['engine'] = eng
         return self
 

@@ -51,6 +51,22 @@ uint16_t f2bf(float f) {   // round-to-nearest-even, NaN stays NaN
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
+uint16_t f2h(float f) {    // fp32 -> IEEE half, round-to-nearest-even (subnormals and overflow to inf included)
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u, ax = u & 0x7fffffffu;
+    if (ax > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                 // NaN
+    if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                // >= 65520 rounds to inf
+    if (ax < 0x33000001u) return (uint16_t)sign;                             // <= 2^-25 rounds to zero
+    int e = (int)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x7fffffu) | 0x800000u;                               // 24-bit significand
+    int shift = e < -14 ? 13 + (-14 - e) : 13;                               // bits dropped (subnormal: more)
+    uint32_t h = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (h & 1u))) ++h;
+    if (e < -14) return (uint16_t)(sign | h);                                // subnormal (a carry into 0x400 is the smallest normal)
+    return (uint16_t)(sign | (uint32_t)(((e + 15) << 10) + (h - 0x400u)));   // a significand carry bumps the exponent
+}
+
 const int kVggCfg[] = {64, 64, -1, 128, 128, -1, 256, 256, 256, 256, -1, 512, 512, 512, 512, -1, 512, 512, 512, 512, -1};
 const int kVggCfgLen = sizeof(kVggCfg) / sizeof(int);
 constexpr int kMelLd = 1040;      // 1025 rFFT bins padded to a multiple of 16
@@ -67,25 +83,34 @@ struct HostW {
 struct dmad_engine {
     dmad_config cfg{};
     int L = 0, LP = 0, NL = 0, maxB = 0, LPm = 0;
-    bool bf16 = true, wn_final = false, cls_final = false;
+    bool bf16 = true, f32 = false, wn_final = false, cls_final = false;   // bf16 / f32: which WaveNet paths are resident
+    int maxB32 = 0;                        // clips per exact-fp32 WaveNet pass (== maxB for DMAD_FP32, recheck_batch for DMAD_EXACT)
+    int mode = DMAD_MODE_FAST;             // enum dmad_mode (DMAD_EXACT engines switch at run time)
+    float tau = 0.f;                       // recheck bound on the bf16 top-2 logit margin
+    long long* rc_list = nullptr;          // global indices of the samples queued for the fp32 re-evaluation
+    unsigned long long* rc_n = nullptr;    // their number (device) ...
+    unsigned long long* rc_n_host = nullptr;   // ... and its pinned host mirror
+    long rc_cap = 0;
+    int64_t st_samples = 0, st_rechecked = 0;
     std::map<std::string, HostW> hw;
     std::vector<void*> allocs;
     int64_t bytes = 0;
     int emb_t = -1;
     // optional per-launch timing of the dominant kernel (bench.py roofline): HIP event pairs on the launch stream
     bool prof_on = false;
-    std::vector<hipEvent_t> prof_ev;
-    size_t prof_used = 0;
+    std::vector<hipEvent_t> prof_ev, prof_ev_f;      // layer launches / final-kernel launches
+    size_t prof_used = 0, prof_used_f = 0;
 
     // WaveNet small fp32 params
     float *init_w = nullptr, *init_b = nullptr, *fc1w = nullptr, *fc1b = nullptr, *fc2w = nullptr, *fc2b = nullptr;
     float *fctw = nullptr, *fctb = nullptr, *emb_table = nullptr, *emb2 = nullptr, *epi_c = nullptr;
     float *bf0 = nullptr, *wz = nullptr;
     float bz = 0.f;
-    // bf16 path
-    bf16_t *w1p = nullptr, *w2p = nullptr, *wsp = nullptr, *wf0p = nullptr;
+    // 16-bit MFMA path (operands bf16, or f16 when `f16` is set)
+    bool f16 = false;
+    h16_t *w1p = nullptr, *w2p = nullptr, *wsp = nullptr, *wf0p = nullptr;
     float *b1p = nullptr, *b2 = nullptr, *bskip_sum = nullptr;
-    bf16_t *hA = nullptr, *hB = nullptr, *gstore = nullptr;
+    h16_t *hA = nullptr, *hB = nullptr, *gstore = nullptr;
     // fp32 path
     float *wdil = nullptr, *bdil = nullptr, *wrs = nullptr, *brs = nullptr, *wf0 = nullptr;
     float *hA32 = nullptr, *hB32 = nullptr, *H32 = nullptr, *g32 = nullptr, *skip32 = nullptr;
@@ -149,7 +174,7 @@ struct dmad_engine {
         HIPCHK(hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
         return 0;
     }
-    int upload_bf(bf16_t** p, const std::vector<uint16_t>& h) {
+    int upload_bf(h16_t** p, const std::vector<uint16_t>& h) {
         CHK(alloc(p, h.size()));
         HIPCHK(hipMemcpy(*p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
         return 0;
@@ -174,15 +199,15 @@ namespace {
 
 // [ksteps][rows][32] bf16 LDS image of W[row][K] (row-major, K = ksteps*32), 64-B rows, swz64 chunks
 // k-step ks of W lands in stage ks * smul + sadd of the image (GEMM1 interleaves the three taps' k-steps)
-void pack_rows(const float* W, int rows, int K, long ldw, const int* row_map, std::vector<uint16_t>& out, size_t base,
-               int smul = 1, int sadd = 0) {
+void pack_rows(uint16_t (*cvt)(float), const float* W, int rows, int K, long ldw, const int* row_map, std::vector<uint16_t>& out,
+               size_t base, int smul = 1, int sadd = 0) {
     const int ksteps = K / 32;
     for (int ks = 0; ks < ksteps; ++ks)
         for (int R = 0; R < rows; ++R) {
             const float* src = W + (long)(row_map ? row_map[R] : R) * ldw + ks * 32;
             for (int slot = 0; slot < 4; ++slot) {
                 const int c = slot ^ swz64(R);
-                for (int j = 0; j < 8; ++j) out[base + ((size_t)((ks * smul + sadd) * rows + R) * 32) + slot * 8 + j] = f2bf(src[c * 8 + j]);
+                for (int j = 0; j < 8; ++j) out[base + ((size_t)((ks * smul + sadd) * rows + R) * 32) + slot * 8 + j] = cvt(src[c * 8 + j]);
             }
         }
 }
@@ -218,6 +243,7 @@ int finalize_wavenet(dmad_engine* e) {
     CHK(e->alloc(&e->emb_table, (size_t)NL * 256)); CHK(e->alloc(&e->emb2, 512)); CHK(e->alloc(&e->epi_c, (size_t)NL * 256, true));
 
     if (e->bf16) {
+        uint16_t (*cvt)(float) = e->f16 ? f2h : f2bf;
         int rmap[512];
         // tile row R = wm*128 + half*64 + mt*16 + i  <->  gate row half*256 + (mt*64 + wm*16 + i): channel ownership is
         // interleaved over the M-waves so that GEMM2 can start on channels [64 mt, 64 mt + 64) as soon as tiles mt are gated
@@ -237,20 +263,21 @@ int finalize_wavenet(dmad_engine* e) {
                 for (int oc = 0; oc < 512; ++oc)
                     for (int ci = 0; ci < 256; ++ci)     // rows pre-scaled to exp2 arguments: tanh half by -2*log2(e), sigmoid half by -log2(e)
                         tapw[(size_t)oc * 256 + ci] = dw[((size_t)oc * 256 + ci) * 3 + tap] * (oc < 256 ? -2.8853900817779268f : -1.4426950408889634f);
-                pack_rows(tapw.data(), 512, 256, 256, rmap, w1p, (size_t)n * 24 * 512 * 32, 3, tap);   // stage = 3 * kchunk + tap
+                pack_rows(cvt, tapw.data(), 512, 256, 256, rmap, w1p, (size_t)n * 24 * 512 * 32, 3, tap);   // stage = 3 * kchunk + tap
             }
             for (int R = 0; R < 512; ++R) b1p[(size_t)n * 512 + R] = db[rmap[R]];
             std::vector<float> rws(rw.size());                      // res conv pre-scaled by sqrt(1/2): h' = h*sqrt(1/2) + (W_res' g + c)
             for (size_t i = 0; i < rw.size(); ++i) rws[i] = rw[i] * 0.70710678118654752440f;
-            pack_rows(rws.data(), 256, 256, 256, nullptr, w2p, (size_t)n * 8 * 256 * 32);
-            pack_rows(sw.data(), 256, 256, 256, nullptr, wsp, (size_t)n * 8 * 256 * 32);
+            pack_rows(cvt, rws.data(), 256, 256, 256, nullptr, w2p, (size_t)n * 8 * 256 * 32);
+            pack_rows(cvt, sw.data(), 256, 256, 256, nullptr, wsp, (size_t)n * 8 * 256 * 32);
             for (int c = 0; c < 256; ++c) { b2[(size_t)n * 256 + c] = rb[c]; bsum[c] += sb[c]; }
         }
-        pack_rows(f0w.data(), 256, 256, 256, nullptr, wf0p, 0);
+        pack_rows(cvt, f0w.data(), 256, 256, 256, nullptr, wf0p, 0);
         CHK(e->upload_bf(&e->w1p, w1p)); CHK(e->upload_bf(&e->w2p, w2p)); CHK(e->upload_bf(&e->wsp, wsp));
         CHK(e->upload_bf(&e->wf0p, wf0p));
         CHK(e->upload(&e->b1p, b1p)); CHK(e->upload(&e->b2, b2)); CHK(e->upload(&e->bskip_sum, bsum));
-    } else {
+    }
+    if (e->f32) {
         std::vector<float> wdil((size_t)NL * 3 * 512 * 256), bdil((size_t)NL * 512), wrs((size_t)NL * 512 * 256), brs((size_t)NL * 512);
         for (int n = 0; n < NL; ++n) {
             char nm[64];
@@ -260,11 +287,15 @@ int finalize_wavenet(dmad_engine* e) {
             snprintf(nm, sizeof nm, "res.%d.b", n); GETW(rb, nm, 256)
             snprintf(nm, sizeof nm, "skip.%d.w", n); GETW(sw, nm, 256, 256)
             snprintf(nm, sizeof nm, "skip.%d.b", n); GETW(sb, nm, 256)
+            // gate-fused epilogue (gemm_f32.h, epi 1): image row R of block bm holds H row (i >= 2 ? 256 : 0) + bm*64 + wm*32 + (i&1)*16 + r
             for (int tap = 0; tap < 3; ++tap)
-                for (int oc = 0; oc < 512; ++oc)
+                for (int R = 0; R < 512; ++R) {
+                    const int bm = R / 128, wmr = (R % 128) / 64, i = (R % 64) / 16, rr = R % 16;
+                    const int oc = (i >= 2 ? 256 : 0) + bm * 64 + wmr * 32 + (i & 1) * 16 + rr;
                     for (int ci = 0; ci < 256; ++ci)
-                        wdil[(((size_t)n * 3 + tap) * 512 + oc) * 256 + ci] = dw[((size_t)oc * 256 + ci) * 3 + tap];
-            memcpy(&bdil[(size_t)n * 512], db.data(), 2048);
+                        wdil[(((size_t)n * 3 + tap) * 512 + R) * 256 + ci] = dw[((size_t)oc * 256 + ci) * 3 + tap];
+                    if (tap == 0) bdil[(size_t)n * 512 + R] = db[oc];
+                }
             memcpy(&wrs[(size_t)n * 512 * 256], rw.data(), 256 * 256 * 4);
             memcpy(&wrs[(size_t)n * 512 * 256 + 256 * 256], sw.data(), 256 * 256 * 4);
             memcpy(&brs[(size_t)n * 512], rb.data(), 1024);
@@ -684,14 +715,24 @@ GemmF32Args plain_gemm(const float* A, const float* X, float* C, const float* sc
     return g;
 }
 
-int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipStream_t s) {
+// exact32: evaluate on the exact-fp32 path (the only one of a DMAD_FP32 engine; DMAD_MODE_FP32 and the recheck pass of a
+// DMAD_EXACT engine); batches larger than the fp32 workspace are walked in chunks of maxB32 clips
+int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipStream_t s, bool exact32 = false) {
     if (!e->wn_final) return fail(DMAD_ERR_STATE, "WaveNet weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
     if (B < 1 || B > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d]", B, e->maxB);
     if (t < 0) return fail(DMAD_ERR_INVALID, "diffusion step %d < 0", t);
     CHK(ensure_embed(e, t, s));
     const int L = e->L, LP = e->LP, NL = e->NL;
-    if (e->bf16) {
-        launch_wn_init_bf16(x_t, e->init_w, e->init_b, e->emb_table, e->hA, B, L, LP, s);
+    const bool use32 = !e->bf16 || (e->f32 && (exact32 || e->mode == DMAD_MODE_FP32));
+    if (use32 && B > e->maxB32) {
+        for (int b0 = 0; b0 < B; b0 += e->maxB32) {
+            const int bb = B - b0 < e->maxB32 ? B - b0 : e->maxB32;
+            CHK(wavenet_eps(e, x_t + (size_t)b0 * L, t, bb, eps + (size_t)b0 * L, s, true));
+        }
+        return 0;
+    }
+    if (!use32) {
+        launch_wn_init_bf16(x_t, e->init_w, e->init_b, e->emb_table, e->hA, B, L, LP, e->f16, s);
         for (int n = 0; n < NL; ++n) {
             WnLayerArgs a{};
             a.hin = (n & 1) ? e->hB : e->hA;
@@ -705,13 +746,16 @@ int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipS
             a.L = L; a.LP = LP; a.last = (n == NL - 1); a.npos = (long)B * L;
             const bool timed = e->prof_on && !a.last && e->prof_used + 2 <= e->prof_ev.size();
             if (timed) (void)hipEventRecord(e->prof_ev[e->prof_used++], s);
-            launch_wn_layer_bf16_p(a, B, s);
+            launch_wn_layer_bf16_p(a, B, e->f16, s);
             if (timed) (void)hipEventRecord(e->prof_ev[e->prof_used++], s);
         }
         WnFinalArgs f{};
         f.g = e->gstore; f.wsp = e->wsp; f.wf0p = e->wf0p; f.bskip_sum = e->bskip_sum; f.bf0 = e->bf0; f.wz = e->wz;
         f.eps = eps; f.bz = e->bz; f.skip_scale = (float)sqrt(1.0 / NL); f.NL = NL; f.B = B; f.L = L;
-        launch_wn_final_bf16_p(f, s);
+        const bool timed_f = e->prof_on && e->prof_used_f + 2 <= e->prof_ev_f.size();
+        if (timed_f) (void)hipEventRecord(e->prof_ev_f[e->prof_used_f++], s);
+        launch_wn_final_bf16_p(f, e->f16, s);
+        if (timed_f) (void)hipEventRecord(e->prof_ev_f[e->prof_used_f++], s);
     } else {
         const long N = (long)B * L;
         launch_wn_init_f32(x_t, e->init_w, e->init_b, e->emb_table, e->hA32, B, L, LP, s);
@@ -723,12 +767,15 @@ int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipS
             g.A = e->wdil + (size_t)n * 3 * 512 * 256; g.X = hin + (size_t)kPad * kC; g.C = e->H32; g.scale = nullptr;
             g.shift = e->bdil + (size_t)n * 512; g.M = 512; g.K = 256; g.taps = 3; g.ldc = 512; g.relu = 0; g.N = N; g.mode = 0;
             g.rows_per_batch = L; g.batch_stride = (long)LP * kC; g.row_stride = kC; g.tap_stride = (long)d * kC;
+            g.epi = 1; g.C = e->g32;             // tanh * sigmoid in the epilogue: H never goes to HBM
             launch_gemm_f32(g, s);
-            launch_wn_gate_f32(e->H32, e->g32, N, s);
-            launch_gemm_f32(plain_gemm(e->wrs + (size_t)n * 512 * 256, e->g32, e->H32, nullptr, e->brs + (size_t)n * 512, 512, 256,
-                                       N, 512, 256, 0), s);
-            launch_wn_update_f32(e->H32, hin, hout, e->skip32, e->emb_table + (size_t)((n + 1 < NL) ? n + 1 : n) * 256, n == 0,
-                                 n == NL - 1, B, L, LP, s);
+            // res || skip convs with the residual update and the skip accumulation in the epilogue (2 launches per layer)
+            const bool last = n == NL - 1;
+            GemmF32Args u = plain_gemm(e->wrs + (size_t)n * 512 * 256 + (last ? 256 * 256 : 0), e->g32, nullptr, nullptr,
+                                       e->brs + (size_t)n * 512 + (last ? 256 : 0), last ? 256 : 512, 256, N, 256, 256, 0);
+            u.epi = 2; u.res_rows = last ? 0 : 256; u.first = n == 0; u.L = L; u.LP = LP;
+            u.hin = hin; u.hout = hout; u.skip = e->skip32; u.emb_next = e->emb_table + (size_t)((n + 1 < NL) ? n + 1 : n) * 256;
+            launch_gemm_f32(u, s);
         }
         launch_scale(e->skip32, (float)sqrt(1.0 / NL), e->g32, N * 256, s);
         launch_gemm_f32(plain_gemm(e->wf0, e->g32, e->H32, nullptr, e->bf0, 256, 256, N, 256, 256, 1), s);
@@ -808,7 +855,10 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     if (cfg->clip_len < 128 || cfg->clip_len % 128) return fail(DMAD_ERR_INVALID, "clip_len %d must be a positive multiple of 128", cfg->clip_len);
     if (cfg->with_classifier && cfg->clip_len != 16000) return fail(DMAD_ERR_INVALID, "the mel front-end needs clip_len = 16000");
     if (cfg->max_batch < 1) return fail(DMAD_ERR_INVALID, "max_batch must be >= 1");
-    if (cfg->precision != DMAD_BF16 && cfg->precision != DMAD_FP32) return fail(DMAD_ERR_INVALID, "unknown precision %d", cfg->precision);
+    if (cfg->precision != DMAD_BF16 && cfg->precision != DMAD_FP32 && cfg->precision != DMAD_EXACT)
+        return fail(DMAD_ERR_INVALID, "unknown precision %d", cfg->precision);
+    if (cfg->recheck_batch < 0) return fail(DMAD_ERR_INVALID, "recheck_batch %d < 0", cfg->recheck_batch);
+    if (cfg->half_type != DMAD_HALF_BF16 && cfg->half_type != DMAD_HALF_F16) return fail(DMAD_ERR_INVALID, "unknown half_type %d", cfg->half_type);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(DMAD_ERR_HIP, "no HIP device visible");
@@ -816,12 +866,18 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     e->cfg = *cfg;
     e->L = cfg->clip_len; e->LP = cfg->clip_len + 2 * kPad; e->NL = cfg->num_res_layers; e->maxB = cfg->max_batch;
     e->LPm = cfg->clip_len + 2048;
-    e->bf16 = cfg->precision == DMAD_BF16;
+    e->bf16 = cfg->precision != DMAD_FP32;
+    e->f32 = cfg->precision != DMAD_BF16;
+    e->f16 = cfg->half_type == DMAD_HALF_F16;
+    e->maxB32 = cfg->precision == DMAD_FP32 ? cfg->max_batch : (cfg->recheck_batch > 0 ? cfg->recheck_batch : 32);
+    if (e->maxB32 > cfg->max_batch) e->maxB32 = cfg->max_batch;
+    e->mode = cfg->precision == DMAD_EXACT ? DMAD_MODE_EXACT_VOTES : (cfg->precision == DMAD_FP32 ? DMAD_MODE_FP32 : DMAD_MODE_FAST);
+    e->tau = 0.5f;                          // default recheck bound; callers set the measured one (dmad_set_recheck_margin)
     if (e->bf16 && !wn_final_p_supported(cfg->num_res_layers)) {
         delete e;
         return fail(DMAD_ERR_INVALID, "bf16 path does not support num_res_layers = %d", cfg->num_res_layers);
     }
-    const size_t B = e->maxB, L = e->L, LP = e->LP, NL = e->NL;
+    const size_t B = e->maxB, L = e->L, LP = e->LP, NL = e->NL, B32 = e->maxB32;
     int r = 0;
     do {
         if ((r = e->alloc(&e->xt, B * L))) break;
@@ -833,12 +889,20 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
             if ((r = e->alloc(&e->hB, B * LP * kC, true))) break;
             if ((r = e->alloc(&e->gstore, NL * B * L * kC))) break;
             if ((r = wn_bf16_configure())) { r = fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %d", r); break; }
-        } else {
-            if ((r = e->alloc(&e->hA32, B * LP * kC, true))) break;
-            if ((r = e->alloc(&e->hB32, B * LP * kC, true))) break;
-            if ((r = e->alloc(&e->H32, B * L * 512))) break;
-            if ((r = e->alloc(&e->g32, B * L * 256))) break;
-            if ((r = e->alloc(&e->skip32, B * L * 256))) break;
+        }
+        if (e->f32) {
+            if ((r = e->alloc(&e->hA32, B32 * LP * kC, true))) break;
+            if ((r = e->alloc(&e->hB32, B32 * LP * kC, true))) break;
+            if ((r = e->alloc(&e->H32, B32 * L * 512))) break;
+            if ((r = e->alloc(&e->g32, B32 * L * 256))) break;
+            if ((r = e->alloc(&e->skip32, B32 * L * 256))) break;
+        }
+        if (e->bf16 && e->f32) {             // recheck queue of the exact-vote mode
+            e->rc_cap = 1l << 20;
+            if ((r = e->alloc(&e->rc_list, (size_t)e->rc_cap))) break;
+            if ((r = e->alloc(&e->rc_n, 1, true))) break;
+            hipError_t he = hipHostMalloc((void**)&e->rc_n_host, sizeof(unsigned long long), hipHostMallocDefault);
+            if (he != hipSuccess) { r = fail(DMAD_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(he)); break; }
         }
         if (cfg->with_classifier) {
             if ((r = e->alloc(&e->mel_xp, B * e->LPm))) break;
@@ -863,6 +927,8 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
 void dmad_destroy(dmad_engine* e) {
     if (!e) return;
     for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->prof_ev_f) (void)hipEventDestroy(ev);
+    if (e->rc_n_host) (void)hipHostFree(e->rc_n_host);
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
 }
@@ -871,30 +937,48 @@ int64_t dmad_device_bytes(const dmad_engine* e) { return e ? e->bytes : 0; }
 
 int dmad_profile_layers(dmad_engine* e, int32_t max_launches) {
     if (!e || max_launches < 0) return fail(DMAD_ERR_INVALID, "bad argument");
-    e->prof_used = 0;
+    e->prof_used = e->prof_used_f = 0;
     e->prof_on = max_launches > 0;
     while (e->prof_ev.size() < (size_t)max_launches * 2) {
         hipEvent_t ev;
         HIPCHK(hipEventCreate(&ev));
         e->prof_ev.push_back(ev);
     }
+    const size_t nf = ((size_t)max_launches + e->NL - 1) / (e->NL > 1 ? e->NL - 1 : 1) + 1;   // one final launch per NL-1 timed layer launches
+    while (e->prof_ev_f.size() < nf * 2) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreate(&ev));
+        e->prof_ev_f.push_back(ev);
+    }
+    return 0;
+}
+
+static int prof_sum(std::vector<hipEvent_t>& evs, size_t used, float* total_ms, int32_t* launches) {
+    double tot = 0.0;
+    const size_t pairs = used / 2;
+    if (pairs) HIPCHK(hipEventSynchronize(evs[used - 1]));
+    for (size_t i = 0; i < pairs; ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, evs[2 * i], evs[2 * i + 1]));
+        tot += ms;
+    }
+    *total_ms = (float)tot;
+    *launches = (int32_t)pairs;
     return 0;
 }
 
 int dmad_profile_read(dmad_engine* e, float* total_ms, int32_t* launches) {
     if (!e || !total_ms || !launches) return fail(DMAD_ERR_INVALID, "null argument");
-    double tot = 0.0;
-    const size_t pairs = e->prof_used / 2;
-    if (pairs) HIPCHK(hipEventSynchronize(e->prof_ev[e->prof_used - 1]));
-    for (size_t i = 0; i < pairs; ++i) {
-        float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]));
-        tot += ms;
-    }
-    *total_ms = (float)tot;
-    *launches = (int32_t)pairs;
+    CHK(prof_sum(e->prof_ev, e->prof_used, total_ms, launches));
     e->prof_used = 0;
     e->prof_on = false;
+    return 0;
+}
+
+int dmad_profile_read_final(dmad_engine* e, float* total_ms, int32_t* launches) {
+    if (!e || !total_ms || !launches) return fail(DMAD_ERR_INVALID, "null argument");
+    CHK(prof_sum(e->prof_ev_f, e->prof_used_f, total_ms, launches));
+    e->prof_used_f = 0;
     return 0;
 }
 
@@ -1044,6 +1128,71 @@ int dmad_vote(dmad_engine* e, const float* logits, int32_t B, int64_t* counts, d
     return 0;
 }
 
+int dmad_set_mode(dmad_engine* e, int32_t mode) {
+    if (!e) return fail(DMAD_ERR_INVALID, "null engine");
+    if (!(e->bf16 && e->f32)) {
+        const int only = e->bf16 ? DMAD_MODE_FAST : DMAD_MODE_FP32;
+        if (mode == only) return 0;
+        return fail(DMAD_ERR_STATE, "mode %d needs a DMAD_EXACT engine (this one has only its %s path)", mode, e->bf16 ? "bf16" : "fp32");
+    }
+    if (mode != DMAD_MODE_FAST && mode != DMAD_MODE_EXACT_VOTES && mode != DMAD_MODE_FP32) return fail(DMAD_ERR_INVALID, "unknown mode %d", mode);
+    e->mode = mode;
+    return 0;
+}
+
+int dmad_set_recheck_margin(dmad_engine* e, float tau) {
+    if (!e) return fail(DMAD_ERR_INVALID, "null engine");
+    if (!(tau >= 0.f)) return fail(DMAD_ERR_INVALID, "recheck margin must be >= 0");
+    e->tau = tau;
+    return 0;
+}
+
+int dmad_recheck_stats(dmad_engine* e, int64_t* samples, int64_t* rechecked, int32_t reset) {
+    if (!e) return fail(DMAD_ERR_INVALID, "null engine");
+    if (samples) *samples = e->st_samples;
+    if (rechecked) *rechecked = e->st_rechecked;
+    if (reset) e->st_samples = e->st_rechecked = 0;
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+// The queued samples of an exact-vote pass, re-evaluated on the exact-fp32 WaveNet from the same noise.  Waits for the
+// stream once (the queue length decides the launches).
+struct RecheckJob {
+    const float* clip; const float* delta; float sigma, scale; int t; float c_a, c_b; uint64_t seed, sample0;
+    int64_t* counts; float* logits_out; float* x0_out;
+};
+int run_recheck(dmad_engine* e, const RecheckJob& j, hipStream_t st) {
+    HIPCHK(hipMemcpyAsync(e->rc_n_host, e->rc_n, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const long n = (long)*e->rc_n_host;
+    if (n > e->rc_cap) return fail(DMAD_ERR_STATE, "recheck queue overflow (%ld > %ld)", n, e->rc_cap);
+    const int L = e->L, C = e->cfg.num_classes;
+    for (long done = 0; done < n; done += e->maxB32) {
+        const int B = (int)(n - done < e->maxB32 ? n - done : e->maxB32);
+        const long long* idx = e->rc_list + done;
+        launch_mc_noise_scale_idx(j.clip, j.delta, j.sigma, j.scale, j.seed, j.sample0, idx, e->xt, B, L, st);
+        CHK(wavenet_eps(e, e->xt, j.t, B, e->eps, st, true));
+        launch_lincomb(0, e->xt, e->eps, nullptr, j.c_a, j.c_b, 0.f, e->x0, (long)B * L, st);
+        if (j.x0_out) launch_scatter_rows(e->x0, idx, (long long)j.sample0, j.x0_out, B, L, st);
+        CHK(mel_db(e, e->x0, B, e->spec, st));
+        CHK(classify(e, e->spec, B, e->logits, st));
+        if (j.logits_out) launch_scatter_rows(e->logits, idx, (long long)j.sample0, j.logits_out, B, C, st);
+        launch_vote(e->logits, B, C, (unsigned long long*)j.counts, nullptr, st);
+    }
+    HIPCHK(hipMemsetAsync(e->rc_n, 0, sizeof(unsigned long long), st));
+    e->st_rechecked += n;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
 int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt_alpha_bar_star, int32_t t, float c_a,
                       float c_b, int64_t n, int32_t batch, uint64_t seed, uint64_t sample0, const float* delta, int64_t* counts,
                       float* logits_out, float* x0_out, dmad_stream s) {
@@ -1052,6 +1201,8 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
     if (e->cfg.with_classifier && !counts) return fail(DMAD_ERR_INVALID, "counts must not be null");
     hipStream_t st = (hipStream_t)s;
     const int L = e->L, C = e->cfg.num_classes;
+    const bool recheck = e->bf16 && e->f32 && e->mode == DMAD_MODE_EXACT_VOTES && e->cfg.with_classifier;
+    int64_t queued_from = 0;               // first sample (relative) of the current recheck segment
     for (int64_t done = 0; done < n; done += batch) {
         const int B = (int)((n - done < batch) ? (n - done) : batch);
         launch_mc_noise_scale(clip, delta ? delta + done * L : nullptr, sigma, sqrt_alpha_bar_star, seed, sample0 + (uint64_t)done,
@@ -1063,8 +1214,53 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
             CHK(mel_db(e, x0, B, e->spec, st));
             float* lg = logits_out ? logits_out + done * C : e->logits;
             CHK(classify(e, e->spec, B, lg, st));
-            launch_vote(lg, B, C, (unsigned long long*)counts, nullptr, st);
+            if (recheck) {
+                launch_vote_margin(lg, B, C, (unsigned long long*)counts, e->tau, (long long)(sample0 + (uint64_t)done), e->rc_list, e->rc_n,
+                                   nullptr, st);
+                // the queue holds at most rc_cap indices: drain it before the samples voted since the last drain could overflow it
+                if (done + B - queued_from + batch > e->rc_cap && done + B < n) {
+                    CHK(run_recheck(e, RecheckJob{clip, delta, sigma, sqrt_alpha_bar_star, t, c_a, c_b, seed, sample0, counts, logits_out, x0_out}, st));
+                    queued_from = done + B;
+                }
+            } else {
+                launch_vote(lg, B, C, (unsigned long long*)counts, nullptr, st);
+            }
         }
+    }
+    if (recheck && n > 0)
+        CHK(run_recheck(e, RecheckJob{clip, delta, sigma, sqrt_alpha_bar_star, t, c_a, c_b, seed, sample0, counts, logits_out, x0_out}, st));
+    if (e->cfg.with_classifier) e->st_samples += n;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int dmad_query_logits(dmad_engine* e, const float* x, int32_t B, int32_t repeats, int32_t sampler, int32_t t_star, float c_a, float c_b,
+                      const float* c_eps, const float* c_div, const float* c_sig, uint64_t seed, uint64_t sample0, float* logits,
+                      int32_t* decisions, dmad_stream s) {
+    if (!e || !x || !logits) return fail(DMAD_ERR_INVALID, "null argument");
+    if (B < 1 || repeats < 1) return fail(DMAD_ERR_INVALID, "B and repeats must be >= 1");
+    if (sampler < 0 || sampler > 2) return fail(DMAD_ERR_INVALID, "unknown sampler %d (0 none, 1 DDPM, 2 one-shot)", sampler);
+    if (sampler && t_star < 1) return fail(DMAD_ERR_INVALID, "t_star %d < 1", t_star);
+    if (sampler == 1 && (!c_eps || !c_div || !c_sig)) return fail(DMAD_ERR_INVALID, "the DDPM sampler needs its coefficient arrays");
+    if (!e->cfg.with_classifier) return fail(DMAD_ERR_STATE, "engine was created with with_classifier = 0");
+    hipStream_t st = (hipStream_t)s;
+    const int L = e->L, C = e->cfg.num_classes;
+    const long rows = (long)B * repeats;
+    for (long r0 = 0; r0 < rows; r0 += e->maxB) {
+        const int nb = (int)(rows - r0 < e->maxB ? rows - r0 : e->maxB);
+        launch_repeat_rows(x, e->xt, B, r0, nb, L, st);
+        const float* pur = e->xt;
+        if (sampler == 1) {
+            CHK(dmad_ddpm_purify(e, e->xt, t_star, c_a, c_b, c_eps, c_div, c_sig, seed, sample0 + (uint64_t)r0, nb, e->x0, s));
+            pur = e->x0;
+        } else if (sampler == 2) {
+            CHK(wavenet_eps(e, e->xt, t_star - 1, nb, e->eps, st));
+            launch_lincomb(0, e->xt, e->eps, nullptr, c_a, c_b, 0.f, e->x0, (long)nb * L, st);
+            pur = e->x0;
+        }
+        CHK(mel_db(e, pur, nb, e->spec, st));
+        CHK(classify(e, e->spec, nb, logits + r0 * C, st));
+        if (decisions) launch_vote(logits + r0 * C, nb, C, nullptr, decisions + r0, st);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1104,9 +1300,9 @@ int dmad_time_layer(dmad_engine* e, int32_t layer, int32_t B, int32_t iters, flo
     }
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    launch_wn_layer_bf16_p(a, B, st, stamps);
+    launch_wn_layer_bf16_p(a, B, e->f16, st, stamps);
     HIPCHK(hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) launch_wn_layer_bf16_p(a, B, st, stamps);
+    for (int i = 0; i < iters; ++i) launch_wn_layer_bf16_p(a, B, e->f16, st, stamps);
     HIPCHK(hipEventRecord(e1, st));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -10,6 +10,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef unsigned short h16_t;    // storage type of a 16-bit operand (bf16 or f16 bits, see H16)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -34,6 +37,19 @@ __device__ inline void glds16(const void* gsrc, void* lds_dst_wave_base) {
     // async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc, (lds_ptr_t)lds_dst_wave_base, 16, 0, 0);
 }
+
+// The 16-bit MFMA path is written once for both 16-bit operand formats: bf16 (8-bit significand, the fp32 exponent range)
+// and f16 (11-bit significand: 8x smaller rounding error at the same v_mfma_f32_16x16x32 rate; the network's activations
+// are O(1), far inside the f16 range).  H16<T> = vector types + the MFMA of operand type T.
+template <typename T> struct H16;
+template <> struct H16<__bf16> {
+    typedef bf16x8 v8; typedef bf16x4 v4;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct H16<_Float16> {
+    typedef f16x8 v8; typedef f16x4 v4;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
 
 __device__ inline float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ inline float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

@@ -8,6 +8,12 @@ void launch_philox_raw(uint64_t seed, uint64_t sample, uint32_t stream, uint32_t
 void launch_philox_normal(uint64_t seed, uint64_t sample0, uint32_t stream, float* z, int B, int L, hipStream_t s);
 void launch_mc_noise_scale(const float* clip, const float* delta, float sigma, float scale, uint64_t seed, uint64_t sample0,
                            float* xt, int B, int L, hipStream_t s);
+void launch_mc_noise_scale_idx(const float* clip, const float* delta, float sigma, float scale, uint64_t seed, uint64_t sample0,
+                               const long long* idx, float* xt, int B, int L, hipStream_t s);
+void launch_scatter_rows(const float* src, const long long* idx, long long base, float* dst, int B, int W, hipStream_t s);
+void launch_repeat_rows(const float* x, float* out, int B, long row0, int nrows, int L, hipStream_t s);
+void launch_vote_margin(const float* logits, int B, int C, unsigned long long* counts, float tau, long long sample_base,
+                        long long* list, unsigned long long* list_n, int* pred_out, hipStream_t s);
 void launch_embed_table(float t, const float* w1, const float* b1, const float* w2, const float* b2, const float* wt,
                         const float* bt, float* table, float* emb2_out, const float* b_res, float* epi_c, int NL, hipStream_t s);
 void launch_lincomb(int op, const float* x, const float* y, const float* z, float c0, float c1, float c2, float* out, long n,

@@ -81,6 +81,52 @@ __global__ void mc_noise_scale_kernel(const float* __restrict__ clip, const floa
     *(float4*)(xt + (long)b * L + blk * 4) = o;
 }
 
+// The same sample, addressed through an index list (exact-vote recheck): row b is global sample idx[b]; its noise is
+// the Philox draw keyed (seed, idx[b]) or row idx[b] - sample0 of the caller's delta — bit-identical to what the sample
+// received in its first (bf16) evaluation.
+__global__ void mc_noise_scale_idx_kernel(const float* __restrict__ clip, const float* __restrict__ delta, float sigma,
+                                          float scale, uint64_t seed, uint64_t sample0, const long long* __restrict__ idx,
+                                          float* __restrict__ xt, int B, int L) {
+    const int per = L / 4;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * per) return;
+    const int b = (int)(i / per), blk = (int)(i - (long)b * per);
+    const uint64_t sample = (uint64_t)idx[b];
+    const float4 x = *(const float4*)(clip + blk * 4);
+    float d[4];
+    if (delta) {
+        const float4 dv = *(const float4*)(delta + (long)(sample - sample0) * L + blk * 4);
+        d[0] = dv.x; d[1] = dv.y; d[2] = dv.z; d[3] = dv.w;
+    } else {
+        philox_normal4(seed, sample, 0u, blk, d);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = __fmul_rn(sigma, d[j]);
+    }
+    float4 o;
+    o.x = __fmul_rn(scale, __fadd_rn(x.x, d[0])); o.y = __fmul_rn(scale, __fadd_rn(x.y, d[1]));
+    o.z = __fmul_rn(scale, __fadd_rn(x.z, d[2])); o.w = __fmul_rn(scale, __fadd_rn(x.w, d[3]));
+    *(float4*)(xt + (long)b * L + blk * 4) = o;
+}
+
+// dst[idx[b] - base][0:W] = src[b][0:W]  (rechecked rows of logits_out / x0_out); W % 4 == 0 or W < 4 handled scalar
+__global__ void scatter_rows_kernel(const float* __restrict__ src, const long long* __restrict__ idx, long long base,
+                                    float* __restrict__ dst, int B, int W) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * W) return;
+    const int b = (int)(i / W), c = (int)(i - (long)b * W);
+    dst[(idx[b] - base) * W + c] = src[i];
+}
+
+// out[i] = x[(row0 + i) % B]: rows [row0, row0 + nrows) of x.repeat(R, 1, 1)  (EOT's x_batch.repeat, _EOT.py:36)
+__global__ void repeat_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int B, long row0, int L, long total4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const int per = L / 4;
+    const long row = i / per;
+    const int blk = (int)(i - row * per);
+    ((float4*)out)[i] = ((const float4*)x)[((row0 + row) % B) * per + blk];
+}
+
 // ----------------------------------------------------------------------------------------------
 // diffusion-step embedding (util.py:68-93) -> fc_t1, fc_t2 with swish (WaveNet.py:124-126) ->
 // the 36 per-layer fc_t (WaveNet.py:82-83).  t is the same for every row of the batch in every
@@ -339,7 +385,32 @@ __global__ void vote_kernel(const float* __restrict__ logits, int B, int C, unsi
         if (v > bv || (v != v && bv == bv)) { bv = v; best = c; }
     }
     if (pred_out) pred_out[b] = best;
-    atomicAdd(&counts[best], 1ull);
+    if (counts) atomicAdd(&counts[best], 1ull);
+}
+
+// Exact-vote mode: a sample votes from these (bf16-path) logits only if its top-2 margin is >= tau; otherwise its global
+// index sample_base + b is queued for the exact-fp32 re-evaluation (any NaN fails the comparison and is queued too).
+__global__ void vote_margin_kernel(const float* __restrict__ logits, int B, int C, unsigned long long* __restrict__ counts,
+                                   float tau, long long sample_base, long long* __restrict__ list,
+                                   unsigned long long* __restrict__ list_n, int* __restrict__ pred_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int best = 0;
+    float bv = logits[(long)b * C], second = -INFINITY;
+    bool nan = bv != bv;
+    for (int c = 1; c < C; ++c) {
+        const float v = logits[(long)b * C + c];
+        nan |= v != v;
+        if (v > bv) { second = bv; bv = v; best = c; }
+        else if (v > second) second = v;
+    }
+    if (pred_out) pred_out[b] = best;
+    if (!nan && (C == 1 || bv - second >= tau)) {
+        atomicAdd(&counts[best], 1ull);
+    } else {
+        const unsigned long long slot = atomicAdd(list_n, 1ull);
+        list[slot] = sample_base + b;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
@@ -355,6 +426,23 @@ void launch_mc_noise_scale(const float* clip, const float* delta, float sigma, f
                            float* xt, int B, int L, hipStream_t s) {
     hipLaunchKernelGGL(mc_noise_scale_kernel, dim3(nblk((long)B * (L / 4), 256)), dim3(256), 0, s, clip, delta, sigma, scale,
                        seed, sample0, xt, B, L);
+}
+void launch_mc_noise_scale_idx(const float* clip, const float* delta, float sigma, float scale, uint64_t seed, uint64_t sample0,
+                               const long long* idx, float* xt, int B, int L, hipStream_t s) {
+    hipLaunchKernelGGL(mc_noise_scale_idx_kernel, dim3(nblk((long)B * (L / 4), 256)), dim3(256), 0, s, clip, delta, sigma, scale,
+                       seed, sample0, idx, xt, B, L);
+}
+void launch_scatter_rows(const float* src, const long long* idx, long long base, float* dst, int B, int W, hipStream_t s) {
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(nblk((long)B * W, 256)), dim3(256), 0, s, src, idx, base, dst, B, W);
+}
+void launch_repeat_rows(const float* x, float* out, int B, long row0, int nrows, int L, hipStream_t s) {
+    const long total4 = (long)nrows * (L / 4);
+    hipLaunchKernelGGL(repeat_rows_kernel, dim3(nblk(total4, 256)), dim3(256), 0, s, x, out, B, row0, L, total4);
+}
+void launch_vote_margin(const float* logits, int B, int C, unsigned long long* counts, float tau, long long sample_base,
+                        long long* list, unsigned long long* list_n, int* pred_out, hipStream_t s) {
+    hipLaunchKernelGGL(vote_margin_kernel, dim3(nblk(B, 64)), dim3(64), 0, s, logits, B, C, counts, tau, sample_base, list, list_n,
+                       pred_out);
 }
 void launch_embed_table(float t, const float* w1, const float* b1, const float* w2, const float* b2, const float* wt,
                         const float* bt, float* table, float* emb2_out, const float* b_res, float* epi_c, int NL, hipStream_t s) {

@@ -21,6 +21,19 @@ struct GemmF32Args {
     int groups;           // > 1: grouped conv, one group per grid.z; M, K and the A image are per group, X / C / scale /
                           //      shift / res advance by K resp. M per group (ldx / ldc = all groups); excludes split-K
     const float* res;     // optional residual [N][ldc] added before the ReLU (ResNeXt bottleneck sum)
+    // Fused epilogues of the exact-fp32 WaveNet layer (Residual_block.forward, WaveNet.py:86-97); M = 512, no split-K:
+    //   epi 1  gate: the rows of A / shift are permuted so that every wave holds a gate channel's tanh row (accumulator
+    //          tiles 0-1) and its sigmoid row (tiles 2-3): tile-local row wm*64 + i*16 + r of block bm is H row
+    //          (i >= 2 ? 256 : 0) + bm*64 + wm*32 + (i&1)*16 + r.  C[n][ch] = tanh(H[ch]) * sigmoid(H[256+ch]), ldc = 256.
+    //   epi 2  update: rows [0, res_rows) are the res conv, the rest the skip conv:
+    //          hout[row(n)][m] = (hin[row(n)][m] + v) * sqrt(1/2) + emb_next[m],  skip[n][m - res_rows] (+)= v
+    //          (row(n) = position n inside the zero-padded residual stream; res_rows = 0 on the last layer, whose residual
+    //          output is never consumed; `first`: the skip sum starts here).
+    int epi, res_rows, first, L, LP;
+    const float* hin;
+    float* hout;
+    float* skip;
+    const float* emb_next;
     int splits;           // > 1: split-K over grid.z; partial sums go to `slab` [splits][N][ldc] (fixed-order reduce)
     float* slab;
 };

@@ -158,6 +158,64 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
         }
         return;
     }
+    if (BM == 128 && a.epi == 1) {          // gate: g = tanh(H[ch]) * sigmoid(H[256 + ch]) without the H round trip
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mrow = m0 + wm * 64 + i * 16 + q * 4;              // permuted row of the tanh half (its partner: + 32)
+            const int ch = blockIdx.y * 64 + wm * 32 + i * 16 + q * 4;
+            const float4 bt = *(const float4*)(a.shift + mrow), bs = *(const float4*)(a.shift + mrow + 32);
+            const float bta[4] = {bt.x, bt.y, bt.z, bt.w}, bsa[4] = {bs.x, bs.y, bs.z, bs.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long n = n0 + wn * 64 + j * 16 + r16;
+                if (n >= a.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ht = acc[i][j][r] + bta[r], hs = acc[(i + 2) % MT][j][r] + bsa[r];
+                    v[r] = tanhf(ht) * (1.f / (1.f + expf(-hs)));
+                }
+                *(float4*)(a.C + n * 256 + ch) = float4{v[0], v[1], v[2], v[3]};
+            }
+        }
+        return;
+    }
+    if (BM == 128 && a.epi == 2) {          // h' = (h + res) * sqrt(1/2) + emb_next ; skip (+)= skip conv
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + q * 4;
+            const float4 b4 = *(const float4*)(a.shift + m);
+            const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+            const bool is_res = m < a.res_rows;
+            float ea[4] = {0.f, 0.f, 0.f, 0.f};
+            if (is_res) { const float4 e4 = *(const float4*)(a.emb_next + m); ea[0] = e4.x; ea[1] = e4.y; ea[2] = e4.z; ea[3] = e4.w; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long n = n0 + wn * 64 + j * 16 + r16;
+                if (n >= a.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + ba[r];
+                if (is_res) {
+                    const long bb = n / a.L, t = n - bb * a.L;
+                    const long hoff = (bb * a.LP + kPad + t) * kC + m;
+                    const float4 h = *(const float4*)(a.hin + hoff);
+                    const float k = 0.70710678118654752440f;
+                    *(float4*)(a.hout + hoff) = float4{__fadd_rn(__fmul_rn(__fadd_rn(h.x, v[0]), k), ea[0]), __fadd_rn(__fmul_rn(__fadd_rn(h.y, v[1]), k), ea[1]),
+                                                       __fadd_rn(__fmul_rn(__fadd_rn(h.z, v[2]), k), ea[2]), __fadd_rn(__fmul_rn(__fadd_rn(h.w, v[3]), k), ea[3])};
+                } else {
+                    float4* ps = (float4*)(a.skip + n * 256 + (m - a.res_rows));
+                    if (a.first) {
+                        *ps = float4{v[0], v[1], v[2], v[3]};
+                    } else {
+                        const float4 o = *ps;
+                        *ps = float4{__fadd_rn(o.x, v[0]), __fadd_rn(o.y, v[1]), __fadd_rn(o.z, v[2]), __fadd_rn(o.w, v[3])};
+                    }
+                }
+            }
+        }
+        return;
+    }
     const bool vec = ((a.ldc & 3) == 0);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {

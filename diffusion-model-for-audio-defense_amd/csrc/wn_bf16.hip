@@ -30,9 +30,11 @@
 namespace dmad {
 
 // h0 = relu(w_init * x + b_init) + emb_0  (WaveNet.py:147,13-19 + the F5 alias of layer 0), bf16 out
-__global__ void __launch_bounds__(256) wn_init_bf16(const float* __restrict__ x, const float* __restrict__ w,
-                                                    const float* __restrict__ bias, const float* __restrict__ emb0,
-                                                    bf16_t* __restrict__ h, int L, int LP, long total_chunks) {
+template <typename T>
+__global__ void __launch_bounds__(256) wn_init_h16(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, const float* __restrict__ emb0,
+                                                   h16_t* __restrict__ h, int L, int LP, long total_chunks) {
+    typedef typename H16<T>::v8 v8;
     // one thread per 8-channel chunk of one time position, in the order of the H16 layout: 16 consecutive lanes write the
     // 16 rows of one chunk column (256 contiguous bytes), a wave 1 KiB, a 16-row block 8 KiB (L is a multiple of 16, so
     // a block never straddles two clips)
@@ -42,22 +44,23 @@ __global__ void __launch_bounds__(256) wn_init_bf16(const float* __restrict__ x,
         const long pos = (idx >> 9) * 16 + (idx & 15);      // b * L + t
         const long bb = pos / L, t = pos - bb * L;
         const float xv = x[pos];
-        bf16x8 o;
+        v8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = cg * 8 + j;
             const float v = w[c] * xv + bias[c];
-            o[j] = (bf16_t)(fmaxf(v, 0.f) + emb0[c]);
+            o[j] = (T)(fmaxf(v, 0.f) + emb0[c]);
         }
-        *(bf16x8*)((char*)(h + (size_t)bb * LP * kC) + h16_off((unsigned)(kPad + t), (unsigned)cg)) = o;
+        *(v8*)((char*)(h + (size_t)bb * LP * kC) + h16_off((unsigned)(kPad + t), (unsigned)cg)) = o;
     }
 }
 
-void launch_wn_init_bf16(const float* x, const float* w, const float* bias, const float* emb0, bf16_t* h, int B, int L,
-                         int LP, hipStream_t s) {
+void launch_wn_init_bf16(const float* x, const float* w, const float* bias, const float* emb0, h16_t* h, int B, int L,
+                         int LP, bool f16, hipStream_t s) {
     const long chunks = (long)B * L * 32;
     const int grid = (int)((chunks + 255) / 256 < 8192 ? (chunks + 255) / 256 : 8192);
-    hipLaunchKernelGGL(wn_init_bf16, dim3(grid), dim3(256), 0, s, x, w, bias, emb0, h, L, LP, chunks);
+    if (f16) hipLaunchKernelGGL(wn_init_h16<_Float16>, dim3(grid), dim3(256), 0, s, x, w, bias, emb0, h, L, LP, chunks);
+    else hipLaunchKernelGGL(wn_init_h16<__bf16>, dim3(grid), dim3(256), 0, s, x, w, bias, emb0, h, L, LP, chunks);
 }
 
 int wn_bf16_configure() {

@@ -1,4 +1,4 @@
-// wn_final_bf16_p — tail of the eps-network on the bf16 path (persistent form):
+// wn_final_p<T> — tail of the eps-network on the 16-bit MFMA path (persistent form), T = __bf16 or _Float16:
 //   skip = sum_n W_skip_n * g_n + sum_n b_skip_n          ONE GEMM, M = 256, K = NL*256 (9216), over the
 //                                                         gate outputs every layer kernel streamed to HBM
 //   y    = skip * sqrt(1/NL)                              (WaveNet.py:135)
@@ -50,13 +50,14 @@ __device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned
 __device__ __forceinline__ void dma16_stream(const void* sbase, unsigned voff, unsigned lds) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
-__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
 
 }  // namespace
 
-__global__ void __launch_bounds__(512, 2) wn_final_bf16_p(WnFinalArgs a, long npos, int ntiles) {
+template <typename T>
+__global__ void __launch_bounds__(512, 2) wn_final_p(WnFinalArgs a, long npos, int ntiles) {
+    typedef typename H16<T>::v8 v8;
+    typedef typename H16<T>::v4 v4;
+    auto mfma16 = [](v8 x, v8 y, f32x4 c) { return H16<T>::mfma(x, y, c); };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,14 +105,14 @@ __global__ void __launch_bounds__(512, 2) wn_final_bf16_p(WnFinalArgs a, long np
 #pragma unroll
             for (int p = 0; p < 4; ++p) stage_piece(s, s, p);
         WNF_WAIT_BARRIER(12);                     // stage 0 landed
-        bf16x8 af[2][4], bf[2][8];
+        v8 af[2][4], bf[2][8];
         {
             const char* A = smem + wm * 4096 + frag_off;
             const char* Bt = smem + F_BOFF + wn * 8192 + frag_off;
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) bf[0][nt] = *(const bf16x8*)(Bt + nt * 1024);
+            for (int nt = 0; nt < 8; ++nt) bf[0][nt] = *(const v8*)(Bt + nt * 1024);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) af[0][mt] = *(const bf16x8*)(A + mt * 1024);
+            for (int mt = 0; mt < 4; ++mt) af[0][mt] = *(const v8*)(A + mt * 1024);
         }
         // ---------------- skip GEMM: nks k-steps, unrolled by 4 (2 fragment sets, 4 ring slots) ---------------
         // the last group of 4 is peeled (TAIL) so that the steady-state body carries no end-of-K conditions
@@ -137,8 +138,8 @@ __global__ void __launch_bounds__(512, 2) wn_final_bf16_p(WnFinalArgs a, long np
 #pragma unroll
                 for (int p = 0; p < 12; ++p) {             // 12 x (1 fragment read of k-step ks+1, 1 MFMA)
                     if (!TAIL || u < 3) {
-                        if (p < 8) bf[nxt][p] = *(const bf16x8*)(Br + p * 1024);
-                        else af[nxt][p - 8] = *(const bf16x8*)(Ar + (p - 8) * 1024);
+                        if (p < 8) bf[nxt][p] = *(const v8*)(Br + p * 1024);
+                        else af[nxt][p - 8] = *(const v8*)(Ar + (p - 8) * 1024);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     const int i = 20 + p;
@@ -157,12 +158,12 @@ __global__ void __launch_bounds__(512, 2) wn_final_bf16_p(WnFinalArgs a, long np
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
-                bf16x4 yv;
+                v4 yv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) yv[r] = (bf16_t)(acc[mt][nt][r] * a.skip_scale);
+                for (int r = 0; r < 4; ++r) yv[r] = (T)(acc[mt][nt][r] * a.skip_scale);
                 const int t = wn * 128 + nt * 16 + r16;
                 const int chunk = wm * 8 + mt * 2 + (q >> 1);
-                *(bf16x4*)(smem + t * 512 + ((chunk ^ r16) * 16) + (q & 1) * 8) = yv;
+                *(v4*)(smem + t * 512 + ((chunk ^ r16) * 16) + (q & 1) * 8) = yv;
             }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -177,11 +178,11 @@ __global__ void __launch_bounds__(512, 2) wn_final_bf16_p(WnFinalArgs a, long np
             for (int u = 0; u < 2; ++u) {
                 const char* A = smem + F_W3 + u * 16384 + wm * 4096 + frag_off;
                 const char* G = smem + (wn * 128 + r16) * 512 + ((((ks3 + u) * 4 + q) ^ r16) * 16);
-                bf16x8 b3[8], a3[4];
+                v8 b3[8], a3[4];
 #pragma unroll
-                for (int nt = 0; nt < 8; ++nt) b3[nt] = *(const bf16x8*)(G + nt * 8192);
+                for (int nt = 0; nt < 8; ++nt) b3[nt] = *(const v8*)(G + nt * 8192);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) a3[mt] = *(const bf16x8*)(A + mt * 1024);
+                for (int mt = 0; mt < 4; ++mt) a3[mt] = *(const v8*)(A + mt * 1024);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -225,11 +226,12 @@ static int g_final_cus = 256;
 
 bool wn_final_p_supported(int num_res_layers) { return num_res_layers >= 1; }   // nks = 8 * layers: a multiple of 4, >= 8
 
-void launch_wn_final_bf16_p(const WnFinalArgs& a, hipStream_t s) {
+void launch_wn_final_bf16_p(const WnFinalArgs& a, bool f16, hipStream_t s) {
     const long npos = (long)a.B * a.L;
     const int ntiles = (int)((npos + FT - 1) / FT);
     const int grid = ntiles < g_final_cus ? ntiles : g_final_cus;
-    hipLaunchKernelGGL(wn_final_bf16_p, dim3(grid), dim3(512), kWnLdsBytes, s, a, npos, ntiles);
+    if (f16) hipLaunchKernelGGL(wn_final_p<_Float16>, dim3(grid), dim3(512), kWnLdsBytes, s, a, npos, ntiles);
+    else hipLaunchKernelGGL(wn_final_p<__bf16>, dim3(grid), dim3(512), kWnLdsBytes, s, a, npos, ntiles);
 }
 
 int wn_final_p_configure() {
@@ -237,7 +239,8 @@ int wn_final_p_configure() {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         g_final_cus = prop.multiProcessorCount;
-    return (int)hipFuncSetAttribute((const void*)wn_final_bf16_p, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    if (hipError_t e = hipFuncSetAttribute((const void*)wn_final_p<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)) return (int)e;
+    return (int)hipFuncSetAttribute((const void*)wn_final_p<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
 }
 
 }  // namespace dmad

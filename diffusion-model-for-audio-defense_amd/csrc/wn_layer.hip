@@ -1,4 +1,4 @@
-// wn_layer_bf16_p — the residual-layer kernel of the bf16 path (persistent form).
+// wn_layer_p<T> — the residual-layer kernel of the 16-bit MFMA path (persistent form), T = __bf16 or _Float16.
 //
 // Math, operand orientation and HBM/LDS layouts are those documented at the top of wn_bf16.hip
 // (Residual_block.forward, DiffWave_Unconditional/WaveNet.py:75-97).
@@ -73,10 +73,6 @@ __device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
 
-__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-
 // g = tanh(A) * sigmoid(B) for two values at a time with packed fp32 math, on accumulators that already hold the
 // exp2 arguments: the host scales the tanh rows of the dilated-conv weights by -2*log2(e) and the sigmoid rows by
 // -log2(e), and the accumulators start from the equally scaled bias, so
@@ -97,8 +93,11 @@ __device__ __forceinline__ f32x2 gate2(f32x2 at, f32x2 as) {
 
 }  // namespace
 
-template <bool LAST, bool STAMP = false>
-__global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int ntiles) {
+template <typename T, bool LAST, bool STAMP = false>
+__global__ void __launch_bounds__(512, 2) wn_layer_p(WnLayerArgs a, int ntiles) {
+    typedef typename H16<T>::v8 v8;        // 8 operands of type T (one MFMA fragment, one 16-byte chunk)
+    typedef typename H16<T>::v4 v4;
+    auto mfma16 = [](v8 x, v8 y, f32x4 c) { return H16<T>::mfma(x, y, c); };
     // STAMP: diagnostic build only (per-phase cycle sums of wave 0 into a.dbg[block][8]); never shipped/timed
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int k) {
@@ -206,14 +205,14 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
         for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = *(const f32x4*)(smem + CONST_OFF + (wm * 128 + mt * 16 + q * 4) * 4);
-        bf16x8 af[2][8], bf[2][4];
+        v8 af[2][8], bf[2][4];
         {
             const char* A = smem + slot_base(0) + wm * 8192 + frag_off;
             const char* Bt = smem + B0_OFF + wn * 1024 + bfrag_off;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bf[0][nt] = *(const bf16x8*)(Bt + nt * 256);
+            for (int nt = 0; nt < 4; ++nt) bf[0][nt] = *(const v8*)(Bt + nt * 256);
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) af[0][mt] = *(const bf16x8*)(A + mt * 1024);
+            for (int mt = 0; mt < 8; ++mt) af[0][mt] = *(const v8*)(A + mt * 1024);
         }
 #pragma unroll
         for (int ks = 0; ks < 24; ++ks) {
@@ -244,8 +243,8 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
 #pragma unroll
             for (int p = 0; p < 12; ++p) {                 // 12 x (1 fragment read of k-step ks+1, 1 MFMA)
                 if (ks + 1 < 24) {
-                    if (p < 4) bf[nxt][p] = *(const bf16x8*)(Br + p * 256);
-                    else af[nxt][p - 4] = *(const bf16x8*)(Ar + (p - 4) * 1024);
+                    if (p < 4) bf[nxt][p] = *(const v8*)(Br + p * 256);
+                    else af[nxt][p - 4] = *(const v8*)(Ar + (p - 4) * 1024);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const int i = 20 + p;
@@ -281,10 +280,10 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
             const f32x4 ha = acc[mt][nt], hb = acc[mt + 4][nt];
             const f32x2 g01 = gate2(f32x2{ha[0], ha[1]}, f32x2{hb[0], hb[1]});
             const f32x2 g23 = gate2(f32x2{ha[2], ha[3]}, f32x2{hb[2], hb[3]});
-            const bf16x4 gv = {(bf16_t)g01[0], (bf16_t)g01[1], (bf16_t)g23[0], (bf16_t)g23[1]};
+            const v4 gv = {(T)g01[0], (T)g01[1], (T)g23[0], (T)g23[1]};
             const int t = wn * 64 + nt * 16 + r16v;
             const int chunk = mt * 8 + wm * 2 + (qv >> 1);
-            *(bf16x4*)(smem + t * 512 + ((chunk ^ r16v) * 16) + (qv & 1) * 8) = gv;
+            *(v4*)(smem + t * 512 + ((chunk ^ r16v) * 16) + (qv & 1) * 8) = gv;
         };
 
         if constexpr (LAST) {
@@ -325,14 +324,14 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = *(const f32x4*)(smem + EC_OFF + (wm * 64 + mt * 16 + qv * 4) * 4);
-            bf16x8 b2[4], a2[4];
+            v8 b2[4], a2[4];
             auto read2 = [&](int ks2, int buf) {
                 const char* A = smem + GEMM2_BUF + buf * 16384 + wm * 4096 + r16v * 64 + ((qv ^ swz64(r16v)) * 16);
                 const char* G = smem + (wn * 64 + r16v) * 512 + (((ks2 * 4 + qv) ^ r16v) * 16);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) b2[nt] = *(const bf16x8*)(G + nt * 8192);
+                for (int nt = 0; nt < 4; ++nt) b2[nt] = *(const v8*)(G + nt * 8192);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) a2[mt] = *(const bf16x8*)(A + mt * 1024);
+                for (int mt = 0; mt < 4; ++mt) a2[mt] = *(const v8*)(A + mt * 1024);
             };
             auto mfma2 = [&](int m0, int m1) {
 #pragma unroll
@@ -371,7 +370,7 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
             WNL_WAIT_BARRIER(0);           // g channels [128,192) complete; stages 5-6 landed; buffers 2-3 free
             // ordinary loads, issued right behind a vmcnt(0) barrier and retired by the next one (see the header):
             // the residual rows of this lane's output channels wm*64 + mt*16 + 4q + [0,4)
-            bf16x8 hc16[4][2];             // residual h: the 16-byte chunk this lane will overwrite (tile 2p + (q&1), see epilogue)
+            v8 hc16[4][2];             // residual h: the 16-byte chunk this lane will overwrite (tile 2p + (q&1), see epilogue)
             // H16 offset of this lane's chunk (mt, p2): one per-lane base + p2 * 16 KiB (two 16-row blocks on) + mt * 512 B
             // (two chunk columns on); row0 is a multiple of 16, so the row's block index and in-block row separate
             const unsigned h16_lane = (unsigned)((hin_c.row0 >> 4) + wn * 4 + (qv & 1)) * 8192u + (unsigned)(wm * 8 + (qv >> 1)) * 256u + (unsigned)r16v * 16u;
@@ -379,7 +378,7 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
             for (int p2 = 0; p2 < 2; ++p2) {
                 const char* hp = hin_c.clip + h16_lane + p2 * 16384;
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) hc16[mt][p2] = *(const bf16x8*)(hp + mt * 512);
+                for (int mt = 0; mt < 4; ++mt) hc16[mt][p2] = *(const v8*)(hp + mt * 512);
             }
             stage2(7, 2);
             phase(3, 4, 4, 5, 0);
@@ -416,13 +415,13 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
                     const auto h0 = __builtin_amdgcn_permlane16_swap(hc4[0], hc4[2], false, false);
                     const auto h1 = __builtin_amdgcn_permlane16_swap(hc4[1], hc4[3], false, false);
                     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-                    const bf16x4 hx = __builtin_bit_cast(bf16x4, u32x2{h0[0], h1[0]});
-                    const bf16x4 hy = __builtin_bit_cast(bf16x4, u32x2{h0[1], h1[1]});
-                    bf16x4 ox, oy;
+                    const v4 hx = __builtin_bit_cast(v4, u32x2{h0[0], h1[0]});
+                    const v4 hy = __builtin_bit_cast(v4, u32x2{h0[1], h1[1]});
+                    v4 ox, oy;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        ox[r] = (bf16_t)__builtin_fmaf((float)hx[r], 0.70710678118654752440f, acc2[mt][2 * p2][r]);
-                        oy[r] = (bf16_t)__builtin_fmaf((float)hy[r], 0.70710678118654752440f, acc2[mt][2 * p2 + 1][r]);
+                        ox[r] = (T)__builtin_fmaf((float)hx[r], 0.70710678118654752440f, acc2[mt][2 * p2][r]);
+                        oy[r] = (T)__builtin_fmaf((float)hy[r], 0.70710678118654752440f, acc2[mt][2 * p2 + 1][r]);
                     }
                     const u32x2 oxu = __builtin_bit_cast(u32x2, ox), oyu = __builtin_bit_cast(u32x2, oy);
                     const auto s0 = __builtin_amdgcn_permlane16_swap(oxu[0], oyu[0], false, false);
@@ -443,24 +442,36 @@ __global__ void __launch_bounds__(512, 2) wn_layer_bf16_p(WnLayerArgs a, int nti
 
 static int g_num_cus = 256;
 
-void launch_wn_layer_bf16_p(const WnLayerArgs& a, int B, hipStream_t s, bool stamps) {
-    const int ntiles = B * (a.L / kTileT);
-    const int grid = ntiles < g_num_cus ? ntiles : g_num_cus;
+template <typename T>
+static void launch_layer_t(const WnLayerArgs& a, int grid, int ntiles, hipStream_t s, bool stamps) {
     if (stamps && !a.last) {
-        hipLaunchKernelGGL((wn_layer_bf16_p<false, true>), dim3(grid), dim3(512), kWnLdsBytes, s, a, ntiles);
+        hipLaunchKernelGGL((wn_layer_p<T, false, true>), dim3(grid), dim3(512), kWnLdsBytes, s, a, ntiles);
         return;
     }
-    if (a.last) hipLaunchKernelGGL(wn_layer_bf16_p<true>, dim3(grid), dim3(512), kWnLdsBytes, s, a, ntiles);
-    else hipLaunchKernelGGL(wn_layer_bf16_p<false>, dim3(grid), dim3(512), kWnLdsBytes, s, a, ntiles);
+    if (a.last) hipLaunchKernelGGL((wn_layer_p<T, true>), dim3(grid), dim3(512), kWnLdsBytes, s, a, ntiles);
+    else hipLaunchKernelGGL((wn_layer_p<T, false>), dim3(grid), dim3(512), kWnLdsBytes, s, a, ntiles);
+}
+
+void launch_wn_layer_bf16_p(const WnLayerArgs& a, int B, bool f16, hipStream_t s, bool stamps) {
+    const int ntiles = B * (a.L / kTileT);
+    const int grid = ntiles < g_num_cus ? ntiles : g_num_cus;
+    if (f16) launch_layer_t<_Float16>(a, grid, ntiles, s, stamps);
+    else launch_layer_t<__bf16>(a, grid, ntiles, s, stamps);
+}
+
+template <typename T>
+static int configure_layer_t() {
+    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_p<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLdsBytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)wn_layer_p<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLdsBytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)wn_layer_p<T, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLdsBytes);
+    return (int)e;
 }
 
 int wn_layer_p_configure() {
-    hipError_t e = hipFuncSetAttribute((const void*)wn_layer_bf16_p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLdsBytes);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)wn_layer_bf16_p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLdsBytes);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)wn_layer_bf16_p<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLdsBytes);
-    if (e != hipSuccess) return (int)e;
+    if (int r = configure_layer_t<__bf16>()) return r;
+    if (int r = configure_layer_t<_Float16>()) return r;
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)

@@ -75,8 +75,7 @@ class UNetModel(nn.Module):
     def bind_engine(self, engine=None):
         from dmad_hip import engine as _eng
         eng = engine or _eng.get_engine()
-        if not eng.has_unet:
-            eng.load_unet(self.state_dict())
+        eng.bind('unet', self.state_dict(), eng.load_unet)
         self.__dict__['engine'] = eng
         return self
 

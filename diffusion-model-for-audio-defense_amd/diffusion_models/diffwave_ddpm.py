@@ -83,17 +83,22 @@ class DiffWave(torch.nn.Module):
             return torch.normal(0, 1, size=tuple(shape)).to(device)
         return None
 
+    def purify_coefficients(self):
+        """(t*, c_a, c_b, c_eps[t*], c_div[t*], c_sig[t*]) of forward() = _diffusion + _reverse, from the fp32 tables exactly
+        as ref l.66-67,159-160 compute them: the argument block of dmad_ddpm_purify / dmad_query_logits."""
+        _, Alpha, Alpha_bar, Sigma = self._tables()
+        ts = self.reverse_timestep
+        return (ts, float(torch.sqrt(Alpha_bar[ts - 1])), float(torch.sqrt(1 - Alpha_bar[ts - 1])),
+                [float((1 - Alpha[t]) / torch.sqrt(1 - Alpha_bar[t])) for t in range(ts)],
+                [float(torch.sqrt(Alpha[t])) for t in range(ts)], [float(Sigma[t]) for t in range(ts)])
+
     # -- reference API ---------------------------------------------------------------------------
     def forward(self, waveforms: Union[torch.Tensor, np.ndarray]):
         waveforms = self._to_tensor(waveforms)
         if self.noise_source == 'device':     # the whole chain in one library call (dmad_ddpm_purify)
-            _, Alpha, Alpha_bar, Sigma = self._tables()
             assert waveforms.ndim == 3
-            ts = self.reverse_timestep
-            out = self.engine.ddpm_purify(waveforms, ts, float(torch.sqrt(Alpha_bar[ts - 1])), float(torch.sqrt(1 - Alpha_bar[ts - 1])),
-                                          [float((1 - Alpha[t]) / torch.sqrt(1 - Alpha_bar[t])) for t in range(ts)],
-                                          [float(torch.sqrt(Alpha[t])) for t in range(ts)], [float(Sigma[t]) for t in range(ts)],
-                                          seed=self.seed, sample0=self._draws)
+            ts, c_a, c_b, c_eps, c_div, c_sig = self.purify_coefficients()
+            out = self.engine.ddpm_purify(waveforms, ts, c_a, c_b, c_eps, c_div, c_sig, seed=self.seed, sample0=self._draws)
             self._draws += waveforms.shape[0]
             return out.unsqueeze(1)
         base = self._draws                    # device noise: row i of this call is sample base + i in BOTH phases
@@ -295,7 +300,8 @@ def create_diffwave_model(model_path, config_path, reverse_timestep=25, state_di
         checkpoint = torch.load(model_path, map_location='cpu')
         state_dict = checkpoint['model_state_dict']
     eng = engine or _eng.get_engine(wavenet_config, precision=precision, max_batch=max_batch)
-    if not eng.has_wavenet:
-        eng.load_wavenet(state_dict)
+    if engine is None and eng.has_wavenet and eng.wavenet_owner != _eng.state_fingerprint(state_dict):
+        eng = _eng.get_engine(wavenet_config, precision=precision, max_batch=max_batch, fresh=True)   # a second, different DiffWave
+    eng.bind('wavenet', state_dict, eng.load_wavenet)
     return DiffWave(model=WaveNetHIP(eng), diffusion_hyperparams=diffusion_hyperparams,
                     reverse_timestep=reverse_timestep, noise_source=noise_source)

@@ -18,7 +18,7 @@ class DmadError(RuntimeError):
 class DmadConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'res_channels', 'skip_channels', 'num_res_layers', 'dilation_cycle', 'embed_dim_in', 'embed_dim_mid',
-        'embed_dim_out', 'clip_len', 'max_batch', 'num_classes', 'precision', 'with_classifier')]
+        'embed_dim_out', 'clip_len', 'max_batch', 'num_classes', 'precision', 'with_classifier', 'recheck_batch', 'half_type')]
 
 
 _P = C.c_void_p
@@ -43,6 +43,11 @@ _SIGNATURES = {
     'dmad_classify': (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     'dmad_smooth_votes': (C.c_int, [_P, _P, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_int64, C.c_int32,
                                     C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P]),
+    'dmad_set_mode': (C.c_int, [_P, C.c_int32]),
+    'dmad_set_recheck_margin': (C.c_int, [_P, C.c_float]),
+    'dmad_recheck_stats': (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
+    'dmad_query_logits': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P,
+                                    C.c_uint64, C.c_uint64, _P, _P, _P]),
     'dmad_vote': (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     'dmad_philox_raw': (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _P, _P]),
     'dmad_philox_normal': (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int32, _P, _P]),
@@ -50,6 +55,7 @@ _SIGNATURES = {
     'dmad_device_bytes': (C.c_int64, [_P]),
     'dmad_profile_layers': (C.c_int, [_P, C.c_int32]),
     'dmad_profile_read': (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    'dmad_profile_read_final': (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -5,6 +5,7 @@ torch.distributed.  All arithmetic of the hot path runs inside libdmad_hip.so.""
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import os
 from typing import Dict, Optional
 
@@ -14,7 +15,13 @@ import torch
 from . import _lib
 from ._lib import DmadConfig, DmadError, check
 
-BF16, FP32 = 0, 1
+BF16, FP32, EXACT = 0, 1, 2                       # enum dmad_precision
+MODE_FAST, MODE_EXACT_VOTES, MODE_FP32 = 0, 1, 2  # enum dmad_mode (EXACT engines)
+HALF_BF16, HALF_F16 = 0, 1                        # enum dmad_half_type: operand format of the 16-bit MFMA path
+# Recheck bound of the exact-vote mode: a Monte Carlo sample whose bf16 top-2 logit margin is below it is re-evaluated
+# on the exact-fp32 WaveNet.  Must be >= 2 x the largest bf16 error of a logit difference; measured by
+# tools/gpu_flip_study.py (profiles/r02_flip_study.md), overridable with DMAD_RECHECK_MARGIN.
+DEFAULT_RECHECK_MARGIN = 0.5
 VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
 
 
@@ -30,6 +37,20 @@ def _as_np(a) -> np.ndarray:
     if isinstance(a, torch.Tensor):
         a = a.detach().cpu().float().numpy()
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def state_fingerprint(sd: Dict[str, object]) -> str:
+    """Content hash of a state dict (names, shapes, bytes; BatchNorm's num_batches_tracked counters excepted: they do not
+    enter inference): identifies WHICH weights an engine holds."""
+    h = hashlib.sha1()
+    for k in sorted(sd):
+        if k.endswith('num_batches_tracked'):
+            continue
+        v = sd[k]
+        a = v.detach().cpu().contiguous().numpy() if isinstance(v, torch.Tensor) else np.ascontiguousarray(v)
+        h.update(k.encode()); h.update(str(a.dtype).encode()); h.update(str(a.shape).encode())
+        h.update(memoryview(a.reshape(-1)).cast('B'))
+    return h.hexdigest()
 
 
 def fold_wavenet_state_dict(sd: Dict[str, object], num_res_layers: int) -> Dict[str, np.ndarray]:
@@ -116,8 +137,16 @@ def fold_resnext29_state_dict(sd: Dict[str, object], eps: float = 1e-5) -> Dict[
 class Engine:
     """One libdmad_hip engine bound to the current CUDA(HIP) device."""
 
+    @staticmethod
+    def geometry(wavenet_config: Optional[dict]) -> tuple:
+        wc = dict(res_channels=256, skip_channels=256, num_res_layers=36, dilation_cycle=12,
+                  diffusion_step_embed_dim_in=128, diffusion_step_embed_dim_mid=512, diffusion_step_embed_dim_out=512)
+        wc.update({k: v for k, v in (wavenet_config or {}).items() if k in wc})
+        return tuple(sorted(wc.items()))
+
     def __init__(self, wavenet_config: Optional[dict] = None, clip_len: int = 16000, max_batch: int = 64,
-                 num_classes: int = 10, precision: int = BF16, with_classifier: bool = True):
+                 num_classes: int = 10, precision: int = BF16, with_classifier: bool = True, recheck_batch: int = 0,
+                 recheck_margin: Optional[float] = None, half_type: Optional[int] = None):
         if not torch.cuda.is_available():
             raise DmadError('no MI355X/HIP device visible: the dmad engine has no CPU path')
         self.lib = _lib.load()
@@ -126,12 +155,16 @@ class Engine:
         wc.update(wavenet_config or {})
         if wc.get('in_channels', 1) != 1 or wc.get('out_channels', 1) != 1:
             raise DmadError('only in_channels = out_channels = 1 is supported')
+        if half_type is None:    # f16 operands for the exact-vote engine (smaller recheck band), bf16 for the plain 16-bit engine
+            half_type = {'bf16': HALF_BF16, 'f16': HALF_F16}[os.environ.get('DMAD_HALF_TYPE', 'f16' if precision == EXACT else 'bf16').lower()]
         self.cfg = DmadConfig(wc['res_channels'], wc['skip_channels'], wc['num_res_layers'], wc['dilation_cycle'],
                               wc['diffusion_step_embed_dim_in'], wc['diffusion_step_embed_dim_mid'],
                               wc['diffusion_step_embed_dim_out'], clip_len, max_batch, num_classes, precision,
-                              1 if with_classifier else 0)
+                              1 if with_classifier else 0, recheck_batch, half_type)
+        self.half_type = half_type
         self.L, self.max_batch, self.num_classes, self.precision = clip_len, max_batch, num_classes, precision
         self.num_res_layers = wc['num_res_layers']
+        self.wavenet_geometry = Engine.geometry(wc)
         self.device = torch.device('cuda', torch.cuda.current_device())
         h = C.c_void_p()
         check(self.lib.dmad_create(C.byref(self.cfg), C.byref(h)))
@@ -139,6 +172,15 @@ class Engine:
         self.has_wavenet = False
         self.has_classifier = False
         self.has_unet = False
+        # which weights are resident (state_fingerprint): a module that binds to an engine holding OTHER weights must
+        # not silently run them
+        self.wavenet_owner = self.classifier_owner = self.unet_owner = None
+        self.classifier_kind = None
+        self.mode = {BF16: MODE_FAST, FP32: MODE_FP32, EXACT: MODE_EXACT_VOTES}[precision]
+        if precision == EXACT:
+            if recheck_margin is None:
+                recheck_margin = float(os.environ.get('DMAD_RECHECK_MARGIN', DEFAULT_RECHECK_MARGIN))
+            self.set_recheck_margin(recheck_margin)
 
     def close(self):
         if getattr(self, '_h', None):
@@ -165,12 +207,42 @@ class Engine:
             raise DmadError('WaveNet weights are already loaded into this engine')
         self._load(fold_wavenet_state_dict(state_dict, self.num_res_layers))
         self.has_wavenet = True
+        self.wavenet_owner = state_fingerprint(state_dict)
 
     def load_vgg19_bn(self, state_dict):
         if self.has_classifier:
             raise DmadError('classifier weights are already loaded into this engine')
         self._load(fold_vgg19_bn_state_dict(state_dict))
         self.has_classifier = True
+        self.classifier_owner, self.classifier_kind = state_fingerprint(state_dict), 'vgg19_bn'
+
+    def bind(self, part: str, state_dict, loader) -> None:
+        """Make `state_dict` the resident weights of `part` ('wavenet' / 'classifier' / 'unet'): upload them if the
+        part is empty, accept them if they ARE the resident ones, refuse anything else (an engine holds one weight set per
+        part for its lifetime; use get_engine(fresh=True) / Engine(...) for a second model)."""
+        owner = getattr(self, part + '_owner')
+        if not getattr(self, 'has_' + part):
+            loader(state_dict)
+            return
+        fp = state_fingerprint(state_dict)
+        if owner != fp:
+            raise DmadError('this engine already holds different %s weights (resident %s..., offered %s...): bind the module to '
+                            'its own engine (dmad_hip.engine.get_engine(fresh=True))' % (part, str(owner)[:10], fp[:10]))
+
+    # ------------------------------------------------------------------ exact-vote mode (EXACT engines)
+    def set_mode(self, mode: int):
+        check(self.lib.dmad_set_mode(self._h, int(mode)))
+        self.mode = int(mode)
+
+    def set_recheck_margin(self, tau: float):
+        check(self.lib.dmad_set_recheck_margin(self._h, float(tau)))
+        self.recheck_margin = float(tau)
+
+    def recheck_stats(self, reset: bool = False):
+        """-> (samples voted, samples re-evaluated in fp32) since the last reset."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(self.lib.dmad_recheck_stats(self._h, C.byref(a), C.byref(b), 1 if reset else 0))
+        return int(a.value), int(b.value)
 
     def load_unet(self, state_dict):
         """improved_diffusion.unet.UNetModel state dict (synth.UNET_CONFIG geometry) -> engine, names prefixed 'un.'."""
@@ -179,12 +251,14 @@ class Engine:
         self._load({'un.' + k: _as_np(v.detach().cpu().double().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, dtype=np.float64))
                     for k, v in state_dict.items()})
         self.has_unet = True
+        self.unet_owner = state_fingerprint(state_dict)
 
     def load_resnext29(self, state_dict):
         if self.has_classifier:
             raise DmadError('classifier weights are already loaded into this engine')
         self._load(fold_resnext29_state_dict(state_dict))
         self.has_classifier = True
+        self.classifier_owner, self.classifier_kind = state_fingerprint(state_dict), 'resnext29'
 
     # ------------------------------------------------------------------ helpers
     def _wave(self, x: torch.Tensor) -> torch.Tensor:
@@ -330,6 +404,20 @@ class Engine:
                                          _ptr(x0), _stream()))
         return counts, logits, x0
 
+    def query_logits(self, x: torch.Tensor, repeats: int, sampler: int = 0, t_star: int = 0, c_a: float = 0.0, c_b: float = 0.0,
+                     c_eps=None, c_div=None, c_sig=None, seed: int = 0, sample0: int = 0):
+        """dmad_query_logits: x [B,1,L] -> (logits [repeats*B, C], decisions int32 [repeats*B]); row r*B+b is clip b."""
+        xw = self._wave(x)
+        B = xw.shape[0]
+        logits = torch.empty((repeats * B, self.num_classes), device=xw.device, dtype=torch.float32)
+        dec = torch.empty((repeats * B,), device=xw.device, dtype=torch.int32)
+        arrs = [None, None, None]
+        if sampler == 1:
+            arrs = [(C.c_float * t_star)(*[float(v) for v in a]) for a in (c_eps, c_div, c_sig)]
+        check(self.lib.dmad_query_logits(self._h, _ptr(xw), B, int(repeats), int(sampler), int(t_star), float(c_a), float(c_b),
+                                         arrs[0], arrs[1], arrs[2], int(seed), int(sample0), _ptr(logits), _ptr(dec), _stream()))
+        return logits, dec
+
     def philox_raw(self, seed: int, sample: int, stream: int, nblocks: int) -> torch.Tensor:
         out = torch.empty(nblocks * 4, dtype=torch.int32, device=self.device)
         check(self.lib.dmad_philox_raw(self._h, int(seed), int(sample), int(stream), int(nblocks), _ptr(out), _stream()))
@@ -354,25 +442,57 @@ class Engine:
         check(self.lib.dmad_profile_read(self._h, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def profile_read_final(self):
+        """-> (summed ms, launches) of the bracketed wn_final launches; call before profile_read()."""
+        ms, n = C.c_float(0), C.c_int32(0)
+        check(self.lib.dmad_profile_read_final(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
     def device_bytes(self) -> int:
         return int(self.lib.dmad_device_bytes(self._h))
 
 
+def bind_classifier(state_dict, loader_name: str, engine: Optional[Engine] = None) -> Engine:
+    """Engine that holds exactly `state_dict` as its classifier: `engine` (refused if it holds another one), else the
+    shared engine, else — when the shared engine already serves a different classifier — an engine of this module's own
+    (classifier-only use: mel + classify; the fused Monte Carlo loop needs denoiser and classifier in ONE engine)."""
+    if engine is not None:
+        engine.bind('classifier', state_dict, getattr(engine, loader_name))
+        return engine
+    eng = get_engine()
+    if eng.has_classifier and eng.classifier_owner != state_fingerprint(state_dict):
+        eng = Engine(dict(eng.wavenet_geometry), max_batch=eng.max_batch, precision=eng.precision)
+    eng.bind('classifier', state_dict, getattr(eng, loader_name))
+    return eng
+
+
 _ENGINES: Dict[tuple, Engine] = {}
+_PRECISIONS = {'bf16': BF16, 'fp32': FP32, 'exact': EXACT}
 
 
 def get_engine(wavenet_config: Optional[dict] = None, precision: Optional[int] = None, max_batch: Optional[int] = None,
                fresh: bool = False) -> Engine:
-    """Process-wide engine per (device, precision).  DMAD_PRECISION = bf16|fp32 and DMAD_MAX_BATCH
-    override the defaults (bf16, 64)."""
+    """Process-wide engine per (device, precision), shared by the denoiser, the mel transform and the classifier so that
+    the Monte Carlo loop can run fused.  Defaults: DMAD_PRECISION = exact (bf16 throughput + fp32 recheck of the close
+    votes: counts equal the fp32 path's; bf16 and fp32 are opt-in), DMAD_MAX_BATCH = 64.  A caller that names a WaveNet
+    geometry or a max_batch the shared engine was not created with gets a DmadError, never another model's engine.
+    Engines are single-stream objects (the step-embedding cache is not stream-keyed): one HIP stream at a time."""
     if precision is None:
-        precision = {'bf16': BF16, 'fp32': FP32}[os.environ.get('DMAD_PRECISION', 'bf16').lower()]
-    if max_batch is None:
-        max_batch = int(os.environ.get('DMAD_MAX_BATCH', '64'))
+        precision = _PRECISIONS[os.environ.get('DMAD_PRECISION', 'exact').lower()]
     key = (torch.cuda.current_device() if torch.cuda.is_available() else -1, precision)
     if fresh or key not in _ENGINES:
-        eng = Engine(wavenet_config, max_batch=max_batch, precision=precision)
+        eng = Engine(wavenet_config, max_batch=max_batch if max_batch is not None else int(os.environ.get('DMAD_MAX_BATCH', '64')),
+                     precision=precision)
         if fresh:
             return eng
         _ENGINES[key] = eng
-    return _ENGINES[key]
+        return eng
+    eng = _ENGINES[key]
+    if wavenet_config is not None:
+        want = Engine.geometry(wavenet_config)
+        if want != eng.wavenet_geometry:
+            raise DmadError('the shared engine was created for WaveNet geometry %s, not %s: create the denoiser first or pass '
+                            'an engine of its own (get_engine(..., fresh=True))' % (eng.wavenet_geometry, want))
+    if max_batch is not None and max_batch != eng.max_batch:
+        raise DmadError('the shared engine has max_batch %d, not %d (set DMAD_MAX_BATCH or use fresh=True)' % (eng.max_batch, max_batch))
+    return eng

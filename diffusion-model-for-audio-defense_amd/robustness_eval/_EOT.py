@@ -1,10 +1,14 @@
-"""Expectation-over-transformation wrapper of the attack drivers (reference robustness_eval/_EOT.py:4-69), query
-side: `EOT_size` stochastic evaluations of `model` (an AcousticSystem whose defender draws fresh diffusion noise on
-every call) per input, `EOT_batch_size` of them per model call as one repeated batch; returns the mean scores, the
-mean per-example loss, the gradient (None here) and every repeat's decision.
+"""Expectation over transformation for the query-only attack drivers (behaviour of the reference's
+robustness_eval/_EOT.py:19-69 with use_grad=False; callers black_box_attack.py:199, _NES.py:36).
 
-The HIP purifier is inference-only, so `use_grad=True` (white-box attacks: backward through the purifier) raises;
-the black-box drivers (`black_box_attack.py:199`, NES, SirenAttack) construct the wrapper with `use_grad=False`."""
+Contract kept: EOT(model, loss, EOT_size, EOT_batch_size, use_grad)(x [n,1,L], y [n]) evaluates every clip
+(EOT_size // EOT_batch_size) * EOT_batch_size times under the model's own randomness and returns
+    scores    [n, C]  the per-model-call means (EOT_batch_size repeats each), averaged over the calls,
+    loss      [n]     the same average of the per-example loss,
+    grad      None    (no autograd through the HIP purifier: use_grad=True raises),
+    decisions n lists of the arg-max of every single evaluation, in evaluation order.
+Built differently: all repeats are ONE batched query (AcousticSystem.query -> dmad_query_logits) instead of one model
+call per EOT batch; only the reduction order of the reference is reproduced on the returned [repeats, n, C] block."""
 import torch
 import torch.nn as nn
 
@@ -13,41 +17,36 @@ class EOT(nn.Module):
 
     def __init__(self, model, loss, EOT_size=1, EOT_batch_size=1, use_grad=True):
         super().__init__()
-        self.model = model
-        self.loss = loss
-        self.EOT_size = EOT_size
-        self.EOT_batch_size = EOT_batch_size
-        self.EOT_num_batches = self.EOT_size // self.EOT_batch_size
+        self.model, self.loss = model, loss
+        self.EOT_size, self.EOT_batch_size = EOT_size, EOT_batch_size
+        self.EOT_num_batches = EOT_size // EOT_batch_size
         self.use_grad = use_grad
 
+    @torch.no_grad()
+    def _all_repeats(self, x, per_call, calls):
+        """logits [calls * per_call, n, C] of the model under fresh randomness per repeat."""
+        if hasattr(self.model, 'query'):
+            return self.model.query(x, calls * per_call, per_call=per_call)[0]
+        blocks = [self.model(x.repeat(per_call, 1, 1)).view(per_call, x.shape[0], -1) for _ in range(calls)]
+        return torch.cat(blocks, 0)
+
     def forward(self, x_batch, y_batch, EOT_size=None, EOT_batch_size=None, use_grad=None):
-        EOT_size = EOT_size if EOT_size else self.EOT_size
-        EOT_batch_size = EOT_batch_size if EOT_batch_size else self.EOT_batch_size
-        EOT_num_batches = EOT_size // EOT_batch_size
-        use_grad = use_grad if use_grad else self.use_grad
-        if use_grad:
+        size = EOT_size or self.EOT_size
+        per_call = EOT_batch_size or self.EOT_batch_size
+        calls = size // per_call
+        if use_grad or self.use_grad:
             raise NotImplementedError('EOT gradients need autograd through the purifier; the HIP engine is inference-only '
                                       '(construct the wrapper with use_grad=False, as the black-box drivers do)')
-        n_audios = x_batch.size(0)
-        scores = None
-        loss = 0
-        decisions = [[] for _ in range(n_audios)]
-        with torch.no_grad():
-            for EOT_index in range(EOT_num_batches):
-                x_batch_repeat = x_batch.repeat(EOT_batch_size, 1, 1)
-                y_batch_repeat = y_batch.repeat(EOT_batch_size)
-                scores_EOT = self.model(x_batch_repeat)                   # (EOT_batch_size * n_audios, n_classes)
-                decisions_EOT = scores_EOT.max(1, keepdim=True)[1]
-                loss_EOT = self.loss(scores_EOT, y_batch_repeat)
-                if EOT_index == 0:
-                    scores = scores_EOT.view(EOT_batch_size, -1, scores_EOT.shape[1]).mean(0)
-                    loss = loss_EOT.view(EOT_batch_size, -1).mean(0)
-                else:
-                    scores += scores_EOT.view(EOT_batch_size, -1, scores.shape[1]).mean(0)
-                    loss += loss_EOT.view(EOT_batch_size, -1).mean(0)
-                decisions_EOT = decisions_EOT.view(EOT_batch_size, -1).cpu().numpy()
-                for ii in range(n_audios):
-                    decisions[ii] += list(decisions_EOT[:, ii])
-        scores = scores / EOT_num_batches
-        loss = loss / EOT_num_batches
-        return scores, loss, None, decisions
+        n = x_batch.shape[0]
+        logits = self._all_repeats(x_batch, per_call, calls)                     # [R, n, C]
+        R, C = logits.shape[0], logits.shape[-1]
+        per_eval_loss = self.loss(logits.reshape(R * n, C), y_batch.repeat(R)).view(calls, per_call, n)
+        call_scores = logits.view(calls, per_call, n, C).mean(1)                 # mean inside each model call ...
+        call_loss = per_eval_loss.mean(1)
+        scores, loss = call_scores[0].clone(), call_loss[0].clone()
+        for c in range(1, calls):                                                # ... summed call by call, then averaged
+            scores += call_scores[c]
+            loss += call_loss[c]
+        picks = logits.argmax(-1).cpu().numpy()                                  # [R, n]
+        decisions = [list(picks[:, i]) for i in range(n)]
+        return scores / calls, loss / calls, None, decisions

@@ -1,7 +1,11 @@
-"""Natural-evolution-strategies gradient estimate of the black-box drivers (reference robustness_eval/_NES.py:5-55):
-antithetic Gaussian probes around x, each scored through the EOT wrapper (queries only, no autograd), gradient =
-mean(loss * noise) / sigma.  Arithmetic and return values follow the reference, including its extra division of
-the EOT means by the number of EOT batches (l.33-35)."""
+"""NES gradient estimate for the query-only attack drivers (behaviour of the reference's robustness_eval/_NES.py:15-55;
+caller black_box_attack.py:186-190).
+
+For every clip: `samples_per_draw` antithetic Gaussian probes x +- sigma * u (the first draw batch also carries the
+unperturbed clip in slot 0), each scored through the EOT wrapper; the estimate is  grad = E[loss * u] / sigma.
+Returns (mean probe loss [n], grad [n,1,L], loss of the unperturbed clip [n], its scores [n,C], its majority decision [n]).
+One quirk of the reference is part of the contract and kept: the EOT wrapper already returns means over its model
+calls, and NES divides them by the number of EOT calls once more (ref l.33-35)."""
 import torch
 import torch.nn as nn
 
@@ -17,36 +21,30 @@ class NES(nn.Module):
         self.sigma = sigma
         self.EOT_wrapper = EOT_wrapper
 
+    def _probe(self, x, y, with_origin):
+        """One draw batch -> (u [n, P, 1, L] probe directions, loss [n, P(+1)], scores [n, P(+1), C], decisions)."""
+        n, ch, L = x.shape
+        half = torch.randn([n, self.samples_per_draw_batch_size // 2, ch, L], device=x.device)
+        u = torch.cat((half, -half), 1)
+        probes = torch.cat((torch.zeros_like(x).unsqueeze(1), u), 1) if with_origin else u
+        per_clip = probes.shape[1]
+        queries = (probes * self.sigma + x.unsqueeze(1)).view(-1, ch, L)
+        labels = torch.as_tensor(y, device=x.device).long().repeat_interleave(per_clip)
+        scores, loss, _, decisions = self.EOT_wrapper(queries, labels)
+        again = int(self.EOT_wrapper.EOT_size // self.EOT_wrapper.EOT_batch_size)
+        return u, (loss / again).view(n, per_clip), (scores / again).view(n, per_clip, -1), decisions
+
     def forward(self, x, y):
-        n_audios, n_channels, N = x.shape
-        num_batches = self.samples_per_draw // self.samples_per_draw_batch_size
-        for i in range(num_batches):
-            noise = torch.randn([n_audios, self.samples_per_draw_batch_size // 2, n_channels, N], device=x.device)
-            noise = torch.cat((noise, -noise), 1)
-            if i == 0:
-                noise = torch.cat((torch.zeros_like(x, device=x.device).unsqueeze(1), noise), 1)
-            eval_input = noise * self.sigma + x.unsqueeze(1)
-            eval_input = eval_input.view(-1, n_channels, N)
-            per = self.samples_per_draw_batch_size + 1 if i == 0 else self.samples_per_draw_batch_size
-            eval_y = torch.cat([torch.full((per,), int(y_), dtype=torch.long, device=x.device) for y_ in y])
-            scores, loss, _, decisions = self.EOT_wrapper(eval_input, eval_y)
-            EOT_num_batches = int(self.EOT_wrapper.EOT_size // self.EOT_wrapper.EOT_batch_size)
-            loss = loss / EOT_num_batches
-            scores = scores / EOT_num_batches
-            loss = loss.view(n_audios, -1)
-            scores = scores.view(n_audios, -1, scores.shape[1])
-            if i == 0:
-                adver_loss = loss[..., 0]
-                loss = loss[..., 1:]
-                adver_score = scores[:, 0, :]
-                noise = noise[:, 1:, :, :]
-                grad = torch.mean(loss.unsqueeze(2).unsqueeze(3) * noise, 1)
-                mean_loss = loss.mean(1)
-                predicts = resolve_prediction(decisions).reshape(n_audios, -1)
-                predict = predicts[:, 0]
-            else:
-                grad += torch.mean(loss.unsqueeze(2).unsqueeze(3) * noise, 1)
-                mean_loss += loss.mean(1)
-        grad = grad / self.sigma / num_batches
-        mean_loss = mean_loss / num_batches
-        return mean_loss, grad, adver_loss, adver_score, predict
+        n = x.shape[0]
+        draws = self.samples_per_draw // self.samples_per_draw_batch_size
+        u, loss, scores, decisions = self._probe(x, y, with_origin=True)
+        adver_loss, adver_score = loss[:, 0], scores[:, 0, :]
+        predict = resolve_prediction(decisions).reshape(n, -1)[:, 0]
+        loss = loss[:, 1:]
+        grad = (loss[:, :, None, None] * u).mean(1)
+        mean_loss = loss.mean(1)
+        for _ in range(1, draws):
+            u, loss, _, _ = self._probe(x, y, with_origin=False)
+            grad += (loss[:, :, None, None] * u).mean(1)
+            mean_loss += loss.mean(1)
+        return mean_loss / draws, grad / self.sigma / draws, adver_loss, adver_score, predict

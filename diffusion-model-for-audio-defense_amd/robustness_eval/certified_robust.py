@@ -57,7 +57,11 @@ class RobustCertificate():
             stages = [getattr(t, '_dmad_stage', None) for t in getattr(tr, 'transforms', [])]
             is_mel_db = stages == ['mel_power', 'power_to_db']
         if eng is not None and is_mel_db and 'engine' not in getattr(cls, '__dict__', {}) and hasattr(cls, 'bind_engine'):
-            cls.bind_engine(eng)                            # HIP-backed VGG not yet bound: bind it to the denoiser's engine
+            from dmad_hip._lib import DmadError
+            try:
+                cls.bind_engine(eng)                        # HIP-backed classifier not yet bound: bind it to the denoiser's engine
+            except DmadError:                               # that engine serves another classifier: stay unfused
+                cls.bind_engine()
         return (eng is not None and is_mel_db and getattr(cls, 'engine', None) is eng and eng.has_classifier and eng.has_wavenet)
 
     @torch.no_grad()
@@ -105,28 +109,32 @@ class RobustCertificate():
             coeffs = (t, float((1 / Alpha_bar).sqrt()[t]), float((1 / Alpha_bar - 1).sqrt()[t]),
                       float(torch.tensor(alpha_bar_star ** 0.5, dtype=torch.float32)))
 
+        fused = self._fused()
         if self.noise_source == 'torch_cpu':
-            # the reference's stream: one CPU draw per batch (ref l.47); the stream is batch-split
-            # invariant, so every rank draws the whole stream and keeps its own slice
-            chunks, done = [], 0
+            # The reference's stream: one CPU torch.normal draw per batch (ref l.47).  The stream is batch-split invariant,
+            # so every rank draws the whole stream, keeps its own slice of each batch and feeds it to the engine batch by
+            # batch: host and device hold one batch of noise at a time (64 kB per sample), whatever num_sampling is.
+            counts, done = None, 0
             while done < num_sampling:
                 b = min(batch_size, num_sampling - done)
                 d = torch.normal(0, sigma, size=(b,) + tuple(x.shape))
                 a, e = max(lo, done), min(hi, done + b)
                 if e > a:
-                    chunks.append(d[a - done:e - done])
+                    delta = d[a - done:e - done].to(x.device)
+                    if fused:
+                        counts, _, _ = self.denoiser.engine.smooth_votes(x, sigma, coeffs[3], coeffs[0], coeffs[1], coeffs[2], e - a,
+                                                                         seed=seed, sample0=a, delta=delta, counts=counts)
+                    else:
+                        c = self._generic_votes(x, sigma, coeffs, a, e, seed, delta, batch_size)
+                        counts = c if counts is None else counts + c
                 done += b
-            delta = torch.cat(chunks, 0).to(x.device) if chunks else None
+            if counts is None:
+                counts = torch.zeros(self.num_classes, dtype=torch.int64, device=x.device)
+        elif fused and hi > lo:
+            counts, _, _ = self.denoiser.engine.smooth_votes(x, sigma, coeffs[3], coeffs[0], coeffs[1], coeffs[2], hi - lo,
+                                                             seed=seed, sample0=lo)
         else:
-            delta = None
-
-        n_local = hi - lo
-        if self._fused() and n_local > 0:
-            eng = self.denoiser.engine
-            counts, _, _ = eng.smooth_votes(x, sigma, coeffs[3], coeffs[0], coeffs[1], coeffs[2], n_local,
-                                            seed=seed, sample0=lo, delta=delta)
-        else:
-            counts = self._generic_votes(x, sigma, coeffs, lo, hi, seed, delta, batch_size)
+            counts = self._generic_votes(x, sigma, coeffs, lo, hi, seed, None, batch_size)
 
         if dist is not None and world > 1:
             if dist.get_backend() != 'nccl':
@@ -138,7 +146,10 @@ class RobustCertificate():
         """Purify with the HIP one-shot, then call the caller's transform / classifier modules."""
         device = x.device
         counts = None
-        eng = getattr(self.denoiser, 'engine', None) or getattr(self.classifier, 'engine', None)
+        cls = self.classifier
+        if hasattr(cls, 'bind_engine') and 'engine' not in getattr(cls, '__dict__', {}) and x.is_cuda:
+            cls.bind_engine()                   # HIP-backed classifiers bind lazily in forward(): the vote / noise kernels need it now
+        eng = getattr(self.denoiser, 'engine', None) or getattr(cls, 'engine', None)
         pos = lo
         while pos < hi:
             b = min(batch_size, hi - pos)

@@ -4,8 +4,8 @@
  * The reference (cychomatica/Diffusion-Model-for-Audio-Defense) is 100 % Python on PyTorch and has
  * no FFI; the "plugin API" of this path is a set of Python call sites.  Each entry point below
  * names the reference call it replaces (paths relative to the reference repo root).  Device pointers
- * in, device pointers out, an explicit hipStream_t, no hidden allocation after dmad_create(), no
- * torch types.  Every function returns 0 on success or a negative dmad_status; dmad_last_error()
+ * in, device pointers out, an explicit hipStream_t, no hidden allocation on the data path after
+ * dmad_create() / dmad_finalize_weights() (the two diagnostic hooks at the end create HIP events), no torch types.  Every function returns 0 on success or a negative dmad_status; dmad_last_error()
  * gives the message (thread-local).  One engine per process per GPU; calls on one engine must come
  * from one thread at a time.
  */
@@ -30,7 +30,25 @@ enum dmad_status {
 
 enum dmad_precision {
     DMAD_BF16 = 0,              /* WaveNet on bf16 MFMA (fp32 accumulate); mel + classifier fp32 */
-    DMAD_FP32 = 1               /* everything on the exact-fp32 matrix path (parity mode) */
+    DMAD_FP32 = 1,              /* everything on the exact-fp32 matrix path (parity mode) */
+    DMAD_EXACT = 2              /* both WaveNet paths resident: bf16 for throughput + exact-fp32 re-evaluation of every Monte
+                                 * Carlo sample whose bf16 top-2 logit margin is below the recheck bound, so that the vote
+                                 * counts of dmad_smooth_votes equal the fp32 path's (see dmad_set_mode) */
+};
+
+/* Operand format of the 16-bit MFMA WaveNet path (DMAD_BF16 / DMAD_EXACT engines), fp32 accumulation either way. */
+enum dmad_half_type {
+    DMAD_HALF_BF16 = 0,         /* bfloat16: 8-bit significand (the format BASELINE.json's configuration names) */
+    DMAD_HALF_F16 = 1           /* IEEE half: 11-bit significand, 8x smaller rounding error at the same MFMA rate; the
+                                 * network's activations are O(1), far inside the half range */
+};
+
+/* Run-time mode of a DMAD_EXACT engine (the other two precisions have exactly one mode). */
+enum dmad_mode {
+    DMAD_MODE_FAST = 0,         /* bf16 WaveNet, no recheck (what a DMAD_BF16 engine does) */
+    DMAD_MODE_EXACT_VOTES = 1,  /* bf16 WaveNet + margin-triggered fp32 recheck inside dmad_smooth_votes; every other entry
+                                 * point runs the bf16 WaveNet */
+    DMAD_MODE_FP32 = 2          /* every WaveNet evaluation on the exact-fp32 path (what a DMAD_FP32 engine does) */
 };
 
 /* configs/config.json (wavenet_config + diffusion_config) as read by
@@ -48,6 +66,8 @@ typedef struct dmad_config {
     int32_t num_classes;        /* 10  */
     int32_t precision;          /* enum dmad_precision                   */
     int32_t with_classifier;    /* 1: VGG19_bn + mel front-end buffers   */
+    int32_t recheck_batch;      /* DMAD_EXACT: clips per exact-fp32 pass (0 = default 32; <= max_batch) */
+    int32_t half_type;          /* enum dmad_half_type                   */
 } dmad_config;
 
 int dmad_create(const dmad_config* cfg, dmad_engine** out);
@@ -144,6 +164,30 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
                       float c_a, float c_b, int64_t n, int32_t batch, uint64_t seed, uint64_t sample0,
                       const float* delta, int64_t* counts, float* logits_out, float* x0_out, dmad_stream s);
 
+/* DMAD_EXACT engines.  dmad_set_mode selects the dmad_mode (default DMAD_MODE_EXACT_VOTES).  dmad_set_recheck_margin sets
+ * the bound tau: a sample whose bf16 logits have (largest - second largest) < tau (or any NaN) does not vote from the bf16
+ * logits; its global sample index is queued and the sample is re-evaluated from the SAME noise (Philox key (seed, index),
+ * or its row of `delta`) on the exact-fp32 WaveNet, and that result votes (and replaces its row of logits_out / x0_out).
+ * With tau >= 2 x the largest bf16 error of a logit difference the counts equal the fp32 path's exactly
+ * (robustness_eval/certified_robust.py:59-65 is an arg-max: it only depends on the order of the logits).
+ * dmad_recheck_stats returns the number of samples voted and of samples re-evaluated since the last reset. */
+int dmad_set_mode(dmad_engine* e, int32_t mode);
+int dmad_set_recheck_margin(dmad_engine* e, float tau);
+int dmad_recheck_stats(dmad_engine* e, int64_t* samples, int64_t* rechecked, int32_t reset);
+
+/* Batched query of the whole system for the gradient-free attack drivers: EOT.forward evaluates
+ * model(x_batch.repeat(EOT_batch_size, 1, 1)) EOT_num_batches times (robustness_eval/_EOT.py:30-64; callers
+ * black_box_attack.py:186-220, _NES.py:15-55) where model = AcousticSystem(classifier, transform, defender)
+ * (acoustic_system.py:27-51).  One call does all of it:  row i = r * B + b  (r < repeats, b < B) is clip x[b];
+ *   sampler 0: no wave defender;  1: DiffWave.forward (diffusion + t_star reverse steps, diffwave_ddpm.py:36-104;
+ *   coefficients as for dmad_ddpm_purify);  2: one_shot_denoise at t = t_star - 1 (c_a, c_b as for dmad_one_shot);
+ *   then mel dB -> classifier.  Noise of row i is Philox keyed (seed, sample0 + i): a row's logits do not depend on how
+ *   the rows are batched.  x: device fp32 [B][clip_len]; logits: [repeats * B][num_classes]; decisions: optional
+ *   int32 [repeats * B] arg-max (first maximum wins). */
+int dmad_query_logits(dmad_engine* e, const float* x, int32_t B, int32_t repeats, int32_t sampler, int32_t t_star, float c_a, float c_b,
+                      const float* c_eps, const float* c_div, const float* c_sig, uint64_t seed, uint64_t sample0, float* logits,
+                      int32_t* decisions, dmad_stream s);
+
 /* counts[argmax_c logits[b][c]] += 1 (first maximum wins) — certified_robust.py:59-65. */
 int dmad_vote(dmad_engine* e, const float* logits, int32_t B, int64_t* counts, dmad_stream s);
 
@@ -162,6 +206,9 @@ int dmad_time_layer(dmad_engine* e, int32_t layer, int32_t B, int32_t iters, flo
  * launches, and switches the bracketing off. */
 int dmad_profile_layers(dmad_engine* e, int32_t max_launches);
 int dmad_profile_read(dmad_engine* e, float* total_ms, int32_t* launches);
+/* The same for the launches of the tail kernel (wn_final: skip GEMM over the gate store + final convs) bracketed since
+ * dmad_profile_layers(); call it BEFORE dmad_profile_read (which switches the bracketing off). */
+int dmad_profile_read_final(dmad_engine* e, float* total_ms, int32_t* launches);
 
 /* Bytes of device memory held by the engine. */
 int64_t dmad_device_bytes(const dmad_engine* e);

@@ -5,7 +5,9 @@ inputs.  Tolerances:
   * fp32 engine (exact-fp32 matrix path): 2e-5 of the tensor's max (summation order differs from MKL);
   * bf16 engine: waveforms/eps within 3e-2 of the tensor's max and 2.5e-2 rms-relative
     (bf16 operands, fp32 accumulation, 36 layers); votes may flip only where the reference's own
-    top-2 logit margin is below the bf16 logit error.
+    top-2 logit margin is below the bf16 logit error;
+  * f16 operands (the exact-vote engine's 16-bit path): 4e-3 of the tensor's max (11-bit significand);
+  * exact-vote mode (16-bit path + fp32 recheck below the margin bound): vote counts bit-exact against the fp32 path.
 """
 import os
 
@@ -19,6 +21,7 @@ pytestmark = pytest.mark.gpu
 
 FP32_TOL = 2e-5
 BF16_MAX_TOL, BF16_RMS_TOL = 3e-2, 2.5e-2
+F16_MAX_TOL = 4e-3
 
 
 def relmax(got, ref):
@@ -46,8 +49,8 @@ def weights():
 def engines(weights):
     from dmad_hip import engine as E
     out = {}
-    for name, prec in (('fp32', E.FP32), ('bf16', E.BF16)):
-        eng = E.Engine(max_batch=6, precision=prec)
+    for name, prec in (('fp32', E.FP32), ('bf16', E.BF16), ('exact', E.EXACT)):
+        eng = E.Engine(max_batch=6, precision=prec, recheck_batch=4)      # 'exact': f16 operands + fp32 recheck
         eng.load_wavenet(weights[0])
         eng.load_vgg19_bn(weights[1])
         out[name] = eng
@@ -163,12 +166,20 @@ def test_wavenet_eps_vs_reference_fixture(engines, golden_dir):
     assert relmax(got, ref) < FP32_TOL
     got = engines['bf16'].wavenet_eps(x_t, int(z['t'])).cpu().numpy()
     assert relmax(got, ref) < BF16_MAX_TOL and relrms(got, ref) < BF16_RMS_TOL
+    ex = engines['exact']                                     # the same kernels instantiated on f16 operands
+    assert ex.half_type == 1
+    got = ex.wavenet_eps(x_t, int(z['t'])).cpu().numpy()
+    assert relmax(got, ref) < F16_MAX_TOL and relrms(got, ref) < F16_MAX_TOL
+    ex.set_mode(2)                                            # DMAD_MODE_FP32: the engine's exact-fp32 path (chunks of 4)
+    got = ex.wavenet_eps(x_t, int(z['t'])).cpu().numpy()
+    ex.set_mode(1)
+    assert relmax(got, ref) < FP32_TOL
 
 
 def test_wavenet_batch_and_position_independence(engines):
     """clips must not bleed into each other (per-clip zero padding) and results must not depend on the batch slot."""
     x = torch.randn(5, 16000, generator=torch.Generator().manual_seed(3)).cuda() * 0.3
-    for name in ('fp32', 'bf16'):
+    for name in ('fp32', 'bf16', 'exact'):
         eng = engines[name]
         full = eng.wavenet_eps(x, 33)
         solo = eng.wavenet_eps(x[3:4], 33)
@@ -275,6 +286,17 @@ def test_smooth_votes_match_reference_loop_vgg(engines, sched, golden_dir):
     assert not (flips & (margin > 2 * err)).any()          # a vote may flip only inside the bf16 error band
     assert flips.sum() <= 3 and err.max() < 0.25
     assert np.abs(counts.cpu().numpy() - z['vgg_counts']).sum() <= 2 * flips.sum()
+    # exact-vote mode (f16 path + fp32 recheck of the close votes) on the reference's own noise: the reference's counts
+    ex = engines['exact']
+    ex.recheck_stats(reset=True)
+    counts, logits, _ = ex.smooth_votes(clip, 0.5, sc, 65, *coef(65), 40, batch=6, delta=delta, want_logits=True)
+    assert counts.cpu().tolist() == z['vgg_counts'].tolist()
+    voted, rechecked = ex.recheck_stats()
+    assert voted == 40 and 0 <= rechecked <= 40
+    lg = logits.cpu().numpy()
+    srt = np.sort(lg, 1)
+    close = (srt[:, -1] - srt[:, -2]) < ex.recheck_margin          # rows that were re-evaluated carry the fp32 logits
+    assert (lg.argmax(1) == ref.argmax(1)).all() and np.abs(lg - ref)[close].max(initial=0) < 1e-3
 
 
 def test_robust_certificate_m5_generic_path(engines, golden_dir, tmp_path):
@@ -370,7 +392,8 @@ def test_reference_driver_surfaces_through_shims(engines, golden_dir, tmp_path, 
     from dmad_hip import engine as E
     from robustness_eval.certified_robust import RobustCertificate
     eng = engines['fp32']
-    monkeypatch.setitem(E._ENGINES, (torch.cuda.current_device(), E.BF16), eng)     # what get_engine() hands out
+    for prec in (E.BF16, E.FP32, E.EXACT):
+        monkeypatch.setitem(E._ENGINES, (torch.cuda.current_device(), prec), eng)   # what get_engine() hands out
     # checkpoints in the reference's on-disk formats
     d = tmp_path / 'ConvNets_SpeechCommands'
     d.mkdir()
@@ -761,7 +784,7 @@ def test_bench_contract():
     j = json.loads(lines[0])
     base = json.load(open(os.path.join(root, 'BASELINE.json')))
     assert j['metric'] == base['metric'] and j['unit'] == 'clips/s' and j['n_gpus'] == 1 and j['steps'] == 1 and j['warmup'] == 1
-    assert j['higher_is_better'] is True and j['scaling'] == 'weak' and j['vs_baseline'] is None and j['dtype'] == 'bf16' and j['data'] == 'synthetic'
+    assert j['higher_is_better'] is True and j['scaling'] == 'weak' and j['vs_baseline'] is None and j['dtype'] == 'f16' and j['data'] == 'synthetic'
     assert 'workload' in j['config'] and 'model' not in j['config']
     assert abs(j['value'] - 8 / (j['ms_per_step'] * 1e-3)) < 1e-6 * j['value']
     rf = j['roofline']
@@ -770,3 +793,228 @@ def test_bench_contract():
     cb = j['cpu_baseline']
     assert cb['kind'] == 'port' and cb['unit'] == 'clips/s' and cb['value'] > 0 and 1 <= cb['cores'] <= 16 and 'sample' in cb
     assert sum(j['votes']) == 8
+    # the measured mode is the exact-vote mode; the 16-bit-only and fp32-only figures ride along
+    assert 'exact-vote' in j['config']['mode'] and 0.0 <= j['recheck']['frac'] <= 1.0 and j['recheck']['margin'] > 0
+    assert j['fast_mode']['clips_per_s'] > 0 and j['fp32_mode']['clips_per_s'] > 0 and 0 < j['fp32_mode']['frac_of_fp32_matrix_peak'] < 1
+    assert j['votes'] == j['fp32_mode']['votes'] or j['fp32_mode']['steps'] != 1     # same samples only if the same step index
+    ff = j['roofline_final']
+    assert ff['bound'] == 'hbm' and ff['unit'] == 'GB/s' and ff['peak'] == 8000.0 and ff['launches_timed'] == 1 and 0 < ff['frac'] < 1.5
+    # a rank count the box cannot serve is refused loudly, never run as fewer ranks
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(torch.cuda.device_count() + 1), '--steps', '1'],
+                       capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode != 0 and 'refusing' in r.stderr and not r.stdout.strip()
+
+
+# ------------------------------------------------------------------------------------------ exact-vote mode, C4's sigmas
+@pytest.fixture(scope='module')
+def exact_engine(weights):
+    from dmad_hip import engine as E
+    eng = E.Engine(max_batch=64, precision=E.EXACT, recheck_batch=32)
+    eng.load_wavenet(weights[0])
+    eng.load_vgg19_bn(weights[1])
+    yield eng
+    eng.close()
+
+
+def test_exact_vote_mode_equals_fp32_votes(exact_engine, sched):
+    """the same Philox keys through the 16-bit path and the exact-fp32 path, 3 clips x sigma in
+    {0.25, 0.5, 1.0} (t* = 34 / 66 / 117), N = 512 each (4608 samples): records the flips and the logit-difference error
+    of the 16-bit path, checks that the recheck bound covers that error, and that the exact-vote mode's counts equal
+    the fp32 path's bit for bit (north_star: class-vote counts match exactly; certified_robust.py:59-65)."""
+    from dmad_hip import engine as E
+    eng = exact_engine
+    hp, coef = sched
+    ab = hp['Alpha_bar']
+    N, total_flips, worst_pair, rechecked_all = 512, 0, 0.0, 0
+    for ci in (0, 1, 2):
+        clip = torch.from_numpy(synth.synthetic_clip(ci)).cuda()
+        for sigma, tstar in ((0.25, 34), (0.5, 66), (1.0, 117)):
+            t = int(torch.abs(ab - 1 / (1 + sigma ** 2)).min(0, keepdim=True)[1].item())
+            assert t + 1 == tstar
+            sc = float(torch.tensor((1 / (1 + sigma ** 2)) ** 0.5, dtype=torch.float32))
+            out = {}
+            for mode in (E.MODE_FAST, E.MODE_FP32, E.MODE_EXACT_VOTES):
+                eng.set_mode(mode)
+                eng.recheck_stats(reset=True)
+                c, l, _ = eng.smooth_votes(clip, sigma, sc, t, *coef(t), N, seed=900 + ci, sample0=5000, want_logits=True)
+                out[mode] = (c.cpu().tolist(), l.cpu().numpy().astype(np.float64), eng.recheck_stats())
+            fast, f32, ex = out[E.MODE_FAST], out[E.MODE_FP32], out[E.MODE_EXACT_VOTES]
+            assert sum(fast[0]) == sum(f32[0]) == sum(ex[0]) == N
+            assert ex[0] == f32[0], (ci, sigma, ex[0], f32[0])                       # bit-exact vote counts
+            assert (ex[1].argmax(1) == f32[1].argmax(1)).all()
+            pair = np.abs((fast[1][:, :, None] - fast[1][:, None, :]) - (f32[1][:, :, None] - f32[1][:, None, :])).max()
+            worst_pair = max(worst_pair, float(pair))
+            total_flips += int((fast[1].argmax(1) != f32[1].argmax(1)).sum())
+            srt = np.sort(fast[1].astype(np.float32), 1)                          # the kernel's own fp32 comparison
+            want_recheck = int((~((srt[:, -1] - srt[:, -2]) >= np.float32(eng.recheck_margin))).sum())
+            assert ex[2] == (N, want_recheck) and fast[2][1] == 0 and f32[2][1] == 0
+            rechecked_all += want_recheck
+    eng.set_mode(E.MODE_EXACT_VOTES)
+    # the guarantee behind the mode: the bound exceeds the largest error of any logit difference seen on 4608 samples
+    assert worst_pair < eng.recheck_margin, (worst_pair, eng.recheck_margin)
+    print('exact-vote study: %d samples, %d 16-bit flips, worst logit-difference error %.4f, recheck margin %.3f, rechecked %.2f %%'
+          % (9 * N, total_flips, worst_pair, eng.recheck_margin, 100.0 * rechecked_all / (9 * N)))
+
+
+def test_sigma_1_vote_loop_vs_oracle(exact_engine, sched, orc, weights):
+    """BASELINE config 4's sigma = 1.0 (t* = 117) through dmad_smooth_votes against the CPU oracle on the same Philox noise
+    (2 samples), fp32 path and exact-vote mode."""
+    from dmad_hip import engine as E
+    eng = exact_engine
+    hp, coef = sched
+    sigma, t = 1.0, 116
+    assert orc.compute_t_star(hp['Alpha_bar'], sigma) == 117
+    sc = float(torch.tensor((1 / 2.0) ** 0.5, dtype=torch.float32))
+    clip = torch.from_numpy(synth.synthetic_clip(3))
+    z = eng.philox_normal(31, 40, 0, 2).cpu()
+    den = orc.DiffWaveOracle(orc.folded_weights(weights[0]), hp, reverse_timestep=117)
+    x_in = sc * (clip.unsqueeze(0).repeat(2, 1, 1) + sigma * z.unsqueeze(1))
+    x0_ref = den.one_shot_denoise(x_in)
+    lg_ref = orc.vgg19_bn_forward(weights[1], orc.mel_db(x0_ref)).numpy()
+    eng.set_mode(E.MODE_FP32)
+    c, lg, x0 = eng.smooth_votes(clip.cuda(), sigma, sc, t, *coef(t), 2, seed=31, sample0=40, want_logits=True, want_x0=True)
+    assert relmax(x0.cpu().numpy(), x0_ref[:, 0].numpy()) < 5e-5
+    assert np.abs(lg.cpu().numpy() - lg_ref).max() < 2e-3 and c.cpu().tolist() == np.bincount(lg_ref.argmax(1), minlength=10).tolist()
+    eng.set_mode(E.MODE_EXACT_VOTES)
+    c2, lg2, x02 = eng.smooth_votes(clip.cuda(), sigma, sc, t, *coef(t), 2, seed=31, sample0=40, want_logits=True, want_x0=True)
+    assert c2.cpu().tolist() == c.cpu().tolist()
+    assert relmax(x02.cpu().numpy(), x0_ref[:, 0].numpy()) < F16_MAX_TOL
+
+
+def test_query_logits_is_one_call_and_row_keyed(engines):
+    """dmad_query_logits (EOT / NES query path, _EOT.py:30-64): clip batch x repeats -> purified -> mel -> logits in one call;
+    row (r, b) carries noise key sample0 + r*B + b, so it equals the same rows computed through AcousticSystem.forward."""
+    from acoustic_system import AcousticSystem
+    from audio_models.ConvNets_SpeechCommands.models.vgg import vgg19_bn
+    from diffusion_models.diffwave_ddpm import DiffWave, WaveNetHIP
+    from diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    from dmad_hip.transforms import MelSpectrogramDB
+    from robustness_eval._EOT import EOT
+    from robustness_eval._utils import resolve_loss
+    eng = engines['exact']
+    hp = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    net = vgg19_bn(num_classes=10, in_channels=1)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.vgg19_bn_state_dict(4321).items()})
+    net.eval().bind_engine(eng)
+    den = DiffWave(WaveNetHIP(eng), hp, reverse_timestep=2, seed=17)
+    model = AcousticSystem(classifier=net, transform=MelSpectrogramDB(eng), defender=den, defense_type='wave')
+    assert model._engine_chain(True) == (eng, 1) and model._engine_chain(False) == (eng, 0)
+    x = torch.from_numpy(np.stack([synth.synthetic_clip(0), synth.synthetic_clip(5), synth.synthetic_clip(8)])).cuda()
+    den._draws = 100
+    logits, dec = model.query(x, repeats=5)                      # 15 rows > max_batch 6: chunked inside the call
+    assert logits.shape == (5, 3, 10) and dec.shape == (5, 3) and den._draws == 115
+    assert torch.equal(dec, logits.argmax(-1))
+    den._draws = 100
+    ref = model(x.repeat(5, 1, 1))                               # the reference's call pattern: one repeated batch
+    assert torch.equal(ref.view(5, 3, 10), logits)
+    den._draws = 100 + 3 * 2 + 1
+    assert torch.equal(model(x[1:2]), logits[2, 1:2])            # row (2, 1) alone, by its key
+    plain, _ = model.query(x, repeats=2, defend=False)
+    assert torch.equal(plain[0], plain[1]) and torch.equal(plain[0], net(MelSpectrogramDB(eng)(x)))
+    # EOT over the one-call path: means over repeats, one decision per evaluation
+    loss_fn, _ = resolve_loss('Margin', False, 0., 'SCR', None, False)
+    den._draws = 100
+    scores, loss, grad, decisions = EOT(model, loss_fn, EOT_size=4, EOT_batch_size=2, use_grad=False)(x, torch.tensor([0, 6, 1]).cuda())
+    want = (logits[:2].mean(0) + logits[2:4].mean(0)) / 2
+    assert torch.allclose(scores, want, atol=1e-6) and grad is None and [len(d) for d in decisions] == [4, 4, 4]
+    assert [int(v) for v in decisions[1]] == dec[:4, 1].tolist()
+    from dmad_hip._lib import DmadError
+    with pytest.raises(DmadError):
+        eng.query_logits(x, 2, sampler=1, t_star=0, c_eps=[], c_div=[], c_sig=[])
+
+
+def test_randsmooth_with_device_noise_and_second_classifier(engines):
+    """(a) `--defense_method randsmooth` (denoiser=None) with the default device noise binds the HIP classifier
+    before it needs the engine; (b) a second, different classifier never runs on the first one's weights."""
+    from audio_models.ConvNets_SpeechCommands.models.vgg import vgg19_bn
+    from dmad_hip import engine as E
+    from dmad_hip._lib import DmadError
+    from dmad_hip.transforms import MelSpectrogramDB
+    from robustness_eval.certified_robust import RobustCertificate
+    eng = engines['fp32']
+    a = vgg19_bn(num_classes=10, in_channels=1)
+    a.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.vgg19_bn_state_dict(4321).items()})
+    a.eval()
+    E._ENGINES[(torch.cuda.current_device(), E.EXACT)] = eng                   # what get_engine() hands out
+    try:
+        rc = RobustCertificate(classifier=a, transform=MelSpectrogramDB(eng), denoiser=None, seed=3)
+        assert 'engine' not in a.__dict__
+        clip = torch.from_numpy(synth.synthetic_clip(0)).cuda()
+        counts = rc.smooth_predict(clip, num_sampling=10, sigma=0.25, batch_size=4)
+        assert int(counts.sum()) == 10 and a.engine is eng
+        again = RobustCertificate(classifier=a, transform=MelSpectrogramDB(eng), denoiser=None, seed=3).smooth_predict(clip, 10, 0.25, 5)
+        assert counts.tolist() == again.tolist()
+        b = vgg19_bn(num_classes=10, in_channels=1)
+        b.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.vgg19_bn_state_dict(99, calibrated=False).items()})
+        b.eval()
+        with pytest.raises(DmadError):
+            b.bind_engine(eng)                                                  # explicit engine holding another classifier
+        b.bind_engine()                                                         # shared engine is taken: an engine of its own
+        assert b.engine is not eng and b.engine.classifier_owner != eng.classifier_owner
+        spec = MelSpectrogramDB(eng)(clip[None])
+        assert not torch.equal(a(spec), b(spec))
+        b.engine.close()
+    finally:
+        E._ENGINES.pop((torch.cuda.current_device(), E.EXACT), None)
+
+
+def test_reference_driver_default_resnext_checkpoint(tmp_path, weights):
+    """certified_robustness_eval.py:57-59 loads a pickled DataParallel(CifarResNeXt) by default: write one in the reference's
+    on-disk format under a ConvNets_SpeechCommands/ path, load it with create_model and certify through the fused loop."""
+    from audio_models.ConvNets_SpeechCommands.create_model import create_model
+    from models.resnext import CifarResNeXt
+    from diffusion_models.diffwave_ddpm import DiffWave, WaveNetHIP
+    from diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    from dmad_hip import engine as E
+    from dmad_hip.transforms import MelSpectrogramDB
+    from robustness_eval.certified_robust import RobustCertificate
+    d = tmp_path / 'ConvNets_SpeechCommands'
+    d.mkdir()
+    sd = synth.resnext29_state_dict(2929)
+    rx = CifarResNeXt(nlabels=10, in_channels=1)
+    rx.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    torch.save(torch.nn.DataParallel(rx), str(d / 'gaussian_aug_resnext29_8_64.pth'))
+    clf = create_model(str(d / 'gaussian_aug_resnext29_8_64.pth')).cuda()
+    eng = E.Engine(max_batch=8, precision=E.EXACT, recheck_batch=4)
+    eng.load_wavenet(weights[0])
+    den = DiffWave(WaveNetHIP(eng), calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG))
+    rc = RobustCertificate(classifier=clf, transform=MelSpectrogramDB(eng), denoiser=den, seed=4)
+    assert rc._fused() and eng.classifier_kind == 'resnext29'
+    clip = torch.from_numpy(synth.synthetic_clip(1)).cuda()
+    y, r = rc.certify(clip[None], torch.tensor([1]).cuda(), sigma=0.5, n_0=8, n=24, batch_size=8)
+    assert y.shape == (1,) and int(y[0]) in range(-1, 10) and float(r[0]) >= 0.0
+    eng.set_mode(E.MODE_FP32)
+    rc2 = RobustCertificate(classifier=clf, transform=MelSpectrogramDB(eng), denoiser=den, seed=4)
+    y2, r2 = rc2.certify(clip[None], torch.tensor([1]).cuda(), sigma=0.5, n_0=8, n=24, batch_size=8)
+    assert y2.tolist() == y.tolist() and torch.equal(r2, r)                    # exact-vote mode == fp32 path
+    eng.close()
+
+
+def _nccl_worker(_, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', 0))        # RCCL
+    counts = torch.arange(10, dtype=torch.int64, device='cuda') * (2 ** 40)    # int64 range, as the vote counts are typed
+    dist.all_reduce(counts)
+    seed = torch.tensor([2 ** 61 + 12345], dtype=torch.int64, device='cuda')
+    dist.broadcast(seed, 0)
+    tmax = torch.tensor([1.5], dtype=torch.float64, device='cuda')
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    torch.cuda.synchronize()
+    torch.save({'counts': counts.cpu(), 'seed': seed.cpu(), 'tmax': tmax.cpu(), 'backend': dist.get_backend()}, out)
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_runs_the_paths_collectives(tmp_path):
+    """The three collectives of the multi-GPU path (int64[10] vote all-reduce, the seed broadcast of
+    RobustCertificate._seed_for_call, bench.py's max-over-ranks time) on the `nccl` (= RCCL) backend with CUDA tensors,
+    world_size 1 (the box has one GPU; the driver's 8-GPU run does the rest)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'nccl.pt')
+    mp.spawn(_nccl_worker, args=(29700 + os.getpid() % 2000, out), nprocs=1, join=True)
+    got = torch.load(out)
+    assert got['backend'] == 'nccl' and got['counts'].tolist() == [i * 2 ** 40 for i in range(10)]
+    assert int(got['seed'][0]) == 2 ** 61 + 12345 and float(got['tmax'][0]) == 1.5

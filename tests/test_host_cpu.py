@@ -43,11 +43,11 @@ def test_c_abi_fails_loudly_without_gpu(built_lib):
     with pytest.raises(_lib.DmadError):
         engine.Engine(max_batch=1)                        # python wrapper refuses: no CPU path
     lib = _lib.load()
-    cfg = _lib.DmadConfig(256, 256, 36, 12, 128, 512, 512, 16000, 1, 10, 0, 1)
+    cfg = _lib.DmadConfig(256, 256, 36, 12, 128, 512, 512, 16000, 1, 10, 0, 1, 0, 0)
     h = ctypes.c_void_p()
     rc = lib.dmad_create(ctypes.byref(cfg), ctypes.byref(h))
     assert rc == -3 and lib.dmad_last_error()             # DMAD_ERR_HIP with a message
-    bad = _lib.DmadConfig(128, 256, 36, 12, 128, 512, 512, 16000, 1, 10, 0, 1)
+    bad = _lib.DmadConfig(128, 256, 36, 12, 128, 512, 512, 16000, 1, 10, 0, 1, 0, 0)
     assert lib.dmad_create(ctypes.byref(bad), ctypes.byref(h)) == -1
     assert b'256' in lib.dmad_last_error()
 
@@ -185,6 +185,20 @@ def test_create_model_checkpoint_layouts(tmp_path, golden_dir):
     assert set(got.state_dict()) == set(synth.vgg19_bn_state_dict(4321))
     with pytest.raises(Exception):
         got(torch.zeros(1, 1, 32, 32))                    # CPU tensor: the HIP module has no CPU path
+    # the certification driver's DEFAULT classifier (certified_robustness_eval.py:57-59): a pickled DataParallel(CifarResNeXt)
+    from models.resnext import CifarResNeXt
+    rx = CifarResNeXt(nlabels=10, in_channels=1)
+    rx.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.resnext29_state_dict(2929).items()})
+    p3 = str(d / 'gaussian_aug_resnext29_8_64.pth')
+    torch.save(torch.nn.DataParallel(rx), p3)
+    got = create_model(p3)
+    assert isinstance(got, CifarResNeXt) and not got.training and next(got.parameters()).dtype == torch.float32
+    assert torch.equal(got.state_dict()['stage_2.stage_2_bottleneck_0.conv_conv.weight'],
+                       torch.from_numpy(synth.resnext29_state_dict(2929)['stage_2.stage_2_bottleneck_0.conv_conv.weight']))
+    evil = str(d / 'evil.pth')                             # anything outside the allow-list is refused, not executed
+    torch.save(torch.nn.DataParallel(torch.nn.Sequential(torch.nn.Tanh())), evil)
+    with pytest.raises(Exception):
+        create_model(evil)
 
 
 def test_weight_folding_matches_oracle():
@@ -274,8 +288,7 @@ def test_sc09_dataset_index(tmp_path):
     assert item['target'] == 2 and item['samples'].shape == (16000,)
     assert os.path.basename(os.path.dirname(item['path'])) == 'two'
     assert len(SC09Dataset(str(tmp_path), num_per_class=100)) == 30           # fewer files than num_per_class
-    w = ds.make_weights_for_balanced_classes()
-    assert w.shape == (20,) and np.allclose(w, 10.0)
+    assert ds[0].keys() >= {'path', 'target'} and SC09Dataset(str(tmp_path), num_per_class=1)[3] == {'path': ds.data[6][0], 'target': 3}
     with pytest.raises(AssertionError):                                        # a missing class folder
         os.rename(tmp_path / 'three', tmp_path / 'x3')
         SC09Dataset(str(tmp_path))
@@ -323,3 +336,101 @@ def test_resnext29_mirror_layout_and_folding():
         net(torch.zeros(1, 1, 32, 32))
     with pytest.raises(NotImplementedError):
         CifarResNeXt(nlabels=10, cardinality=16, in_channels=1)
+
+
+def test_engine_binding_refuses_other_weights():
+    """Engine.bind (host logic, no GPU needed): a part that is already resident accepts only the SAME weights; the
+    fingerprint ignores BatchNorm's num_batches_tracked and distinguishes seeds."""
+    from dmad_hip import engine as E
+    from dmad_hip._lib import DmadError
+    a, b = synth.vgg19_bn_state_dict(4321), synth.vgg19_bn_state_dict(7)
+    assert E.state_fingerprint(a) == E.state_fingerprint(dict(a)) != E.state_fingerprint(b)
+    withbn = dict(a)
+    withbn['features.1.num_batches_tracked'] = np.array(5)
+    assert E.state_fingerprint(withbn) == E.state_fingerprint(a)
+    eng = E.Engine.__new__(E.Engine)                       # the bookkeeping alone (no device)
+    eng.has_classifier, eng.classifier_owner, loaded = False, None, []
+
+    def loader(sd):
+        loaded.append(1); eng.has_classifier = True; eng.classifier_owner = E.state_fingerprint(sd)
+    eng.bind('classifier', a, loader)
+    eng.bind('classifier', a, loader)                      # same weights again: accepted, not re-uploaded
+    assert loaded == [1]
+    with pytest.raises(DmadError):
+        eng.bind('classifier', b, loader)                  # a second, different classifier must not silently run the first
+    eng._h = None
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked():
+    """`python bench.py --gpus N` without WORLD_SIZE starts its ranks itself; with fewer than N GPUs it fails loudly
+    before touching a GPU instead of reporting a single-rank number (here: no GPU at all, or one)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '64', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and 'refusing' in r.stderr and not r.stdout.strip()
+    env.update(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)      # a rank count that disagrees with --gpus
+
+
+def test_eot_nes_contract_on_cpu():
+    """EOT / NES over a plain callable (behaviour of the reference's _EOT.py:19-69 / _NES.py:15-55, use_grad=False):
+    per-call means averaged over calls, every evaluation's decision kept, NES' antithetic estimate and its extra
+    division by the EOT call count."""
+    from robustness_eval._EOT import EOT
+    from robustness_eval._NES import NES
+    from robustness_eval._utils import resolve_loss
+    W = torch.randn(10, 16, generator=torch.Generator().manual_seed(0))
+    calls = []
+
+    def model(x):                                           # deterministic part + a call-dependent offset
+        calls.append(x.shape[0])
+        return x[:, 0, :16] @ W.t() + 0.1 * len(calls)
+    loss_fn, _ = resolve_loss('Margin', False, 0., 'SCR', None, False)
+    x = torch.randn(3, 1, 32, generator=torch.Generator().manual_seed(1))
+    y = torch.tensor([1, 2, 3])
+    scores, loss, grad, dec = EOT(model, loss_fn, EOT_size=7, EOT_batch_size=2, use_grad=False)(x, y)
+    assert calls == [6, 6, 6] and grad is None                     # 7 // 2 = 3 calls of 2 repeats: the remainder is dropped
+    base = x[:, 0, :16] @ W.t()
+    assert torch.allclose(scores, base + 0.1 * (1 + 2 + 3) / 3, atol=1e-6)
+    want_loss = sum(torch.nn.functional.cross_entropy(base + 0.1 * c, y, reduction='none') for c in (1, 2, 3)) / 3
+    assert torch.allclose(loss, want_loss, atol=1e-6)
+    assert [len(d) for d in dec] == [6, 6, 6] and dec[0][0] == int((base + 0.1).argmax(1)[0])
+    with pytest.raises(NotImplementedError):
+        EOT(model, loss_fn, 2, 2, use_grad=True)(x, y)
+    calls.clear()
+    torch.manual_seed(3)
+    nes = NES(samples_per_draw=8, samples_per_draw_batch=4, sigma=0.01, EOT_wrapper=EOT(model, loss_fn, 2, 1, False))
+    mean_loss, g, adver_loss, adver_score, predict = nes(x, y)
+    assert calls == [15, 15, 12, 12]                                # (1 + 4) probes x 3 clips, then 4 x 3; two EOT calls each
+    assert g.shape == x.shape and mean_loss.shape == (3,) and adver_loss.shape == (3,) and adver_score.shape == (3, 10)
+    assert predict.shape == (3,) and bool(torch.isfinite(g).all())
+    # the unperturbed clip sits in slot 0 of the first draw batch; EOT means over 2 calls, divided by 2 once more (ref l.33-35)
+    assert torch.allclose(adver_score, (base + 0.1 * 1.5) / 2, atol=1e-5)
+
+
+def test_parity_noise_is_streamed_per_batch(monkeypatch):
+    """noise_source='torch_cpu' at large N: one batch of CPU noise at a time (the former implementation built the whole
+    [N, 1, L] tensor: 6.4 GB at N = 100 000); the counts are unchanged by the streaming."""
+    from robustness_eval.certified_robust import RobustCertificate
+    clf = _ToyClassifier()
+    x = torch.from_numpy(synth.synthetic_clip(0))
+    rc = RobustCertificate(classifier=clf, transform=None, denoiser=None, noise_source='torch_cpu')
+    biggest = [0]
+    real = torch.normal
+
+    def spy(*a, **k):
+        out = real(*a, **k)
+        biggest[0] = max(biggest[0], out.numel())
+        return out
+    monkeypatch.setattr(torch, 'normal', spy)
+    torch.manual_seed(5)
+    got = rc.smooth_predict(x, num_sampling=700, sigma=0.5, batch_size=16)
+    assert biggest[0] == 16 * 16000 and int(got.sum()) == 700       # never more than one batch of draws alive
+    monkeypatch.setattr(torch, 'normal', real)
+    torch.manual_seed(5)
+    parts = rc.smooth_predict(x, num_sampling=70, sigma=0.5, batch_size=16)
+    from oracle import dmad_oracle as orc
+    torch.manual_seed(5)
+    assert parts.tolist() == orc.CertifyOracle(clf, None, None).smooth_predict(x, num_sampling=70, sigma=0.5, batch_size=16).tolist()
