@@ -168,8 +168,9 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
  * the bound tau: a sample whose bf16 logits have (largest - second largest) < tau (or any NaN) does not vote from the bf16
  * logits; its global sample index is queued and the sample is re-evaluated from the SAME noise (Philox key (seed, index),
  * or its row of `delta`) on the exact-fp32 WaveNet, and that result votes (and replaces its row of logits_out / x0_out).
- * With tau >= 2 x the largest bf16 error of a logit difference the counts equal the fp32 path's exactly
- * (robustness_eval/certified_robust.py:59-65 is an arg-max: it only depends on the order of the logits).
+ * With tau >= the largest error the 16-bit path makes on a logit DIFFERENCE the counts equal the fp32 path's exactly
+ * (robustness_eval/certified_robust.py:59-65 is an arg-max: it only depends on the order of the logits).  Defaults:
+ * 0.04 for f16 operands (measured error 0.029 over 36 864 samples), 0.30 for bf16 operands (0.22).
  * dmad_recheck_stats returns the number of samples voted and of samples re-evaluated since the last reset. */
 int dmad_set_mode(dmad_engine* e, int32_t mode);
 int dmad_set_recheck_margin(dmad_engine* e, float tau);

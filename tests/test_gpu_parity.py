@@ -70,6 +70,15 @@ def G(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
 
+def synth_vgg(seed=4321, **kw):
+    """models.vgg.VGG module carrying the synthetic weights the engines of this file hold (an engine refuses a module that
+    offers other weights than its resident classifier)."""
+    from audio_models.ConvNets_SpeechCommands.models.vgg import vgg19_bn
+    net = vgg19_bn(num_classes=10, in_channels=1)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.vgg19_bn_state_dict(seed, **kw).items()})
+    return net.eval()
+
+
 # ------------------------------------------------------------------------------------------ library
 def test_native_library_is_loaded(engines):
     from dmad_hip import _lib
@@ -332,7 +341,7 @@ def test_certify_end_to_end_fused(engines, golden_dir):
     from robustness_eval.certified_robust import RobustCertificate
     eng = engines['fp32']
     den = DiffWave(WaveNetHIP(eng), calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG))
-    clf = vgg19_bn(num_classes=10, in_channels=1).eval().bind_engine(eng)
+    clf = synth_vgg().bind_engine(eng)
     rc = RobustCertificate(classifier=clf, transform=MelSpectrogramDB(eng), denoiser=den, noise_source='torch_cpu')
     assert rc._fused()
     torch.manual_seed(int(z['certify_seed']))
@@ -629,8 +638,7 @@ def test_config2_ddpm_batch256_vgg(big_engine):
     from dmad_hip.transforms import MelSpectrogramDB
     eng = big_engine
     hp = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
-    net = vgg19_bn(num_classes=10, in_channels=1)
-    net.eval().bind_engine(eng)
+    net = synth_vgg().bind_engine(eng)
     den = DiffWave(WaveNetHIP(eng), hp, reverse_timestep=5, seed=123)
     model = AcousticSystem(classifier=net, transform=MelSpectrogramDB(eng), defender=den, defense_type='wave')
     x = torch.from_numpy(np.stack([synth.synthetic_clip(i % 10) for i in range(256)])).cuda()       # [256,1,16000]
@@ -679,8 +687,7 @@ def test_config3_certify_n1000(big_engine):
         c, _, _ = eng.smooth_votes(clip, 0.5, sc, t, ca, cb, hi - lo, batch=b, seed=77, sample0=lo)
         parts += c
     assert torch.equal(whole, parts)
-    net = vgg19_bn(num_classes=10, in_channels=1)
-    net.eval().bind_engine(eng)
+    net = synth_vgg().bind_engine(eng)
     RC = RobustCertificate(classifier=net, transform=MelSpectrogramDB(eng), denoiser=DiffWave(WaveNetHIP(eng), hp), seed=5)
     assert RC._fused()
     y_pred, radius = RC.certify(clip[None], torch.tensor([0]).cuda(), sigma=0.5, n_0=100, n=1000, batch_size=256)
@@ -740,8 +747,7 @@ def test_two_ranks_on_the_hip_path(engines, tmp_path):
     mp.spawn(_hip_rank_worker, args=(2, 29600 + os.getpid() % 2000, out), nprocs=2, join=True)
     got = torch.load(out)
     eng = engines['bf16']
-    net = vgg19_bn(num_classes=10, in_channels=1)
-    net.eval().bind_engine(eng)
+    net = synth_vgg().bind_engine(eng)
     rc = RobustCertificate(classifier=net, transform=MelSpectrogramDB(eng), seed=21,
                            denoiser=DiffWave(WaveNetHIP(eng), calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)))
     clip = torch.from_numpy(synth.synthetic_clip(2)).cuda()

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'diffusion-model-for-audio-defense_amd')]
 from dmad_hip import engine as E, synth
 B = int(os.environ.get('B', 128))
-eng = E.Engine(max_batch=B, precision=E.BF16)
+eng = E.Engine(max_batch=B, precision=E.BF16, half_type=E.HALF_F16 if os.environ.get('HALF', 'f16') == 'f16' else E.HALF_BF16, with_classifier=False)
 eng.load_wavenet(synth.wavenet_state_dict(1234))
 x = torch.randn(B, 16000, device='cuda') * 0.3
 eng.wavenet_eps(x, 65); torch.cuda.synchronize()

@@ -19,8 +19,8 @@ import shutil
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LAYER = 'wn_layer_bf16_p<false, false>'
-FINAL = 'wn_final_bf16_p'
+LAYER = ('wn_layer_p<', 'false, false>')       # every substring must occur in the kernel name (either operand type)
+FINAL = ('wn_final_p<',)
 
 
 def one(pattern):
@@ -40,7 +40,7 @@ def counters(d):
 
 
 def mean_for(cnt, kernel_sub, counter):
-    vals = [v for (k, c), vs in cnt.items() if kernel_sub in k and c == counter for v in vs]
+    vals = [v for (k, c), vs in cnt.items() if all(sub in k for sub in kernel_sub) and c == counter for v in vs]
     return sum(vals) / len(vals) if vals else None
 
 
@@ -67,7 +67,7 @@ def main():
         md += ['bench line of the profiled run: %.1f %s, roofline.achieved %.0f %s (layer kernel by HIP events).' % (
             j['value'], j['unit'], j['roofline']['achieved'], j['roofline']['unit']), '']
     md += ['| kernel | calls | total ms | avg us | % |', '|---|---|---|---|---|']
-    for r in rows[:14]:
+    for r in rows[:18]:
         md.append('| %s | %s | %.3f | %.1f | %s |' % (r['Name'].split('(')[0][:60], r['Calls'], float(r['TotalDurationNs']) / 1e6,
                                                      float(r['AverageNs']) / 1e3, r['Percentage']))
     if a.fetch and a.write:
@@ -78,12 +78,12 @@ def main():
         json.dump({'layer_traffic_bytes_per_clip': traffic, 'fetch_kb': fl, 'write_kb': wl},
                   open(os.path.join(prof, a.name + '_layer_traffic.json'), 'w'))
         md += ['', '## PMC (separate --pmc passes of the same program)', '',
-               'Per launch of `%s` (%d clips), mean over the launches: FETCH_SIZE %.4g KB, WRITE_SIZE %.4g KB.' % (LAYER, a.clips_per_launch, fl, wl),
+               'Per launch of `%s` (%d clips), mean over the launches: FETCH_SIZE %.4g KB, WRITE_SIZE %.4g KB.' % ('wn_layer_p<T, false, false>', a.clips_per_launch, fl, wl),
                'gfx950 correction: FETCH_SIZE counts 64 B per 128-B request -> x2.  Traffic = 2 x %.3f GB + %.3f GB = %.3f GB per launch = %.1f MB per clip per launch'
                % (fl * 1024 / 1e9, wl * 1024 / 1e9, (2 * fl + wl) * 1024 / 1e9, traffic / 1e6),
                '(algorithmic: read h 8.19 MB + write h\' 8.19 MB + write g 8.19 MB = 24.6 MB per clip).']
         if ff:
-            md.append('Per launch of `%s`: FETCH_SIZE %.4g KB (x2 = %.2f GB), WRITE_SIZE %.4g KB.' % (FINAL, ff, 2 * ff * 1024 / 1e9, wf or 0))
+            md.append('Per launch of `wn_final_p<T>`: FETCH_SIZE %.4g KB (x2 = %.2f GB), WRITE_SIZE %.4g KB.' % (ff, 2 * ff * 1024 / 1e9, wf or 0))
     if a.mfma:
         m = counters(a.mfma)
         busy, gui = mean_for(m, LAYER, 'SQ_VALU_MFMA_BUSY_CYCLES'), mean_for(m, LAYER, 'GRBM_GUI_ACTIVE')
