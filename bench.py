@@ -243,8 +243,8 @@ def main():
             dt = float(tmax.item())
         votes = total.cpu().tolist()
         assert sum(votes) == steps * S * world, 'vote conservation violated: %s' % votes
-        voted, rechecked = eng.recheck_stats()
-        return dt, votes, (rechecked / voted if voted else 0.0), prof
+        voted, rechecked, rechecked32 = eng.recheck_stats(detail=True)
+        return dt, votes, ((rechecked / voted, rechecked32 / voted) if voted else (0.0, 0.0)), prof
 
     # ---- the measured region: exactly --steps steps after --warmup untimed ones, in --mode --------------------------
     dt, votes, recheck_frac, prof = timed(args.mode, args.steps, args.warmup, 0, profile=(args.mode != 'fp32'))
@@ -261,7 +261,7 @@ def main():
             first += k + 1
             side[mode] = {"clips_per_s": k * S * world / sdt, "steps": k, "votes": svotes}
             if mode == 'exact':
-                side[mode]["recheck_frac"] = sfrac
+                side[mode]["recheck_frac"], side[mode]["recheck_frac_fp32"] = sfrac
             if mode == 'fp32':
                 side[mode]["tflops"] = k * S / sdt * CLIP_FLOP / 1e12
                 side[mode]["frac_of_fp32_matrix_peak"] = side[mode]["tflops"] / PEAK_FP32_TFLOPS
@@ -312,7 +312,10 @@ def main():
             "votes": votes,
         }
         if args.mode == 'exact':
-            out["recheck"] = {"margin": eng.recheck_margin, "frac": recheck_frac, "fp32_batch": min(args.recheck_batch, args.max_batch)}
+            out["recheck"] = {"margin": eng.recheck_margin, "frac": recheck_frac[0], "margin_split_f16_tier": eng.recheck_margin2,
+                              "frac_fp32": recheck_frac[1], "batch": min(args.recheck_batch, args.max_batch),
+                              "tiers": "16-bit MFMA -> (margin < %.3g) split-f16 three-MFMA fp32 pipeline -> (margin < %.3g) exact fp32"
+                                       % (eng.recheck_margin, eng.recheck_margin2)}
         if prof is not None:
             (layer_ms, launches), (final_ms, flaunches) = prof
             # launches of a step's last (possibly smaller) chunk and of the recheck passes carry fewer clips; the recheck

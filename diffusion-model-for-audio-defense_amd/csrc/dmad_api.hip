@@ -67,6 +67,37 @@ uint16_t f2h(float f) {    // fp32 -> IEEE half, round-to-nearest-even (subnorma
     return (uint16_t)(sign | (uint32_t)(((e + 15) << 10) + (h - 0x400u)));   // a significand carry bumps the exponent
 }
 
+float h2f(uint16_t h) {    // IEEE half -> fp32 (exact)
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = sign;
+        else {                                                               // subnormal: normalise
+            int sh = 0;
+            uint32_t mm = m;
+            while (!(mm & 0x400u)) { mm <<= 1; ++sh; }
+            u = sign | ((uint32_t)(127 - 15 - sh + 1) << 23) | ((mm & 0x3ffu) << 13);
+        }
+    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// fp32 matrix [rows][K] -> the split-f16 storage format of dmad_common.h (same bytes per row: every 4 consecutive k become
+// the 16-byte chunk [hi0 hi1 hi2 hi3 lo0 lo1 lo2 lo3], lo = f16((x - hi) * 2^11))
+void split_rows(const float* src, size_t count, float* dst) {
+    uint16_t* o = (uint16_t*)dst;
+    for (size_t i = 0; i < count; i += 4)
+        for (int j = 0; j < 4; ++j) {
+            const float x = src[i + j];
+            const uint16_t hi = f2h(x);
+            o[2 * i + j] = hi;
+            o[2 * i + 4 + j] = f2h((x - h2f(hi)) * 2048.f);
+        }
+}
+
 const int kVggCfg[] = {64, 64, -1, 128, 128, -1, 256, 256, 256, 256, -1, 512, 512, 512, 512, -1, 512, 512, 512, 512, -1};
 const int kVggCfgLen = sizeof(kVggCfg) / sizeof(int);
 constexpr int kMelLd = 1040;      // 1025 rFFT bins padded to a multiple of 16
@@ -113,6 +144,10 @@ struct dmad_engine {
     h16_t *hA = nullptr, *hB = nullptr, *gstore = nullptr;
     // fp32 path
     float *wdil = nullptr, *bdil = nullptr, *wrs = nullptr, *brs = nullptr, *wf0 = nullptr;
+    float *wdil_x3 = nullptr, *wrs_x3 = nullptr, *wf0_x3 = nullptr;      // the same weights in the split-f16 storage format (x3 tier)
+    float tau2 = 0.f;                      // recheck bound of the x3 tier (its logit-difference error against the fp32 path)
+    long long* rc_list2 = nullptr;         // samples the x3 tier leaves to the fp32 tier
+    int64_t st_rechecked2 = 0;
     float *hA32 = nullptr, *hB32 = nullptr, *H32 = nullptr, *g32 = nullptr, *skip32 = nullptr;
     // common work buffers
     float *xt = nullptr, *eps = nullptr, *x0 = nullptr, *znoise = nullptr;
@@ -303,6 +338,12 @@ int finalize_wavenet(dmad_engine* e) {
         }
         CHK(e->upload(&e->wdil, wdil)); CHK(e->upload(&e->bdil, bdil)); CHK(e->upload(&e->wrs, wrs)); CHK(e->upload(&e->brs, brs));
         CHK(e->upload(&e->wf0, f0w));
+        if (e->bf16) {                      // exact-vote engines: the middle (split-f16, three-MFMA) tier reads these
+            std::vector<float> t(wdil.size());
+            split_rows(wdil.data(), wdil.size(), t.data()); CHK(e->upload(&e->wdil_x3, t));
+            t.resize(wrs.size()); split_rows(wrs.data(), wrs.size(), t.data()); CHK(e->upload(&e->wrs_x3, t));
+            t.resize(f0w.size()); split_rows(f0w.data(), f0w.size(), t.data()); CHK(e->upload(&e->wf0_x3, t));
+        }
     }
     return 0;
 }
@@ -606,8 +647,8 @@ int unet_prepare_step(dmad_engine* e, int t, hipStream_t s) {
         te[i] = cosf(arg);
         te[kUnMC / 2 + i] = sinf(arg);
     }
-    HIPCHK(hipMemcpyAsync(e->un_temb, te, sizeof te, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));        // `te` lives on this stack frame
+    static_assert(kUnMC == 128, "launch_store_vec128 carries 128 floats");
+    launch_store_vec128(te, e->un_temb, s); // as a kernel argument: no host buffer to keep alive, no synchronisation
     launch_gemm_f32(plain_gemm(e->un_te0w, e->un_temb, e->un_emb1, nullptr, e->un_te0b, kUnTE, kUnMC, 1, kUnTE, kUnMC, 0), s);
     launch_silu(e->un_emb1, e->un_emb1, kUnTE, s);
     launch_gemm_f32(plain_gemm(e->un_te2w, e->un_emb1, e->un_emb, nullptr, e->un_te2b, kUnTE, kUnTE, 1, kUnTE, kUnTE, 0), s);
@@ -717,17 +758,19 @@ GemmF32Args plain_gemm(const float* A, const float* X, float* C, const float* sc
 
 // exact32: evaluate on the exact-fp32 path (the only one of a DMAD_FP32 engine; DMAD_MODE_FP32 and the recheck pass of a
 // DMAD_EXACT engine); batches larger than the fp32 workspace are walked in chunks of maxB32 clips
-int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipStream_t s, bool exact32 = false) {
+enum { PATH_DEFAULT = 0, PATH_FP32 = 1, PATH_X3 = 2 };
+int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipStream_t s, int path = PATH_DEFAULT) {
     if (!e->wn_final) return fail(DMAD_ERR_STATE, "WaveNet weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
     if (B < 1 || B > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d]", B, e->maxB);
     if (t < 0) return fail(DMAD_ERR_INVALID, "diffusion step %d < 0", t);
     CHK(ensure_embed(e, t, s));
     const int L = e->L, LP = e->LP, NL = e->NL;
-    const bool use32 = !e->bf16 || (e->f32 && (exact32 || e->mode == DMAD_MODE_FP32));
+    const bool use32 = !e->bf16 || (e->f32 && (path != PATH_DEFAULT || e->mode == DMAD_MODE_FP32));
+    const bool x3 = use32 && path == PATH_X3 && e->wdil_x3;     // fp32 pipeline on split-f16 operands (three MFMAs per product)
     if (use32 && B > e->maxB32) {
         for (int b0 = 0; b0 < B; b0 += e->maxB32) {
             const int bb = B - b0 < e->maxB32 ? B - b0 : e->maxB32;
-            CHK(wavenet_eps(e, x_t + (size_t)b0 * L, t, bb, eps + (size_t)b0 * L, s, true));
+            CHK(wavenet_eps(e, x_t + (size_t)b0 * L, t, bb, eps + (size_t)b0 * L, s, x3 ? PATH_X3 : PATH_FP32));
         }
         return 0;
     }
@@ -758,27 +801,31 @@ int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipS
         if (timed_f) (void)hipEventRecord(e->prof_ev_f[e->prof_used_f++], s);
     } else {
         const long N = (long)B * L;
-        launch_wn_init_f32(x_t, e->init_w, e->init_b, e->emb_table, e->hA32, B, L, LP, s);
+        launch_wn_init_f32(x_t, e->init_w, e->init_b, e->emb_table, e->hA32, B, L, LP, s, x3);
         for (int n = 0; n < NL; ++n) {
             float* hin = (n & 1) ? e->hB32 : e->hA32;
             float* hout = (n & 1) ? e->hA32 : e->hB32;
             const int d = 1 << (n % e->cfg.dilation_cycle);
             GemmF32Args g{};
-            g.A = e->wdil + (size_t)n * 3 * 512 * 256; g.X = hin + (size_t)kPad * kC; g.C = e->H32; g.scale = nullptr;
+            g.A = (x3 ? e->wdil_x3 : e->wdil) + (size_t)n * 3 * 512 * 256; g.X = hin + (size_t)kPad * kC; g.C = e->H32; g.scale = nullptr;
+            g.x3 = x3;
             g.shift = e->bdil + (size_t)n * 512; g.M = 512; g.K = 256; g.taps = 3; g.ldc = 512; g.relu = 0; g.N = N; g.mode = 0;
             g.rows_per_batch = L; g.batch_stride = (long)LP * kC; g.row_stride = kC; g.tap_stride = (long)d * kC;
             g.epi = 1; g.C = e->g32;             // tanh * sigmoid in the epilogue: H never goes to HBM
             launch_gemm_f32(g, s);
             // res || skip convs with the residual update and the skip accumulation in the epilogue (2 launches per layer)
             const bool last = n == NL - 1;
-            GemmF32Args u = plain_gemm(e->wrs + (size_t)n * 512 * 256 + (last ? 256 * 256 : 0), e->g32, nullptr, nullptr,
+            GemmF32Args u = plain_gemm((x3 ? e->wrs_x3 : e->wrs) + (size_t)n * 512 * 256 + (last ? 256 * 256 : 0), e->g32, nullptr, nullptr,
                                        e->brs + (size_t)n * 512 + (last ? 256 : 0), last ? 256 : 512, 256, N, 256, 256, 0);
             u.epi = 2; u.res_rows = last ? 0 : 256; u.first = n == 0; u.L = L; u.LP = LP;
             u.hin = hin; u.hout = hout; u.skip = e->skip32; u.emb_next = e->emb_table + (size_t)((n + 1 < NL) ? n + 1 : n) * 256;
+            u.x3 = x3;
             launch_gemm_f32(u, s);
         }
-        launch_scale(e->skip32, (float)sqrt(1.0 / NL), e->g32, N * 256, s);
-        launch_gemm_f32(plain_gemm(e->wf0, e->g32, e->H32, nullptr, e->bf0, 256, 256, N, 256, 256, 1), s);
+        launch_scale(e->skip32, (float)sqrt(1.0 / NL), e->g32, N * 256, s, x3);
+        GemmF32Args f = plain_gemm(x3 ? e->wf0_x3 : e->wf0, e->g32, e->H32, nullptr, e->bf0, 256, 256, N, 256, 256, 1);
+        f.x3 = x3;
+        launch_gemm_f32(f, s);
         launch_dot256(e->H32, e->wz, e->bz, eps, N, s);
     }
     HIPCHK(hipGetLastError());
@@ -873,6 +920,7 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     if (e->maxB32 > cfg->max_batch) e->maxB32 = cfg->max_batch;
     e->mode = cfg->precision == DMAD_EXACT ? DMAD_MODE_EXACT_VOTES : (cfg->precision == DMAD_FP32 ? DMAD_MODE_FP32 : DMAD_MODE_FAST);
     e->tau = cfg->half_type == DMAD_HALF_F16 ? 0.04f : 0.30f;   // measured logit-difference error of the 16-bit path x 1.4 (see dmad.h)
+    e->tau2 = 2e-3f;                        // the same for the split-f16 tier (dmad_set_recheck_margin2)
     if (e->bf16 && !wn_final_p_supported(cfg->num_res_layers)) {
         delete e;
         return fail(DMAD_ERR_INVALID, "bf16 path does not support num_res_layers = %d", cfg->num_res_layers);
@@ -900,6 +948,7 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
         if (e->bf16 && e->f32) {             // recheck queue of the exact-vote mode
             e->rc_cap = 1l << 20;
             if ((r = e->alloc(&e->rc_list, (size_t)e->rc_cap))) break;
+            if ((r = e->alloc(&e->rc_list2, (size_t)e->rc_cap))) break;
             if ((r = e->alloc(&e->rc_n, 1, true))) break;
             hipError_t he = hipHostMalloc((void**)&e->rc_n_host, sizeof(unsigned long long), hipHostMallocDefault);
             if (he != hipSuccess) { r = fail(DMAD_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(he)); break; }
@@ -1147,12 +1196,27 @@ int dmad_set_recheck_margin(dmad_engine* e, float tau) {
     return 0;
 }
 
-int dmad_recheck_stats(dmad_engine* e, int64_t* samples, int64_t* rechecked, int32_t reset) {
+int dmad_set_recheck_margin2(dmad_engine* e, float tau2) {
+    if (!e) return fail(DMAD_ERR_INVALID, "null engine");
+    if (tau2 != tau2) return fail(DMAD_ERR_INVALID, "recheck margin is NaN");
+    e->tau2 = tau2;                          // < 0: no middle tier, the queued samples go straight to the fp32 path
+    return 0;
+}
+
+int dmad_recheck_stats(dmad_engine* e, int64_t* samples, int64_t* rechecked, int64_t* rechecked_fp32, int32_t reset) {
     if (!e) return fail(DMAD_ERR_INVALID, "null engine");
     if (samples) *samples = e->st_samples;
     if (rechecked) *rechecked = e->st_rechecked;
-    if (reset) e->st_samples = e->st_rechecked = 0;
+    if (rechecked_fp32) *rechecked_fp32 = e->st_rechecked2;
+    if (reset) e->st_samples = e->st_rechecked = e->st_rechecked2 = 0;
     return 0;
+}
+
+int dmad_wavenet_eps_path(dmad_engine* e, const float* x_t, int32_t t, int32_t B, int32_t path, float* eps, dmad_stream s) {
+    if (!e || !x_t || !eps) return fail(DMAD_ERR_INVALID, "null argument");
+    if (path != PATH_DEFAULT && path != PATH_FP32 && path != PATH_X3) return fail(DMAD_ERR_INVALID, "unknown path %d", path);
+    if (path != PATH_DEFAULT && !(e->bf16 && e->f32)) return fail(DMAD_ERR_STATE, "explicit WaveNet paths need a DMAD_EXACT engine");
+    return wavenet_eps(e, x_t, t, B, eps, (hipStream_t)s, path);
 }
 
 }  // extern "C"
@@ -1165,27 +1229,59 @@ struct RecheckJob {
     const float* clip; const float* delta; float sigma, scale; int t; float c_a, c_b; uint64_t seed, sample0;
     int64_t* counts; float* logits_out; float* x0_out;
 };
-int run_recheck(dmad_engine* e, const RecheckJob& j, hipStream_t st) {
-    HIPCHK(hipMemcpyAsync(e->rc_n_host, e->rc_n, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const long n = (long)*e->rc_n_host;
-    if (n > e->rc_cap) return fail(DMAD_ERR_STATE, "recheck queue overflow (%ld > %ld)", n, e->rc_cap);
+// one tier of the recheck: rows idx[0..n) re-evaluated on `path`; tau >= 0: rows whose margin is still below tau are queued in
+// `next` (they do not vote), tau < 0: every row votes
+int recheck_pass(dmad_engine* e, const RecheckJob& j, const long long* list, long n, int path, float tau, long long* next, hipStream_t st) {
     const int L = e->L, C = e->cfg.num_classes;
     for (long done = 0; done < n; done += e->maxB32) {
         const int B = (int)(n - done < e->maxB32 ? n - done : e->maxB32);
-        const long long* idx = e->rc_list + done;
+        const long long* idx = list + done;
         launch_mc_noise_scale_idx(j.clip, j.delta, j.sigma, j.scale, j.seed, j.sample0, idx, e->xt, B, L, st);
-        CHK(wavenet_eps(e, e->xt, j.t, B, e->eps, st, true));
+        CHK(wavenet_eps(e, e->xt, j.t, B, e->eps, st, path));
         launch_lincomb(0, e->xt, e->eps, nullptr, j.c_a, j.c_b, 0.f, e->x0, (long)B * L, st);
         if (j.x0_out) launch_scatter_rows(e->x0, idx, (long long)j.sample0, j.x0_out, B, L, st);
         CHK(mel_db(e, e->x0, B, e->spec, st));
         CHK(classify(e, e->spec, B, e->logits, st));
         if (j.logits_out) launch_scatter_rows(e->logits, idx, (long long)j.sample0, j.logits_out, B, C, st);
-        launch_vote(e->logits, B, C, (unsigned long long*)j.counts, nullptr, st);
+        if (tau >= 0.f) launch_vote_margin(e->logits, B, C, (unsigned long long*)j.counts, tau, 0, idx, next, e->rc_n, nullptr, st);
+        else launch_vote(e->logits, B, C, (unsigned long long*)j.counts, nullptr, st);
     }
-    HIPCHK(hipMemsetAsync(e->rc_n, 0, sizeof(unsigned long long), st));
-    e->st_rechecked += n;
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+long read_queue_length(dmad_engine* e, hipStream_t st, int* rc) {
+    *rc = 0;
+    if (hipMemcpyAsync(e->rc_n_host, e->rc_n, sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemsetAsync(e->rc_n, 0, sizeof(unsigned long long), st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        *rc = fail(DMAD_ERR_HIP, "reading the recheck queue length failed");
+        return 0;
+    }
+    const long n = (long)*e->rc_n_host;
+    if (n > e->rc_cap) *rc = fail(DMAD_ERR_STATE, "recheck queue overflow (%ld > %ld)", n, e->rc_cap);
+    return n;
+}
+
+// The samples the 16-bit pass queued: tier 2 = the fp32 pipeline on split-f16 operands (three MFMAs per product, ~fp32
+// accuracy at several times the fp32 matrix rate) settles every sample whose margin exceeds ITS error bound tau2; what is
+// left (margins inside tau2) goes to tier 3, the exact-fp32 path.  Two stream synchronisations (the queue lengths decide
+// the launches).
+int run_recheck(dmad_engine* e, const RecheckJob& j, hipStream_t st) {
+    int rc = 0;
+    const long n1 = read_queue_length(e, st, &rc);
+    if (rc) return rc;
+    e->st_rechecked += n1;
+    if (n1 == 0) return 0;
+    if (e->tau2 >= 0.f && e->wdil_x3) {
+        CHK(recheck_pass(e, j, e->rc_list, n1, PATH_X3, e->tau2, e->rc_list2, st));
+        const long n2 = read_queue_length(e, st, &rc);
+        if (rc) return rc;
+        e->st_rechecked2 += n2;
+        if (n2) CHK(recheck_pass(e, j, e->rc_list2, n2, PATH_FP32, -1.f, nullptr, st));
+    } else {
+        e->st_rechecked2 += n1;
+        CHK(recheck_pass(e, j, e->rc_list, n1, PATH_FP32, -1.f, nullptr, st));
+    }
     return 0;
 }
 
@@ -1215,8 +1311,8 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
             float* lg = logits_out ? logits_out + done * C : e->logits;
             CHK(classify(e, e->spec, B, lg, st));
             if (recheck) {
-                launch_vote_margin(lg, B, C, (unsigned long long*)counts, e->tau, (long long)(sample0 + (uint64_t)done), e->rc_list, e->rc_n,
-                                   nullptr, st);
+                launch_vote_margin(lg, B, C, (unsigned long long*)counts, e->tau, (long long)(sample0 + (uint64_t)done), nullptr, e->rc_list,
+                                   e->rc_n, nullptr, st);
                 // the queue holds at most rc_cap indices: drain it before the samples voted since the last drain could overflow it
                 if (done + B - queued_from + batch > e->rc_cap && done + B < n) {
                     CHK(run_recheck(e, RecheckJob{clip, delta, sigma, sqrt_alpha_bar_star, t, c_a, c_b, seed, sample0, counts, logits_out, x0_out}, st));

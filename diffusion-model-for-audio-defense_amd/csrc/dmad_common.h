@@ -51,6 +51,32 @@ template <> struct H16<_Float16> {
     static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 
+// "Split-f16" storage of fp32 GEMM operands (the middle tier of the exact-vote mode): a value x is kept as the pair
+//   hi = f16(x),  lo = f16((x - hi) * 2^11)      (x ~= hi + lo * 2^-11 to 22 significant bits; the 2^11 keeps lo a normal f16),
+// four values per 16-byte chunk as [hi0 hi1 | hi2 hi3 | lo0 lo1 | lo2 lo3] — the size and the chunk position of four floats,
+// so buffers, row gathers and LDS images are those of the fp32 path.  A product is then three f16 MFMAs with fp32
+// accumulation:  x*y ~= hi_x*hi_y + (hi_x*lo_y + lo_x*hi_y) * 2^-11  (the dropped lo*lo term is 2^-22 relative).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+constexpr float kSplitScale = 2048.f, kSplitInv = 1.f / 2048.f;
+__host__ __device__ inline void split1(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)((x - (float)hi) * kSplitScale);
+}
+__device__ inline u32x4_t split4(float x0, float x1, float x2, float x3) {
+    _Float16 h[4], l[4];
+    split1(x0, h[0], l[0]); split1(x1, h[1], l[1]); split1(x2, h[2], l[2]); split1(x3, h[3], l[3]);
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+    return u32x4_t{__builtin_bit_cast(unsigned, f16x2_t{h[0], h[1]}), __builtin_bit_cast(unsigned, f16x2_t{h[2], h[3]}),
+                   __builtin_bit_cast(unsigned, f16x2_t{l[0], l[1]}), __builtin_bit_cast(unsigned, f16x2_t{l[2], l[3]})};
+}
+__device__ inline void join4(u32x4_t c, float out[4]) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+    const f16x2_t h01 = __builtin_bit_cast(f16x2_t, c[0]), h23 = __builtin_bit_cast(f16x2_t, c[1]);
+    const f16x2_t l01 = __builtin_bit_cast(f16x2_t, c[2]), l23 = __builtin_bit_cast(f16x2_t, c[3]);
+    out[0] = (float)h01[0] + (float)l01[0] * kSplitInv; out[1] = (float)h01[1] + (float)l01[1] * kSplitInv;
+    out[2] = (float)h23[0] + (float)l23[0] * kSplitInv; out[3] = (float)h23[1] + (float)l23[1] * kSplitInv;
+}
+
 __device__ inline float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ inline float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

@@ -197,6 +197,7 @@ __global__ void lincomb_kernel(int op, const float* __restrict__ x, const float*
 // ----------------------------------------------------------------------------------------------
 // fp32 (parity) WaveNet helpers
 // ----------------------------------------------------------------------------------------------
+template <bool SPLIT>      // SPLIT: write the split-f16 storage format (dmad_common.h) for the x3 GEMM tier
 __global__ void wn_init_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                    const float* __restrict__ emb0, float* __restrict__ h, int L, int LP, long total) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 (4 channels) each
@@ -211,7 +212,8 @@ __global__ void wn_init_f32_kernel(const float* __restrict__ x, const float* __r
         const int c = c4 * 4 + j;
         po[j] = __fadd_rn(fmaxf(__fadd_rn(__fmul_rn(w[c], xv), bias[c]), 0.f), emb0[c]);
     }
-    *(float4*)(h + ((bb * LP + kPad + t) * kC + c4 * 4)) = o;
+    if (SPLIT) *(u32x4_t*)(h + ((bb * LP + kPad + t) * kC + c4 * 4)) = split4(o.x, o.y, o.z, o.w);
+    else *(float4*)(h + ((bb * LP + kPad + t) * kC + c4 * 4)) = o;
 }
 
 // g = tanh(H[:, :256]) * sigmoid(H[:, 256:])   (WaveNet.py:89), H is [N][512]
@@ -257,12 +259,14 @@ __global__ void wn_update_f32_kernel(const float* __restrict__ RS, const float* 
     *(float4*)(hout + hoff) = o;
 }
 
+template <bool SPLIT>
 __global__ void scale_kernel(const float* __restrict__ x, float c, float* __restrict__ y, long n4) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     float4 v = ((const float4*)x)[i];
     v.x = __fmul_rn(v.x, c); v.y = __fmul_rn(v.y, c); v.z = __fmul_rn(v.z, c); v.w = __fmul_rn(v.w, c);
-    ((float4*)y)[i] = v;
+    if (SPLIT) ((u32x4_t*)y)[i] = split4(v.x, v.y, v.z, v.w);
+    else ((float4*)y)[i] = v;
 }
 
 // eps[n] = w . f[n][:256] + b  (final_conv.2, WaveNet.py:160-162): one wave per position
@@ -391,7 +395,7 @@ __global__ void vote_kernel(const float* __restrict__ logits, int B, int C, unsi
 // Exact-vote mode: a sample votes from these (bf16-path) logits only if its top-2 margin is >= tau; otherwise its global
 // index sample_base + b is queued for the exact-fp32 re-evaluation (any NaN fails the comparison and is queued too).
 __global__ void vote_margin_kernel(const float* __restrict__ logits, int B, int C, unsigned long long* __restrict__ counts,
-                                   float tau, long long sample_base, long long* __restrict__ list,
+                                   float tau, long long sample_base, const long long* __restrict__ idx, long long* __restrict__ list,
                                    unsigned long long* __restrict__ list_n, int* __restrict__ pred_out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -409,7 +413,7 @@ __global__ void vote_margin_kernel(const float* __restrict__ logits, int B, int 
         atomicAdd(&counts[best], 1ull);
     } else {
         const unsigned long long slot = atomicAdd(list_n, 1ull);
-        list[slot] = sample_base + b;
+        list[slot] = idx ? idx[b] : sample_base + b;     // row b is global sample idx[b] (a recheck pass) or sample_base + b
     }
 }
 
@@ -440,8 +444,8 @@ void launch_repeat_rows(const float* x, float* out, int B, long row0, int nrows,
     hipLaunchKernelGGL(repeat_rows_kernel, dim3(nblk(total4, 256)), dim3(256), 0, s, x, out, B, row0, L, total4);
 }
 void launch_vote_margin(const float* logits, int B, int C, unsigned long long* counts, float tau, long long sample_base,
-                        long long* list, unsigned long long* list_n, int* pred_out, hipStream_t s) {
-    hipLaunchKernelGGL(vote_margin_kernel, dim3(nblk(B, 64)), dim3(64), 0, s, logits, B, C, counts, tau, sample_base, list, list_n,
+                        const long long* idx, long long* list, unsigned long long* list_n, int* pred_out, hipStream_t s) {
+    hipLaunchKernelGGL(vote_margin_kernel, dim3(nblk(B, 64)), dim3(64), 0, s, logits, B, C, counts, tau, sample_base, idx, list, list_n,
                        pred_out);
 }
 void launch_embed_table(float t, const float* w1, const float* b1, const float* w2, const float* b2, const float* wt,
@@ -453,9 +457,10 @@ void launch_lincomb(int op, const float* x, const float* y, const float* z, floa
     hipLaunchKernelGGL(lincomb_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, op, x, y, z, c0, c1, c2, out, n);
 }
 void launch_wn_init_f32(const float* x, const float* w, const float* bias, const float* emb0, float* h, int B, int L, int LP,
-                        hipStream_t s) {
+                        hipStream_t s, bool split) {
     const long total = (long)B * L * 64;
-    hipLaunchKernelGGL(wn_init_f32_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, x, w, bias, emb0, h, L, LP, total);
+    if (split) hipLaunchKernelGGL(wn_init_f32_kernel<true>, dim3(nblk(total, 256)), dim3(256), 0, s, x, w, bias, emb0, h, L, LP, total);
+    else hipLaunchKernelGGL(wn_init_f32_kernel<false>, dim3(nblk(total, 256)), dim3(256), 0, s, x, w, bias, emb0, h, L, LP, total);
 }
 void launch_wn_gate_f32(const float* H, float* g, long N, hipStream_t s) {
     hipLaunchKernelGGL(wn_gate_f32_kernel, dim3(nblk(N * 64, 256)), dim3(256), 0, s, H, g, N * 64);
@@ -466,8 +471,9 @@ void launch_wn_update_f32(const float* RS, const float* hin, float* hout, float*
     hipLaunchKernelGGL(wn_update_f32_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, RS, hin, hout, skip, emb_next, first, last,
                        L, LP, total);
 }
-void launch_scale(const float* x, float c, float* y, long n, hipStream_t s) {
-    hipLaunchKernelGGL(scale_kernel, dim3(nblk(n / 4, 256)), dim3(256), 0, s, x, c, y, n / 4);
+void launch_scale(const float* x, float c, float* y, long n, hipStream_t s, bool split) {
+    if (split) hipLaunchKernelGGL(scale_kernel<true>, dim3(nblk(n / 4, 256)), dim3(256), 0, s, x, c, y, n / 4);
+    else hipLaunchKernelGGL(scale_kernel<false>, dim3(nblk(n / 4, 256)), dim3(256), 0, s, x, c, y, n / 4);
 }
 void launch_dot256(const float* f, const float* w, float bias, float* out, long N, hipStream_t s) {
     hipLaunchKernelGGL(dot256_kernel, dim3(nblk(N, 4)), dim3(256), 0, s, f, w, bias, out, N);
@@ -506,6 +512,16 @@ void launch_avgpool_nhwc(const float* in, float* out, int B, int HW, int C, hipS
 }
 void launch_vote(const float* logits, int B, int C, unsigned long long* counts, int* pred_out, hipStream_t s) {
     hipLaunchKernelGGL(vote_kernel, dim3(nblk(B, 64)), dim3(64), 0, s, logits, B, C, counts, pred_out);
+}
+
+// out[0:128] = v: a small host-computed vector travels as a kernel argument (copied at launch: no host buffer to keep alive,
+// no stream synchronisation)
+struct Vec128 { float v[128]; };
+__global__ void store_vec128_kernel(Vec128 a, float* __restrict__ out) { out[threadIdx.x] = a.v[threadIdx.x]; }
+void launch_store_vec128(const float* host128, float* out, hipStream_t s) {
+    Vec128 a;
+    for (int i = 0; i < 128; ++i) a.v[i] = host128[i];
+    hipLaunchKernelGGL(store_vec128_kernel, dim3(1), dim3(128), 0, s, a, out);
 }
 
 void philox4x32_10_host(uint32_t c[4], uint32_t k0, uint32_t k1) { philox4x32_10(c, k0, k1); }

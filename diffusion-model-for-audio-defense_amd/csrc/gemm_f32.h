@@ -34,6 +34,10 @@ struct GemmF32Args {
     float* hout;
     float* skip;
     const float* emb_next;
+    // x3 != 0 (mode 0, M a multiple of 128, an even number of k-steps, no split-K): both operands are in the split-f16
+    // storage format (dmad_common.h) and every product is three v_mfma_f32_16x16x32_f16; outputs that feed another GEMM
+    // (epi 1: the gate, epi 2: hout) are written in that format, everything else (plain C, the skip sum) stays fp32.
+    int x3;
     int splits;           // > 1: split-K over grid.z; partial sums go to `slab` [splits][N][ldc] (fixed-order reduce)
     float* slab;
 };

@@ -17,6 +17,8 @@
 // MFMA j in BOTH operands, so each MFMA still contracts 4 distinct k and the 4 together cover the 16.  Rows outside the
 // problem (conv zero padding, M / N tails) are fetched from a zero page.  3-slot LDS ring, counted vmcnt, one barrier
 // per k-step, no register staging.
+#include <stdlib.h>
+
 #include "gemm_f32.h"
 
 namespace dmad {
@@ -249,6 +251,165 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Split-f16 variant (GemmF32Args::x3): the same 128 x 128 tile, staging and fragment addresses, but both operands are in the
+// split-f16 storage format (dmad_common.h: a 16-byte chunk = 4 values as [hi0 hi1 | hi2 hi3 | lo0 lo1 | lo2 lo3]) and the
+// contraction runs on v_mfma_f32_16x16x32_f16: k-steps are consumed in PAIRS — lane (row, q) reads its chunk q of both
+// stages, which gives 8 hi and 8 lo halves = one K = 32 fragment of each part (the k-slot assignment is the same for both
+// operands, so the contraction is unchanged) — and every product is three MFMAs:
+//     main += hi_a * hi_b ;  corr += hi_a * lo_b + lo_a * hi_b ;  result = main + corr * 2^-11.
+// No conversion work in the loop: producers write the format once (epilogues below, wn_init / scale kernels).
+// 4-slot ring (2 pairs), one barrier per pair, pair p+1 in flight while pair p is contracted; 2 workgroups per CU.
+// ----------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmF32Args a) {
+    constexpr int BM = 128, MT = 4;
+    __shared__ __attribute__((aligned(16))) char smem[4 * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1, q = lane >> 4, r16 = lane & 15;
+    const long n0 = (long)blockIdx.x * BN;
+    const int m0 = blockIdx.y * BM;
+    const int ksteps_per_tap = a.K / BK, npairs = (a.taps * ksteps_per_tap) >> 1;
+    const int rloc = wv * 16 + (lane >> 2), chunk4 = ((lane & 3) ^ swz64(lane >> 2)) * 4;
+    const float* zero = g_zero_page;
+    const float* arow[2];
+    long xbase[2];
+    bool xok[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int m = m0 + p * 64 + rloc;
+        arow[p] = m < a.M ? a.A + (size_t)m * a.K + chunk4 : nullptr;
+        const long n = n0 + p * 64 + rloc;
+        xok[p] = n < a.N;
+        const long b = xok[p] ? n / a.rows_per_batch : 0, r = xok[p] ? n - b * a.rows_per_batch : 0;
+        xbase[p] = b * a.batch_stride + r * a.row_stride;
+    }
+    auto stage = [&](int ks, int slot) {
+        const int tap = ks / ksteps_per_tap, kc = (ks - tap * ksteps_per_tap) * BK;
+        char* la = smem + slot * SLOT + wv * 1024;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) glds16(arow[p] ? arow[p] + (size_t)tap * a.M * a.K + kc : zero, la + p * 4096);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            glds16(xok[p] ? a.X + xbase[p] + (long)(tap - (a.taps >> 1)) * a.tap_stride + kc + chunk4 : zero, la + 8192 + p * 4096);
+    };
+    f32x4 acc[MT][4], cor[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; cor[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int frag = r16 * 64 + ((q ^ swz64(r16)) * 16);
+    stage(0, 0);
+    stage(1, 1);
+    for (int p = 0; p < npairs; ++p) {
+        const int s0 = (p & 1) * 2;
+        GF_WAIT_BARRIER(0);                    // pair p landed; every wave is done reading pair p-1
+        if (p + 1 < npairs) { stage(2 * p + 2, s0 ^ 2); stage(2 * p + 3, (s0 ^ 2) + 1); }
+        const char* A0 = smem + s0 * SLOT + wm * (BM * 32) + frag;
+        const char* B0 = smem + s0 * SLOT + 8192 + wn * 4096 + frag;
+        f16x8 ahi[MT], alo[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const u32x4_t c0 = *(const u32x4_t*)(A0 + i * 1024), c1 = *(const u32x4_t*)(A0 + SLOT + i * 1024);
+            ahi[i] = __builtin_bit_cast(f16x8, u32x4_t{c0[0], c0[1], c1[0], c1[1]});
+            alo[i] = __builtin_bit_cast(f16x8, u32x4_t{c0[2], c0[3], c1[2], c1[3]});
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4_t c0 = *(const u32x4_t*)(B0 + j * 1024), c1 = *(const u32x4_t*)(B0 + SLOT + j * 1024);
+            const f16x8 bhi = __builtin_bit_cast(f16x8, u32x4_t{c0[0], c0[1], c1[0], c1[1]});
+            const f16x8 blo = __builtin_bit_cast(f16x8, u32x4_t{c0[2], c0[3], c1[2], c1[3]});
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], bhi, acc[i][j], 0, 0, 0);
+                cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], blo, cor[i][j], 0, 0, 0);
+                cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[i], bhi, cor[i][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(cor[i][j][r], kSplitInv, acc[i][j][r]);
+
+    if (a.epi == 1) {                        // gate -> split-f16 g (operand of the res / skip GEMM)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mrow = m0 + wm * 64 + i * 16 + q * 4;
+            const int ch = blockIdx.y * 64 + wm * 32 + i * 16 + q * 4;
+            const float4 bt = *(const float4*)(a.shift + mrow), bs = *(const float4*)(a.shift + mrow + 32);
+            const float bta[4] = {bt.x, bt.y, bt.z, bt.w}, bsa[4] = {bs.x, bs.y, bs.z, bs.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long n = n0 + wn * 64 + j * 16 + r16;
+                if (n >= a.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ht = acc[i][j][r] + bta[r], hs = acc[i + 2][j][r] + bsa[r];
+                    v[r] = tanhf(ht) * (1.f / (1.f + expf(-hs)));
+                }
+                *(u32x4_t*)(a.C + n * 256 + ch) = split4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        return;
+    }
+    if (a.epi == 2) {                        // h' (split-f16, operand of the next layer) ; skip sum (fp32)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + q * 4;
+            const float4 b4 = *(const float4*)(a.shift + m);
+            const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+            const bool is_res = m < a.res_rows;
+            float ea[4] = {0.f, 0.f, 0.f, 0.f};
+            if (is_res) { const float4 e4 = *(const float4*)(a.emb_next + m); ea[0] = e4.x; ea[1] = e4.y; ea[2] = e4.z; ea[3] = e4.w; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long n = n0 + wn * 64 + j * 16 + r16;
+                if (n >= a.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + ba[r];
+                if (is_res) {
+                    const long bb = n / a.L, t = n - bb * a.L;
+                    const long hoff = (bb * a.LP + kPad + t) * kC + m;
+                    float h[4];
+                    join4(*(const u32x4_t*)(a.hin + hoff), h);
+                    const float k = 0.70710678118654752440f;
+                    *(u32x4_t*)(a.hout + hoff) = split4(__fadd_rn(__fmul_rn(__fadd_rn(h[0], v[0]), k), ea[0]), __fadd_rn(__fmul_rn(__fadd_rn(h[1], v[1]), k), ea[1]),
+                                                         __fadd_rn(__fmul_rn(__fadd_rn(h[2], v[2]), k), ea[2]), __fadd_rn(__fmul_rn(__fadd_rn(h[3], v[3]), k), ea[3]));
+                } else {
+                    float4* ps = (float4*)(a.skip + n * 256 + (m - a.res_rows));
+                    if (a.first) {
+                        *ps = float4{v[0], v[1], v[2], v[3]};
+                    } else {
+                        const float4 o = *ps;
+                        *ps = float4{__fadd_rn(o.x, v[0]), __fadd_rn(o.y, v[1]), __fadd_rn(o.z, v[2]), __fadd_rn(o.w, v[3])};
+                    }
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {           // plain: fp32 out, bias, optional ReLU (final_conv.0)
+        const int m = m0 + wm * 64 + i * 16 + q * 4;
+        const float4 b4 = a.shift ? *(const float4*)(a.shift + m) : float4{0.f, 0.f, 0.f, 0.f};
+        const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long n = n0 + wn * 64 + j * 16 + r16;
+            if (n >= a.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float t = acc[i][j][r] + ba[r]; v[r] = a.relu ? fmaxf(t, 0.f) : t; }
+            *(float4*)(a.C + n * a.ldc + m) = float4{v[0], v[1], v[2], v[3]};
+        }
+    }
+}
+
 // C[n][m] = act(scale[m] * sum_z slab[z][n][m] + shift[m]), splits summed in index order (deterministic)
 __global__ void gemm_f32_reduce_kernel(GemmF32Args a) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -264,6 +425,13 @@ __global__ void gemm_f32_reduce_kernel(GemmF32Args a) {
 
 void launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab_floats, long n_ref) {
     GemmF32Args a = a0;
+    if (a.x3) {                                   // split-f16 operands: WaveNet shapes only (checked here, not in the kernel)
+        const int nks = a.taps * (a.K / BK);
+        if (a.mode != 0 || (a.M & 127) || (nks & 1) || a.scale || a.res || a.groups > 1 || (a.ldc & 3)) abort();
+        a.splits = 1; a.slab = nullptr;
+        hipLaunchKernelGGL(gemm_x3_kernel, dim3((unsigned)((a.N + BN - 1) / BN), (unsigned)(a.M / 128)), dim3(256), 0, s, a);
+        return;
+    }
     const int BM = a.M <= 64 ? 64 : 128;          // 64-row tiles where a 128-row tile would be half empty
     const unsigned gx = (unsigned)((a.N + BN - 1) / BN), gy = (unsigned)((a.M + BM - 1) / BM);
     const int nks = a.taps * (a.K / BK);

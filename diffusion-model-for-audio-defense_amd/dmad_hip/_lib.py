@@ -45,7 +45,9 @@ _SIGNATURES = {
                                     C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P]),
     'dmad_set_mode': (C.c_int, [_P, C.c_int32]),
     'dmad_set_recheck_margin': (C.c_int, [_P, C.c_float]),
-    'dmad_recheck_stats': (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
+    'dmad_set_recheck_margin2': (C.c_int, [_P, C.c_float]),
+    'dmad_recheck_stats': (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
+    'dmad_wavenet_eps_path': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     'dmad_query_logits': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P,
                                     C.c_uint64, C.c_uint64, _P, _P, _P]),
     'dmad_vote': (C.c_int, [_P, _P, C.c_int32, _P, _P]),

@@ -24,6 +24,9 @@ HALF_BF16, HALF_F16 = 0, 1                        # enum dmad_half_type: operand
 # tools/gpu_flip_study.py, profiles/r02_flip_study.md): f16 operands 0.0286 (35 flips, the largest at margin 0.011),
 # bf16 operands 0.221 (261 flips) -> bounds with ~1.4x headroom.  Overridable: DMAD_RECHECK_MARGIN / recheck_margin=.
 DEFAULT_RECHECK_MARGIN = {1: 0.04, 0: 0.30}           # by dmad_half_type: HALF_F16, HALF_BF16
+# The queued samples first go through the split-f16 tier (fp32 pipeline, three f16 MFMAs per product, ~22 significant bits);
+# only those whose margin is inside ITS error bound reach the exact-fp32 path.
+DEFAULT_RECHECK_MARGIN2 = 2e-3
 VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
 
 
@@ -183,6 +186,7 @@ class Engine:
             if recheck_margin is None:
                 recheck_margin = float(os.environ.get('DMAD_RECHECK_MARGIN', DEFAULT_RECHECK_MARGIN[half_type]))
             self.set_recheck_margin(recheck_margin)
+            self.set_recheck_margin2(float(os.environ.get('DMAD_RECHECK_MARGIN2', DEFAULT_RECHECK_MARGIN2)))
 
     def close(self):
         if getattr(self, '_h', None):
@@ -240,11 +244,24 @@ class Engine:
         check(self.lib.dmad_set_recheck_margin(self._h, float(tau)))
         self.recheck_margin = float(tau)
 
-    def recheck_stats(self, reset: bool = False):
-        """-> (samples voted, samples re-evaluated in fp32) since the last reset."""
-        a, b = C.c_int64(0), C.c_int64(0)
-        check(self.lib.dmad_recheck_stats(self._h, C.byref(a), C.byref(b), 1 if reset else 0))
-        return int(a.value), int(b.value)
+    def set_recheck_margin2(self, tau2: float):
+        """bound of the split-f16 middle tier (< 0: tier off, queued samples go straight to the fp32 path)."""
+        check(self.lib.dmad_set_recheck_margin2(self._h, float(tau2)))
+        self.recheck_margin2 = float(tau2)
+
+    def recheck_stats(self, reset: bool = False, detail: bool = False):
+        """-> (samples voted, samples that left the 16-bit pass) since the last reset; detail: + samples that reached fp32."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(self.lib.dmad_recheck_stats(self._h, C.byref(a), C.byref(b), C.byref(c), 1 if reset else 0))
+        return (int(a.value), int(b.value), int(c.value)) if detail else (int(a.value), int(b.value))
+
+    def wavenet_eps_path(self, x_t: torch.Tensor, t: int, path: int) -> torch.Tensor:
+        """eps-network on an explicit path of an EXACT engine: 0 mode default, 1 exact fp32, 2 split-f16 (three MFMAs per product)."""
+        x = self._wave(x_t)
+        out = torch.empty_like(x)
+        for s, e in self._chunks(x.shape[0]):
+            check(self.lib.dmad_wavenet_eps_path(self._h, _ptr(x[s:e]), int(t), e - s, int(path), _ptr(out[s:e]), _stream()))
+        return out
 
     def load_unet(self, state_dict):
         """improved_diffusion.unet.UNetModel state dict (synth.UNET_CONFIG geometry) -> engine, names prefixed 'un.'."""

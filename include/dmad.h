@@ -171,10 +171,19 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
  * With tau >= the largest error the 16-bit path makes on a logit DIFFERENCE the counts equal the fp32 path's exactly
  * (robustness_eval/certified_robust.py:59-65 is an arg-max: it only depends on the order of the logits).  Defaults:
  * 0.04 for f16 operands (measured error 0.029 over 36 864 samples), 0.30 for bf16 operands (0.22).
- * dmad_recheck_stats returns the number of samples voted and of samples re-evaluated since the last reset. */
+ *
+ * The queued samples pass through two tiers.  Tier 2 is the fp32 pipeline on SPLIT-f16 operands: every fp32 value is kept
+ * as hi = f16(x), lo = f16((x - hi) * 2^11) and every product is three f16 MFMAs (hi*hi + (hi*lo + lo*hi) * 2^-11, fp32
+ * accumulate) — about 22 significant bits at several times the fp32 matrix rate.  It settles every queued sample whose
+ * margin exceeds ITS error bound tau2 (dmad_set_recheck_margin2; default 2e-3, tau2 < 0 switches the tier off); the rest
+ * (margins inside tau2) are evaluated on the exact-fp32 path, tier 3.  dmad_recheck_stats: samples voted, samples that
+ * left the 16-bit pass, samples that reached the fp32 path.  dmad_wavenet_eps_path evaluates the eps-network on an
+ * explicit path (0: the mode's default, 1: exact fp32, 2: split-f16) — test / measurement hook for the tiers. */
 int dmad_set_mode(dmad_engine* e, int32_t mode);
 int dmad_set_recheck_margin(dmad_engine* e, float tau);
-int dmad_recheck_stats(dmad_engine* e, int64_t* samples, int64_t* rechecked, int32_t reset);
+int dmad_set_recheck_margin2(dmad_engine* e, float tau2);
+int dmad_recheck_stats(dmad_engine* e, int64_t* samples, int64_t* rechecked, int64_t* rechecked_fp32, int32_t reset);
+int dmad_wavenet_eps_path(dmad_engine* e, const float* x_t, int32_t t, int32_t B, int32_t path, float* eps, dmad_stream s);
 
 /* Batched query of the whole system for the gradient-free attack drivers: EOT.forward evaluates
  * model(x_batch.repeat(EOT_batch_size, 1, 1)) EOT_num_batches times (robustness_eval/_EOT.py:30-64; callers

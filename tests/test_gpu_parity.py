@@ -800,9 +800,9 @@ def test_bench_contract():
     assert cb['kind'] == 'port' and cb['unit'] == 'clips/s' and cb['value'] > 0 and 1 <= cb['cores'] <= 16 and 'sample' in cb
     assert sum(j['votes']) == 8
     # the measured mode is the exact-vote mode; the 16-bit-only and fp32-only figures ride along
-    assert 'exact-vote' in j['config']['mode'] and 0.0 <= j['recheck']['frac'] <= 1.0 and j['recheck']['margin'] > 0
+    assert 'exact-vote' in j['config']['mode'] and 0.0 <= j['recheck']['frac_fp32'] <= j['recheck']['frac'] <= 1.0 and j['recheck']['margin'] > 0
     assert j['fast_mode']['clips_per_s'] > 0 and j['fp32_mode']['clips_per_s'] > 0 and 0 < j['fp32_mode']['frac_of_fp32_matrix_peak'] < 1
-    assert j['votes'] == j['fp32_mode']['votes'] or j['fp32_mode']['steps'] != 1     # same samples only if the same step index
+    assert sum(j['fast_mode']['votes']) == 8 * j['fast_mode']['steps'] and sum(j['fp32_mode']['votes']) == 8 * j['fp32_mode']['steps']
     ff = j['roofline_final']
     assert ff['bound'] == 'hbm' and ff['unit'] == 'GB/s' and ff['peak'] == 8000.0 and ff['launches_timed'] == 1 and 0 < ff['frac'] < 1.5
     # a rank count the box cannot serve is refused loudly, never run as fewer ranks
@@ -855,6 +855,7 @@ def test_exact_vote_mode_equals_fp32_votes(exact_engine, sched):
             srt = np.sort(fast[1].astype(np.float32), 1)                          # the kernel's own fp32 comparison
             want_recheck = int((~((srt[:, -1] - srt[:, -2]) >= np.float32(eng.recheck_margin))).sum())
             assert ex[2] == (N, want_recheck) and fast[2][1] == 0 and f32[2][1] == 0
+            assert 0 <= eng.recheck_stats(detail=True)[2] <= want_recheck         # only what the split-f16 tier left open reached fp32
             rechecked_all += want_recheck
     eng.set_mode(E.MODE_EXACT_VOTES)
     # the guarantee behind the mode: the bound exceeds the largest error of any logit difference seen on 4608 samples
@@ -1024,3 +1025,24 @@ def test_rccl_backend_runs_the_paths_collectives(tmp_path):
     got = torch.load(out)
     assert got['backend'] == 'nccl' and got['counts'].tolist() == [i * 2 ** 40 for i in range(10)]
     assert int(got['seed'][0]) == 2 ** 61 + 12345 and float(got['tmax'][0]) == 1.5
+
+
+def test_split_f16_tier_is_fp32_grade(exact_engine, golden_dir):
+    """The middle tier of the exact-vote mode: the fp32 pipeline on split-f16 operands (hi + lo * 2^-11, three f16 MFMAs per
+    product) against the reference fixture and the exact-fp32 path: two orders of magnitude below the f16 path's error."""
+    z = G(golden_dir, 'wavenet_full.npz')
+    x_t = torch.from_numpy(z['x_t']).cuda()
+    ref = z['eps'][:, 0]
+    eng = exact_engine
+    f32 = eng.wavenet_eps_path(x_t, int(z['t']), 1).cpu().numpy()
+    x3 = eng.wavenet_eps_path(x_t, int(z['t']), 2).cpu().numpy()
+    f16 = eng.wavenet_eps_path(x_t, int(z['t']), 0).cpu().numpy()
+    assert relmax(f32, ref) < FP32_TOL
+    assert relmax(x3, ref) < 4 * FP32_TOL and relmax(x3, f32) < 4 * FP32_TOL, (relmax(x3, ref), relmax(x3, f32))
+    assert relmax(f16, ref) > 20 * relmax(x3, ref)
+    x = torch.randn(3, 16000, generator=torch.Generator().manual_seed(8)).cuda() * 0.4
+    full = eng.wavenet_eps_path(x, 20, 2)
+    assert torch.equal(full[1:2], eng.wavenet_eps_path(x[1:2], 20, 2))            # batch-slot independent, like the other paths
+    from dmad_hip._lib import DmadError
+    with pytest.raises(DmadError):
+        eng.wavenet_eps_path(x, 20, 7)

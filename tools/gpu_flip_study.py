@@ -41,6 +41,9 @@ if CLASSIFIER == 'resnext29':
 else:
     eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321))
 engs = {'bf16': (eng, E.MODE_FAST), 'fp32': (eng, E.MODE_FP32)}      # 'bf16' = the 16-bit path (either operand format)
+if os.environ.get('X3', '1') == '1':
+    engs['x3'] = (eng, 'x3')             # every sample through the split-f16 tier: tau1 = inf (nothing votes from the 16-bit pass), tau2 = 0
+TAU1, TAU2 = eng.recheck_margin, eng.recheck_margin2
 
 report, raw = [], {}
 for ci in CLIPS:
@@ -52,7 +55,10 @@ for ci in CLIPS:
         sc = float(torch.tensor(abar_star ** 0.5, dtype=torch.float32))
         lg, cnt, secs = {}, {}, {}
         for name, (e, mode) in engs.items():
-            e.set_mode(mode)
+            if mode == 'x3':
+                e.set_mode(E.MODE_EXACT_VOTES); e.set_recheck_margin(1e30); e.set_recheck_margin2(0.0)
+            else:
+                e.set_mode(mode); e.set_recheck_margin(TAU1); e.set_recheck_margin2(TAU2)
             torch.cuda.synchronize()
             t0 = time.time()
             c, l, _ = e.smooth_votes(clip, sigma, sc, t, c_a, c_b, N, seed=1000 + ci, sample0=0, want_logits=True)
@@ -79,6 +85,16 @@ for ci in CLIPS:
                'flip_margins_bf16': sorted(float(v) for v in mb_[flips]), 'flip_margins_fp32': sorted(float(v) for v in mf_[flips]),
                'tau': {str(tau): {'recheck_frac': float((mb_ < tau).mean()), 'surviving_flips': int((flips & (mb_ >= tau)).sum())} for tau in TAUS},
                'clips_per_s': {k: N / v for k, v in secs.items()}}
+        if 'x3' in lg:
+            xx = lg['x3']
+            pe = np.abs((xx[:, :, None] - xx[:, None, :]) - (f[:, :, None] - f[:, None, :])).max((1, 2))
+            srt_x = np.sort(xx, 1)
+            mx_ = srt_x[:, -1] - srt_x[:, -2]
+            xflips = xx.argmax(1) != f.argmax(1)
+            rec['x3'] = {'flips': int(xflips.sum()), 'logit_err_max': float(np.abs(xx - f).max()), 'pair_diff_err_max': float(pe.max()),
+                         'pair_diff_err_rms': float(np.sqrt((pe ** 2).mean())), 'flip_margins_x3': sorted(float(v) for v in mx_[xflips]),
+                         'frac_below': {str(t): float((mx_ < t).mean()) for t in (1e-4, 3e-4, 1e-3, 2e-3, 5e-3)}, 'clips_per_s': N / secs['x3']}
+            print('   x3 tier vs fp32:', json.dumps(rec['x3']), flush=True)
         report.append(rec)
         raw['bf16_c%d_s%g' % (ci, sigma)] = b.astype(np.float32)
         raw['fp32_c%d_s%g' % (ci, sigma)] = f.astype(np.float32)
