@@ -71,8 +71,10 @@ __device__ inline u32x4_t split4(float x0, float x1, float x2, float x3) {
 }
 __device__ inline void join4(u32x4_t c, float out[4]) {
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
-    const f16x2_t h01 = __builtin_bit_cast(f16x2_t, c[0]), h23 = __builtin_bit_cast(f16x2_t, c[1]);
-    const f16x2_t l01 = __builtin_bit_cast(f16x2_t, c[2]), l23 = __builtin_bit_cast(f16x2_t, c[3]);
+    // (scalars first: __builtin_bit_cast applied directly to a vector ELEMENT reads element 0 for every index with this clang)
+    const unsigned c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+    const f16x2_t h01 = __builtin_bit_cast(f16x2_t, c0), h23 = __builtin_bit_cast(f16x2_t, c1);
+    const f16x2_t l01 = __builtin_bit_cast(f16x2_t, c2), l23 = __builtin_bit_cast(f16x2_t, c3);
     out[0] = (float)h01[0] + (float)l01[0] * kSplitInv; out[1] = (float)h01[1] + (float)l01[1] * kSplitInv;
     out[2] = (float)h23[0] + (float)l23[0] * kSplitInv; out[3] = (float)h23[1] + (float)l23[1] * kSplitInv;
 }
