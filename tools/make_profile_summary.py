@@ -19,8 +19,10 @@ import shutil
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LAYER = ('wn_layer_p<', 'false, false>')       # every substring must occur in the kernel name (either operand type)
-FINAL = ('wn_final_p<',)
+# kernel-name patterns, demangled (kernel stats) or mangled (counter collection): a name matches if ALL substrings of ONE
+# alternative occur in it (either operand type)
+LAYER = (('wn_layer_p<', 'false, false>'), ('wn_layer_pI', 'Lb0ELb0E'))
+FINAL = (('wn_final_p<',), ('wn_final_pI',))
 
 
 def one(pattern):
@@ -40,7 +42,7 @@ def counters(d):
 
 
 def mean_for(cnt, kernel_sub, counter):
-    vals = [v for (k, c), vs in cnt.items() if all(sub in k for sub in kernel_sub) and c == counter for v in vs]
+    vals = [v for (k, c), vs in cnt.items() if any(all(sub in k for sub in alt) for alt in kernel_sub) and c == counter for v in vs]
     return sum(vals) / len(vals) if vals else None
 
 
