@@ -252,46 +252,43 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// Split-f16 variant (GemmF32Args::x3): the same 128 x 128 tile, staging and fragment addresses, but both operands are in the
-// split-f16 storage format (dmad_common.h: a 16-byte chunk = 4 values as [hi0 hi1 | hi2 hi3 | lo0 lo1 | lo2 lo3]) and the
-// contraction runs on v_mfma_f32_16x16x32_f16: k-steps are consumed in PAIRS — lane (row, q) reads its chunk q of both
+// Split-f16 variant (GemmF32Args::x3): the staging scheme and fragment addresses of the kernel above, but both operands are
+// in the split-f16 storage format (dmad_common.h: a 16-byte chunk = 4 values as [hi0 hi1 | hi2 hi3 | lo0 lo1 | lo2 lo3]) and
+// the contraction runs on v_mfma_f32_16x16x32_f16: k-steps are consumed in PAIRS — lane (row, q) reads its chunk q of both
 // stages, which gives 8 hi and 8 lo halves = one K = 32 fragment of each part (the k-slot assignment is the same for both
 // operands, so the contraction is unchanged) — and every product is three MFMAs:
 //     main += hi_a * hi_b ;  corr += hi_a * lo_b + lo_a * hi_b ;  result = main + corr * 2^-11.
 // No conversion work in the loop: producers write the format once (epilogues below, wn_init / scale kernels).
-// 4-slot ring (2 pairs), one barrier per pair, pair p+1 in flight while pair p is contracted; 2 workgroups per CU.
+// Three MFMAs per staged byte make the loop LDS-DMA-latency bound, not matrix bound, unless several k-step pairs are in
+// flight: tile 256(M) x 128(N), 8 waves (4 x 2, wave tile 64 x 64, one workgroup per CU), pair = 48 KiB (A 2 x 16 KiB,
+// X 2 x 8 KiB), 3-pair ring = 144 KiB of dynamic LDS: two pairs in flight while one is contracted, one barrier per pair.
 // ----------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmF32Args a) {
-    constexpr int BM = 128, MT = 4;
-    __shared__ __attribute__((aligned(16))) char smem[4 * SLOT];
+constexpr int X3_BM = 256, X3_STAGE = 24576, X3_PAIR = 2 * X3_STAGE, X3_LDS = 3 * X3_PAIR;
+__global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
+    constexpr int BM = X3_BM, MT = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1, q = lane >> 4, r16 = lane & 15;
     const long n0 = (long)blockIdx.x * BN;
     const int m0 = blockIdx.y * BM;
     const int ksteps_per_tap = a.K / BK, npairs = (a.taps * ksteps_per_tap) >> 1;
+    // staging rows of this thread: A rows rloc and rloc + 128 of the 256, X row rloc of the 128 (8 waves x 16 rows per piece)
     const int rloc = wv * 16 + (lane >> 2), chunk4 = ((lane & 3) ^ swz64(lane >> 2)) * 4;
     const float* zero = g_zero_page;
     const float* arow[2];
-    long xbase[2];
-    bool xok[2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int m = m0 + p * 64 + rloc;
-        arow[p] = m < a.M ? a.A + (size_t)m * a.K + chunk4 : nullptr;
-        const long n = n0 + p * 64 + rloc;
-        xok[p] = n < a.N;
-        const long b = xok[p] ? n / a.rows_per_batch : 0, r = xok[p] ? n - b * a.rows_per_batch : 0;
-        xbase[p] = b * a.batch_stride + r * a.row_stride;
-    }
-    auto stage = [&](int ks, int slot) {
+    for (int p = 0; p < 2; ++p) arow[p] = a.A + (size_t)(m0 + p * 128 + rloc) * a.K + chunk4;       // M is a multiple of 256 (launcher)
+    const long n = n0 + rloc;
+    const bool xok = n < a.N;
+    const long xb = xok ? n / a.rows_per_batch : 0;
+    const long xbase = xb * a.batch_stride + (xok ? n - xb * a.rows_per_batch : 0) * a.row_stride;
+    auto stage = [&](int ks, char* base) {          // base: this k-step's 24 KiB (A rows 0-255: 16 KiB, X rows 0-127: 8 KiB)
         const int tap = ks / ksteps_per_tap, kc = (ks - tap * ksteps_per_tap) * BK;
-        char* la = smem + slot * SLOT + wv * 1024;
+        char* la = base + wv * 1024;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) glds16(arow[p] ? arow[p] + (size_t)tap * a.M * a.K + kc : zero, la + p * 4096);
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-            glds16(xok[p] ? a.X + xbase[p] + (long)(tap - (a.taps >> 1)) * a.tap_stride + kc + chunk4 : zero, la + 8192 + p * 4096);
+        for (int p = 0; p < 2; ++p) glds16(arow[p] + (size_t)tap * a.M * a.K + kc, la + p * 8192);
+        glds16(xok ? a.X + xbase + (long)(tap - (a.taps >> 1)) * a.tap_stride + kc + chunk4 : zero, la + 16384);
     };
     f32x4 acc[MT][4], cor[MT][4];
 #pragma unroll
@@ -299,24 +296,28 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmF32Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; cor[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const int frag = r16 * 64 + ((q ^ swz64(r16)) * 16);
-    stage(0, 0);
-    stage(1, 1);
+    stage(0, smem); stage(1, smem + X3_STAGE);
+    if (npairs > 1) { stage(2, smem + X3_PAIR); stage(3, smem + X3_PAIR + X3_STAGE); }
+    int slot = 0;
     for (int p = 0; p < npairs; ++p) {
-        const int s0 = (p & 1) * 2;
-        GF_WAIT_BARRIER(0);                    // pair p landed; every wave is done reading pair p-1
-        if (p + 1 < npairs) { stage(2 * p + 2, s0 ^ 2); stage(2 * p + 3, (s0 ^ 2) + 1); }
-        const char* A0 = smem + s0 * SLOT + wm * (BM * 32) + frag;
-        const char* B0 = smem + s0 * SLOT + 8192 + wn * 4096 + frag;
+        // pair p landed (the 6 pieces of pair p+1 may still fly); every wave is done reading pair p-1
+        if (p + 1 < npairs) { GF_WAIT_BARRIER(6); } else { GF_WAIT_BARRIER(0); }
+        if (p + 2 < npairs) {
+            char* nb = smem + (slot == 0 ? 2 : slot - 1) * X3_PAIR;      // the slot pair p-1 occupied
+            stage(2 * p + 4, nb); stage(2 * p + 5, nb + X3_STAGE);
+        }
+        const char* A0 = smem + slot * X3_PAIR + wm * 4096 + frag;
+        const char* B0 = smem + slot * X3_PAIR + 16384 + wn * 4096 + frag;
         f16x8 ahi[MT], alo[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const u32x4_t c0 = *(const u32x4_t*)(A0 + i * 1024), c1 = *(const u32x4_t*)(A0 + SLOT + i * 1024);
+            const u32x4_t c0 = *(const u32x4_t*)(A0 + i * 1024), c1 = *(const u32x4_t*)(A0 + X3_STAGE + i * 1024);
             ahi[i] = __builtin_bit_cast(f16x8, u32x4_t{c0[0], c0[1], c1[0], c1[1]});
             alo[i] = __builtin_bit_cast(f16x8, u32x4_t{c0[2], c0[3], c1[2], c1[3]});
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const u32x4_t c0 = *(const u32x4_t*)(B0 + j * 1024), c1 = *(const u32x4_t*)(B0 + SLOT + j * 1024);
+            const u32x4_t c0 = *(const u32x4_t*)(B0 + j * 1024), c1 = *(const u32x4_t*)(B0 + X3_STAGE + j * 1024);
             const f16x8 bhi = __builtin_bit_cast(f16x8, u32x4_t{c0[0], c0[1], c1[0], c1[1]});
             const f16x8 blo = __builtin_bit_cast(f16x8, u32x4_t{c0[2], c0[3], c1[2], c1[3]});
 #pragma unroll
@@ -326,6 +327,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmF32Args a) {
                 cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[i], bhi, cor[i][j], 0, 0, 0);
             }
         }
+        slot = slot == 2 ? 0 : slot + 1;
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -338,7 +340,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmF32Args a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int mrow = m0 + wm * 64 + i * 16 + q * 4;
-            const int ch = blockIdx.y * 64 + wm * 32 + i * 16 + q * 4;
+            const int ch = ((m0 + wm * 64) >> 1) + i * 16 + q * 4;       // 64-row wave slab = 32 gate channels (tanh rows | sigmoid rows)
             const float4 bt = *(const float4*)(a.shift + mrow), bs = *(const float4*)(a.shift + mrow + 32);
             const float bta[4] = {bt.x, bt.y, bt.z, bt.w}, bsa[4] = {bs.x, bs.y, bs.z, bs.w};
 #pragma unroll
@@ -348,8 +350,13 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmF32Args a) {
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    // tanh(ht) * sigmoid(hs) = (1 - u) / ((1 + u)(1 + v)), u = e^-2ht, v = e^-hs: two v_exp + one v_rcp (~1 ulp each)
+                    // instead of the libm tanhf / expf / division of the exact path, whose ~150 instructions per value would cost
+                    // this tier as much as its matrix work; the difference (~3e-7 relative) is far inside the tier's bound
                     const float ht = acc[i][j][r] + bta[r], hs = acc[i + 2][j][r] + bsa[r];
-                    v[r] = tanhf(ht) * (1.f / (1.f + expf(-hs)));
+                    const float u = fast_exp2(fminf(ht * -2.8853900817779268f, 30.f)), w = fast_exp2(hs * -1.4426950408889634f);
+                    const float pp = 1.f + u, rr = fast_rcp(pp * w + pp);
+                    v[r] = rr - u * rr;
                 }
                 *(u32x4_t*)(a.C + n * 256 + ch) = split4(v[0], v[1], v[2], v[3]);
             }
@@ -427,9 +434,14 @@ void launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long sla
     GemmF32Args a = a0;
     if (a.x3) {                                   // split-f16 operands: WaveNet shapes only (checked here, not in the kernel)
         const int nks = a.taps * (a.K / BK);
-        if (a.mode != 0 || (a.M & 127) || (nks & 1) || a.scale || a.res || a.groups > 1 || (a.ldc & 3)) abort();
+        if (a.mode != 0 || (a.M % X3_BM) || (nks & 1) || a.scale || a.res || a.groups > 1 || (a.ldc & 3)) abort();
+        static bool configured = false;
+        if (!configured) {
+            if (hipFuncSetAttribute((const void*)gemm_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) != hipSuccess) abort();
+            configured = true;
+        }
         a.splits = 1; a.slab = nullptr;
-        hipLaunchKernelGGL(gemm_x3_kernel, dim3((unsigned)((a.N + BN - 1) / BN), (unsigned)(a.M / 128)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(gemm_x3_kernel, dim3((unsigned)((a.N + BN - 1) / BN), (unsigned)(a.M / X3_BM)), dim3(512), X3_LDS, s, a);
         return;
     }
     const int BM = a.M <= 64 ? 64 : 128;          // 64-row tiles where a 128-row tile would be half empty
