@@ -1330,6 +1330,37 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
     return 0;
 }
 
+int dmad_spec_smooth_votes(dmad_engine* e, const float* clip, float sigma, int32_t t_star, float q_a, float q_b, const float* c_a,
+                           const float* c_b, const float* c_1, const float* c_2, const float* c_sig, float mel_lo, float mel_hi, int64_t n,
+                           int32_t batch, uint64_t seed, uint64_t sample0, int64_t* counts, float* logits_out, float* spec_out, dmad_stream s) {
+    if (!e || !clip || !counts || !c_a || !c_b || !c_1 || !c_2 || !c_sig) return fail(DMAD_ERR_INVALID, "null argument");
+    if (!e->cfg.with_classifier || !e->cls_final) return fail(DMAD_ERR_STATE, "the spec-domain vote loop needs the mel front-end and a finalised classifier");
+    if (!e->un_final) return fail(DMAD_ERR_STATE, "UNet weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
+    if (n < 0 || batch < 1 || batch > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d] or n < 0", batch, e->maxB);
+    if (t_star < 0) return fail(DMAD_ERR_INVALID, "t_star %d < 0", t_star);
+    if (!(mel_hi > mel_lo)) return fail(DMAD_ERR_INVALID, "empty mel range");
+    hipStream_t st = (hipStream_t)s;
+    const int L = e->L, C = e->cfg.num_classes;
+    for (int64_t done = 0; done < n; done += batch) {
+        const int B = (int)((n - done < batch) ? (n - done) : batch);
+        const uint64_t s0 = sample0 + (uint64_t)done;
+        launch_mc_noise_scale(clip, nullptr, sigma, 1.f, seed, s0, e->xt, B, L, st);      // no wave denoiser: no sqrt(alpha_bar*) scale
+        CHK(mel_db(e, e->xt, B, e->spec, st));
+        launch_philox_normal(seed, s0, 0x5BECu, e->znoise, B, 1024, st);
+        float* x = e->x0;                                                                   // [B][32][32] chain state
+        launch_spec_diffuse(e->spec, e->znoise, mel_lo, mel_hi, q_a, q_b, x, (long)B * 1024, st);
+        for (int t = t_star; t >= 0; --t)
+            CHK(dmad_unet_p_sample(e, x, t, c_a[t], c_b[t], c_1[t], c_2[t], t > 0 ? c_sig[t] : 0.f, nullptr, seed, s0, B, nullptr, s));
+        float* sp = spec_out ? spec_out + done * 1024 : e->spec;
+        launch_spec_unstandardize(x, mel_lo, mel_hi, sp, (long)B * 1024, st);
+        float* lg = logits_out ? logits_out + done * C : e->logits;
+        CHK(classify(e, sp, B, lg, st));
+        launch_vote(lg, B, C, (unsigned long long*)counts, nullptr, st);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int dmad_query_logits(dmad_engine* e, const float* x, int32_t B, int32_t repeats, int32_t sampler, int32_t t_star, float c_a, float c_b,
                       const float* c_eps, const float* c_div, const float* c_sig, uint64_t seed, uint64_t sample0, float* logits,
                       int32_t* decisions, dmad_stream s) {

@@ -25,4 +25,9 @@ void launch_qkv_attention(const float* qkv, float* out, int B, int T, int heads,
 void launch_unet_p_sample(const float* x, const float* eps, const float* z, float ca, float cb, float c1, float c2, float sig,
                           float* out, float* x0_out, long n, hipStream_t s);
 
+// melspec_standardize + q_sample (z == nullptr: standardise only) and melspec_inv_standardize of the spec-domain purifier
+// (sc09_spectrogram_dataset.py:62-81, gaussian_diffusion.py:188-206)
+void launch_spec_diffuse(const float* spec, const float* z, float lo, float hi, float qa, float qb, float* xt, long n, hipStream_t s);
+void launch_spec_unstandardize(const float* x, float lo, float hi, float* spec, long n, hipStream_t s);
+
 }  // namespace dmad

@@ -152,7 +152,29 @@ __global__ void unet_p_sample_kernel(const float* __restrict__ x, const float* _
     out[i] = r;
     if (x0_out) x0_out[i] = x0;
 }
+// melspec_standardize (sc09_spectrogram_dataset.py:65-72) then q_sample (gaussian_diffusion.py:188-206), reference op order:
+//   x0 = 2 * (spec - lo) / (hi - lo) - 1 ;  x_t = qa * x0 + qb * z
+__global__ void spec_diffuse_kernel(const float* __restrict__ spec, const float* __restrict__ z, float lo, float range, float qa, float qb,
+                                    float* __restrict__ xt, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x0 = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, __fsub_rn(spec[i], lo)), range), 1.f);
+    xt[i] = z ? __fadd_rn(__fmul_rn(qa, x0), __fmul_rn(qb, z[i])) : x0;
+}
+// melspec_inv_standardize (l.74-81): spec = (x + 1) * (hi - lo) / 2 + lo
+__global__ void spec_unstandardize_kernel(const float* __restrict__ x, float lo, float range, float* __restrict__ spec, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    spec[i] = __fadd_rn(__fdiv_rn(__fmul_rn(__fadd_rn(x[i], 1.f), range), 2.f), lo);
+}
 }  // namespace
+
+void launch_spec_diffuse(const float* spec, const float* z, float lo, float hi, float qa, float qb, float* xt, long n, hipStream_t s) {
+    hipLaunchKernelGGL(spec_diffuse_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, spec, z, lo, hi - lo, qa, qb, xt, n);
+}
+void launch_spec_unstandardize(const float* x, float lo, float hi, float* spec, long n, hipStream_t s) {
+    hipLaunchKernelGGL(spec_unstandardize_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, x, lo, hi - lo, spec, n);
+}
 
 void launch_conv1ch_3x3(const float* in, const float* w, const float* bias, float* out, int B, int Cout, hipStream_t s) {
     const long total = (long)B * 1024 * Cout;

@@ -33,12 +33,37 @@ class ImprovedDiffusion(torch.nn.Module):
         t = torch.full((x_0.shape[0],), self.reverse_timestep, dtype=torch.long, device=x_0.device)
         return self.diffusion.q_sample(x_0, t=t)
 
+    def purify_coefficients(self):
+        """The argument block of dmad_spec_smooth_votes: (t*, q_a, q_b, c_a[], c_b[], c_1[], c_2[], c_sig[]) for q_sample at t* and
+        p_sample at t = 0..t*, each the fp32 table entry GaussianDiffusion.q_sample / p_sample use."""
+        gd, ts = self.diffusion, self.reverse_timestep
+        f = gd._f32
+        sig = [0.0 if t == 0 else float(torch.exp(torch.tensor(0.5 * f(gd.model_log_variance, t)))) for t in range(ts + 1)]
+        return (ts, f(gd.sqrt_alphas_cumprod, ts), f(gd.sqrt_one_minus_alphas_cumprod, ts),
+                [f(gd.sqrt_recip_alphas_cumprod, t) for t in range(ts + 1)], [f(gd.sqrt_recipm1_alphas_cumprod, t) for t in range(ts + 1)],
+                [f(gd.posterior_mean_coef1, t) for t in range(ts + 1)], [f(gd.posterior_mean_coef2, t) for t in range(ts + 1)], sig)
+
     @torch.no_grad()
     def _reverse(self, x_t):
         if isinstance(x_t, np.ndarray):
             x_t = torch.from_numpy(x_t)
         return self.diffusion.p_sample_loop(model=self.model, shape=x_t.shape, noise=x_t, start_timestep=self.reverse_timestep + 1,
                                             seed=self.seed)
+
+
+class SpecDefense(torch.nn.Module):
+    """Waveform -> purified mel-dB spectrogram: the `transform` + spec `defender` of an AcousticSystem(defense_type='spec')
+    (acoustic_system.py:40-49) as one callable, so that RobustCertificate(classifier, transform=SpecDefense(mel, purifier))
+    is the certified-smoothing loop of BASELINE configuration C5.  With all three stages on one engine that loop is ONE
+    C-ABI call (dmad_spec_smooth_votes); called directly it is mel -> standardise -> ImprovedDiffusion.forward."""
+
+    def __init__(self, mel, purifier: ImprovedDiffusion):
+        super().__init__()
+        self.mel, self.purifier = mel, purifier
+
+    @torch.no_grad()
+    def forward(self, x):
+        return self.purifier(melspec_standardize(self.mel(x)))
 
 
 def create_improved_diffusion(model_path, reverse_timestep=25, state_dict=None, engine=None):

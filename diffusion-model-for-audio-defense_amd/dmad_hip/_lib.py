@@ -50,6 +50,8 @@ _SIGNATURES = {
     'dmad_wavenet_eps_path': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     'dmad_query_logits': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P,
                                     C.c_uint64, C.c_uint64, _P, _P, _P]),
+    'dmad_spec_smooth_votes': (C.c_int, [_P, _P, C.c_float, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, _P, C.c_float, C.c_float,
+                                         C.c_int64, C.c_int32, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
     'dmad_vote': (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     'dmad_philox_raw': (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _P, _P]),
     'dmad_philox_normal': (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int32, _P, _P]),

@@ -423,6 +423,24 @@ class Engine:
                                          _ptr(x0), _stream()))
         return counts, logits, x0
 
+    def spec_smooth_votes(self, clip: torch.Tensor, sigma: float, t_star: int, q_a: float, q_b: float, c_a, c_b, c_1, c_2, c_sig,
+                          mel_lo: float, mel_hi: float, n: int, batch: Optional[int] = None, seed: int = 0, sample0: int = 0,
+                          want_logits: bool = False, want_spec: bool = False, counts: Optional[torch.Tensor] = None):
+        """dmad_spec_smooth_votes (BASELINE C5): the vote loop with the spec-domain UNet purifier.  Coefficient sequences
+        c_*: t_star + 1 floats each (p_sample at t = 0..t_star).  Returns (counts, logits|None, purified spec|None)."""
+        clip = clip.detach().reshape(-1).contiguous().float()
+        assert clip.is_cuda and clip.numel() == self.L
+        batch = min(batch or self.max_batch, self.max_batch)
+        if counts is None:
+            counts = torch.zeros(self.num_classes, dtype=torch.int64, device=clip.device)
+        logits = torch.empty((n, self.num_classes), device=clip.device) if want_logits else None
+        spec = torch.empty((n, 1, 32, 32), device=clip.device) if want_spec else None
+        arrs = [(C.c_float * (t_star + 1))(*[float(v) for v in a]) for a in (c_a, c_b, c_1, c_2, c_sig)]
+        check(self.lib.dmad_spec_smooth_votes(self._h, _ptr(clip), float(sigma), int(t_star), float(q_a), float(q_b), arrs[0], arrs[1], arrs[2],
+                                              arrs[3], arrs[4], float(mel_lo), float(mel_hi), int(n), int(batch), int(seed), int(sample0),
+                                              _ptr(counts), _ptr(logits), _ptr(spec), _stream()))
+        return counts, logits, spec
+
     def query_logits(self, x: torch.Tensor, repeats: int, sampler: int = 0, t_star: int = 0, c_a: float = 0.0, c_b: float = 0.0,
                      c_eps=None, c_div=None, c_sig=None, seed: int = 0, sample0: int = 0):
         """dmad_query_logits: x [B,1,L] -> (logits [repeats*B, C], decisions int32 [repeats*B]); row r*B+b is clip b."""

@@ -64,6 +64,28 @@ class RobustCertificate():
                 cls.bind_engine()
         return (eng is not None and is_mel_db and getattr(cls, 'engine', None) is eng and eng.has_classifier and eng.has_wavenet)
 
+    def _fused_spec(self):
+        """The engine that runs the spec-domain loop (BASELINE C5) in one call: no waveform denoiser, transform = SpecDefense(mel,
+        Improved-Diffusion purifier), every stage HIP-backed on ONE engine, device noise.  None otherwise."""
+        if self.denoiser is not None or self.noise_source != 'device':
+            return None
+        from diffusion_models.improved_diffusion_ddpm import SpecDefense
+        from dmad_hip.transforms import MelSpectrogramDB
+        tr, cls = self.transform, self.classifier
+        if not isinstance(tr, SpecDefense) or not isinstance(tr.mel, MelSpectrogramDB):
+            return None
+        eng = tr.mel.engine
+        model = tr.purifier.model
+        if getattr(model, '__dict__', {}).get('engine') is not eng:      # the HIP UNet keeps its engine in __dict__ once bound
+            return None
+        if hasattr(cls, 'bind_engine') and 'engine' not in getattr(cls, '__dict__', {}):
+            from dmad_hip._lib import DmadError
+            try:
+                cls.bind_engine(eng)
+            except DmadError:
+                return None
+        return eng if (getattr(cls, 'engine', None) is eng and eng.has_classifier and eng.has_unet) else None
+
     @torch.no_grad()
     def forward(self, x: torch.Tensor):
         x_in = x
@@ -130,6 +152,12 @@ class RobustCertificate():
                 done += b
             if counts is None:
                 counts = torch.zeros(self.num_classes, dtype=torch.int64, device=x.device)
+        elif self._fused_spec() is not None and hi > lo:
+            from diffusion_models.Improved_Diffusion_Unconditional.improved_diffusion.sc09_spectrogram_dataset import MEL_LOWER_BOUND, MEL_UPPER_BOUND
+            pur = self.transform.purifier
+            ts, q_a, q_b, c_a, c_b, c_1, c_2, c_sig = pur.purify_coefficients()
+            counts, _, _ = self._fused_spec().spec_smooth_votes(x, sigma, ts, q_a, q_b, c_a, c_b, c_1, c_2, c_sig, MEL_LOWER_BOUND, MEL_UPPER_BOUND,
+                                                                hi - lo, batch=batch_size, seed=seed, sample0=lo)
         elif fused and hi > lo:
             counts, _, _ = self.denoiser.engine.smooth_votes(x, sigma, coeffs[3], coeffs[0], coeffs[1], coeffs[2], hi - lo,
                                                              seed=seed, sample0=lo)

@@ -185,6 +185,22 @@ int dmad_set_recheck_margin2(dmad_engine* e, float tau2);
 int dmad_recheck_stats(dmad_engine* e, int64_t* samples, int64_t* rechecked, int64_t* rechecked_fp32, int32_t reset);
 int dmad_wavenet_eps_path(dmad_engine* e, const float* x_t, int32_t t, int32_t B, int32_t path, float* eps, dmad_stream s);
 
+/* BASELINE configuration C5: the Monte Carlo vote loop with the SPEC-domain purifier (Improved-Diffusion UNet on 1x32x32 mel
+ * spectrograms) in place of the waveform purifier.  The reference has no working composite for it
+ * (diffusion_models/improved_diffusion_ddpm.py:53-59 discards its reverse chain), so the loop is DEFINED here as what its parts
+ * are for — randomized smoothing in the input domain (certified_robust.py:46-48, no denoiser => no sqrt(alpha_bar*) scale), then
+ * AcousticSystem's defense_type = 'spec' order (acoustic_system.py:40-49):  for samples i in [sample0, sample0 + n):
+ *   x_i = clip + sigma * delta_i                    (Philox keyed (seed, i), stream 0)
+ *   s   = mel_dB(x_i) ; s0 = 2 (s - lo) / (hi - lo) - 1            (melspec_standardize, sc09_spectrogram_dataset.py:62-72)
+ *   s_t = q_a * s0 + q_b * z                        (q_sample at t = t_star, gaussian_diffusion.py:188-206; Philox stream 0x5BEC)
+ *   for t = t_star .. 0:  s_t <- p_sample(s_t, t)   (dmad_unet_p_sample with c_a/c_b/c_1/c_2/c_sig[t]: HOST arrays of t_star + 1 entries)
+ *   logits = classifier((s_0 + 1)(hi - lo) / 2 + lo) ; counts[argmax] += 1.
+ * q_a / q_b = sqrt_alphas_cumprod[t_star] / sqrt_one_minus_alphas_cumprod[t_star].  counts: device int64[num_classes],
+ * accumulated; logits_out [n][num_classes] and spec_out [n][32][32] (the purified dB spectrograms) optional. */
+int dmad_spec_smooth_votes(dmad_engine* e, const float* clip, float sigma, int32_t t_star, float q_a, float q_b, const float* c_a,
+                           const float* c_b, const float* c_1, const float* c_2, const float* c_sig, float mel_lo, float mel_hi, int64_t n,
+                           int32_t batch, uint64_t seed, uint64_t sample0, int64_t* counts, float* logits_out, float* spec_out, dmad_stream s);
+
 /* Batched query of the whole system for the gradient-free attack drivers: EOT.forward evaluates
  * model(x_batch.repeat(EOT_batch_size, 1, 1)) EOT_num_batches times (robustness_eval/_EOT.py:30-64; callers
  * black_box_attack.py:186-220, _NES.py:15-55) where model = AcousticSystem(classifier, transform, defender)

@@ -1046,3 +1046,58 @@ def test_split_f16_tier_is_fp32_grade(exact_engine, golden_dir):
     from dmad_hip._lib import DmadError
     with pytest.raises(DmadError):
         eng.wavenet_eps_path(x, 20, 7)
+
+
+# ------------------------------------------------------------------------------------------ BASELINE C5: spec-domain vote loop
+def test_config5_spec_domain_vote_loop(golden_dir):
+    """BASELINE config 5 — certified smoothing with the Improved-Diffusion UNet purifier on mel spectrograms.  The reference has
+    no working composite (improved_diffusion_ddpm.py:53-59), so the loop is the one include/dmad.h defines for
+    dmad_spec_smooth_votes; checked here against the SAME chain composed from the separately pinned parts (mel, q_sample,
+    p_sample, classifier: each vs reference fixtures elsewhere in this file) on the same Philox keys, plus the shard /
+    batch-size invariance the multi-GPU path relies on."""
+    from diffusion_models.improved_diffusion_ddpm import SpecDefense, create_improved_diffusion, melspec_standardize, melspec_inv_standardize
+    from dmad_hip import engine as E
+    from dmad_hip.transforms import MelSpectrogramDB
+    from robustness_eval.certified_robust import RobustCertificate
+    z = G(golden_dir, 'unet.npz')
+    eng = E.Engine(max_batch=16, precision=E.FP32)
+    pur = create_improved_diffusion(None, reverse_timestep=3, state_dict=synth.unet_state_dict(int(z['seed'])), engine=eng)
+    net = synth_vgg().bind_engine(eng)
+    mel = MelSpectrogramDB(eng)
+    rc = RobustCertificate(classifier=net, transform=SpecDefense(mel, pur), denoiser=None, seed=5)
+    assert rc._fused_spec() is eng
+    clip = torch.from_numpy(synth.synthetic_clip(6)).cuda()
+    counts = rc.smooth_predict(clip, num_sampling=40, sigma=0.5, batch_size=16)
+    assert counts.dtype == torch.int64 and int(counts.sum()) == 40
+    # the engine call against the chain composed from its parts, same keys
+    ts, q_a, q_b, c_a, c_b, c_1, c_2, c_sig = pur.purify_coefficients()
+    assert ts == 3 and len(c_a) == 4 and c_sig[0] == 0.0
+    seed, s0, B, sigma = 77, 10, 6, 0.5
+    cnt, lg, sp = eng.spec_smooth_votes(clip, sigma, ts, q_a, q_b, c_a, c_b, c_1, c_2, c_sig, -100.0, 38.22, B, seed=seed, sample0=s0,
+                                        want_logits=True, want_spec=True)
+    x_in = clip.reshape(1, 1, -1) + sigma * eng.philox_normal(seed, s0, 0, B).unsqueeze(1)
+    x0 = melspec_standardize(mel(x_in))
+    zq = eng.philox_normal(seed, s0, 0x5BEC, B)[:, :1024].reshape(B, 1, 32, 32)
+    x = pur.diffusion.q_sample(x0, torch.full((B,), ts, dtype=torch.long).cuda(), noise=zq)
+    for t in range(ts, -1, -1):
+        x = pur.diffusion.p_sample(pur.model, x, torch.full((B,), t), seed=seed, sample0=s0)['sample']
+    ref_spec = melspec_inv_standardize(x)
+    ref_logits = net(ref_spec)
+    assert float((sp - ref_spec).abs().max()) < 2e-3 and float((lg - ref_logits).abs().max()) < 2e-3
+    assert lg.argmax(1).tolist() == ref_logits.argmax(1).tolist()
+    assert cnt.cpu().tolist() == torch.bincount(ref_logits.argmax(1).cpu(), minlength=10).tolist()
+    assert float(sp.min()) >= -100.0 - 1e-3 and float(sp.max()) <= 38.22 + 1e-3          # clip_denoised keeps the chain in range
+    # shard / batch invariance: rows are keyed by their global sample index
+    a, _, _ = eng.spec_smooth_votes(clip, sigma, ts, q_a, q_b, c_a, c_b, c_1, c_2, c_sig, -100.0, 38.22, 40, batch=16, seed=3)
+    b1, _, _ = eng.spec_smooth_votes(clip, sigma, ts, q_a, q_b, c_a, c_b, c_1, c_2, c_sig, -100.0, 38.22, 13, batch=5, seed=3, sample0=0)
+    b2, _, _ = eng.spec_smooth_votes(clip, sigma, ts, q_a, q_b, c_a, c_b, c_1, c_2, c_sig, -100.0, 38.22, 27, batch=16, seed=3, sample0=13)
+    assert torch.equal(a, b1 + b2)
+    # unfused use of the same object: SpecDefense as a plain transform
+    out = SpecDefense(mel, pur)(x_in[:2])
+    assert out.shape == (2, 1, 32, 32) and bool(torch.isfinite(out).all())
+    from dmad_hip._lib import DmadError
+    bare = E.Engine(max_batch=2, precision=E.FP32)
+    with pytest.raises(DmadError):
+        bare.spec_smooth_votes(clip, sigma, ts, q_a, q_b, c_a, c_b, c_1, c_2, c_sig, -100.0, 38.22, 2)     # no UNet / classifier loaded
+    bare.close()
+    eng.close()
