@@ -947,6 +947,10 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
         }
         if (e->bf16 && e->f32) {             // recheck queue of the exact-vote mode
             e->rc_cap = 1l << 20;
+            if (const char* q = getenv("DMAD_RECHECK_QUEUE")) {     // tests: a small queue exercises the mid-call drain
+                const long v = atol(q);
+                if (v >= 1 && v < e->rc_cap) e->rc_cap = v;
+            }
             if ((r = e->alloc(&e->rc_list, (size_t)e->rc_cap))) break;
             if ((r = e->alloc(&e->rc_list2, (size_t)e->rc_cap))) break;
             if ((r = e->alloc(&e->rc_n, 1, true))) break;

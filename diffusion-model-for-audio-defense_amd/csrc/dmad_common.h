@@ -79,6 +79,13 @@ __device__ inline void join4(u32x4_t c, float out[4]) {
     out[2] = (float)h23[0] + (float)l23[0] * kSplitInv; out[3] = (float)h23[1] + (float)l23[1] * kSplitInv;
 }
 
+// torch.relu / torch.maximum / torch.clamp / max_pool keep a NaN a NaN; fmaxf / fminf return the other operand.  A NaN sample
+// must come out as NaN logits (its vote is then the reference's: the first NaN index), so the path uses these forms.
+__device__ inline float relu_nan(float t) { return t < 0.f ? 0.f : t; }
+__device__ inline float max_nan(float a, float b) { return (a > b || a != a) ? a : b; }
+__device__ inline float clamp_min_nan(float t, float lo) { return t < lo ? lo : t; }
+__device__ inline float clamp_nan(float t, float lo, float hi) { return t < lo ? lo : (t > hi ? hi : t); }
+
 __device__ inline float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ inline float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

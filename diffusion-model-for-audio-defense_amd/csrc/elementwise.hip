@@ -210,7 +210,7 @@ __global__ void wn_init_f32_kernel(const float* __restrict__ x, const float* __r
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = c4 * 4 + j;
-        po[j] = __fadd_rn(fmaxf(__fadd_rn(__fmul_rn(w[c], xv), bias[c]), 0.f), emb0[c]);
+        po[j] = __fadd_rn(relu_nan(__fadd_rn(__fmul_rn(w[c], xv), bias[c])), emb0[c]);
     }
     if (SPLIT) *(u32x4_t*)(h + ((bb * LP + kPad + t) * kC + c4 * 4)) = split4(o.x, o.y, o.z, o.w);
     else *(float4*)(h + ((bb * LP + kPad + t) * kC + c4 * 4)) = o;
@@ -316,7 +316,7 @@ __global__ void mel_db_kernel(const float* __restrict__ M, float* __restrict__ s
     const long b = i >> 10;
     const int mel = (int)((i >> 5) & 31), fr = (int)(i & 31);
     if (!to_db) { spec[i] = M[(b * 32 + fr) * 32 + mel]; return; }     // MelSpectrogram alone: power, [b][mel][frame]
-    const float v = fmaxf(M[(b * 32 + fr) * 32 + mel], 1e-10f);
+    const float v = clamp_min_nan(M[(b * 32 + fr) * 32 + mel], 1e-10f);
     // fp32 log10 rounded from a double evaluation (10*log10(1e-10f) must be exactly -100 like on the CPU)
     spec[i] = __fmul_rn(10.f, (float)log10((double)v));
 }
@@ -340,7 +340,7 @@ __global__ void vgg_conv1_kernel(const float* __restrict__ in, const float* __re
             const int yy = y + ky - 1, xx = x + kx - 1;
             if ((unsigned)yy < 32u && (unsigned)xx < 32u) s = fmaf(w[co * 9 + ky * 3 + kx], in[(b << 10) + yy * 32 + xx], s);
         }
-    out[i] = fmaxf(s * scale[co] + shift[co], 0.f);
+    out[i] = relu_nan(s * scale[co] + shift[co]);
 }
 
 // 2x2 max pool, NHWC
@@ -357,8 +357,8 @@ __global__ void maxpool2_nhwc_kernel(const float* __restrict__ in, float* __rest
     const float4 a = *(const float4*)s, bq = *(const float4*)(s + C), c = *(const float4*)(s + (long)W * C),
                  d = *(const float4*)(s + (long)W * C + C);
     float4 o;
-    o.x = fmaxf(fmaxf(a.x, bq.x), fmaxf(c.x, d.x)); o.y = fmaxf(fmaxf(a.y, bq.y), fmaxf(c.y, d.y));
-    o.z = fmaxf(fmaxf(a.z, bq.z), fmaxf(c.z, d.z)); o.w = fmaxf(fmaxf(a.w, bq.w), fmaxf(c.w, d.w));
+    o.x = max_nan(max_nan(a.x, bq.x), max_nan(c.x, d.x)); o.y = max_nan(max_nan(a.y, bq.y), max_nan(c.y, d.y));
+    o.z = max_nan(max_nan(a.z, bq.z), max_nan(c.z, d.z)); o.w = max_nan(max_nan(a.w, bq.w), max_nan(c.w, d.w));
     ((float4*)out)[i] = o;
 }
 
@@ -493,7 +493,7 @@ void launch_mel_db(const float* M, float* spec, int B, int to_db, hipStream_t s)
 // AmplitudeToDB(stype='power') on its own: y = 10 * log10(max(x, 1e-10))
 __global__ void power_to_db_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] = __fmul_rn(10.f, (float)log10((double)fmaxf(x[i], 1e-10f)));
+    if (i < n) y[i] = __fmul_rn(10.f, (float)log10((double)clamp_min_nan(x[i], 1e-10f)));
 }
 void launch_power_to_db(const float* x, float* y, long n, hipStream_t s) {
     hipLaunchKernelGGL(power_to_db_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, x, y, n);

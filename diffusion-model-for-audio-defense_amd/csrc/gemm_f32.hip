@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
             for (int r = 0; r < 4; ++r) {
                 float t = a.scale ? acc[i][j][r] * sc[r] + sh[r] : acc[i][j][r] + sh[r];
                 if (a.res && m + r < a.M) t += a.res[n * a.ldc + m + r];
-                v[r] = a.relu ? fmaxf(t, 0.f) : t;
+                v[r] = a.relu ? relu_nan(t) : t;
             }
             float* dst = a.C + n * a.ldc + m;
             if (vec && m + 3 < a.M) {
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
             if (n >= a.N) continue;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float t = acc[i][j][r] + ba[r]; v[r] = a.relu ? fmaxf(t, 0.f) : t; }
+            for (int r = 0; r < 4; ++r) { const float t = acc[i][j][r] + ba[r]; v[r] = a.relu ? relu_nan(t) : t; }
             *(float4*)(a.C + n * a.ldc + m) = float4{v[0], v[1], v[2], v[3]};
         }
     }
@@ -427,7 +427,7 @@ __global__ void gemm_f32_reduce_kernel(GemmF32Args a) {
     for (int z = 0; z < a.splits; ++z) s += a.slab[((long)z * a.N + n) * a.ldc + m];
     float t = a.scale ? s * a.scale[m] + (a.shift ? a.shift[m] : 0.f) : s + (a.shift ? a.shift[m] : 0.f);
     if (a.res) t += a.res[n * a.ldc + m];
-    a.C[n * a.ldc + m] = a.relu ? fmaxf(t, 0.f) : t;
+    a.C[n * a.ldc + m] = a.relu ? relu_nan(t) : t;
 }
 
 void launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab_floats, long n_ref) {

@@ -146,7 +146,7 @@ __global__ void unet_p_sample_kernel(const float* __restrict__ x, const float* _
     if (i >= n) return;
     const float xv = x[i];
     float x0 = __fsub_rn(__fmul_rn(ca, xv), __fmul_rn(cb, eps[i]));      // reference op order, no FMA contraction
-    x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    x0 = clamp_nan(x0, -1.f, 1.f);
     float r = __fadd_rn(__fmul_rn(c1, x0), __fmul_rn(c2, xv));
     if (z) r = __fadd_rn(r, __fmul_rn(sig, z[i]));
     out[i] = r;

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) wn_init_h16(const float* __restrict__ x, 
         for (int j = 0; j < 8; ++j) {
             const int c = cg * 8 + j;
             const float v = w[c] * xv + bias[c];
-            o[j] = (T)(fmaxf(v, 0.f) + emb0[c]);
+            o[j] = (T)(relu_nan(v) + emb0[c]);
         }
         *(v8*)((char*)(h + (size_t)bb * LP * kC) + h16_off((unsigned)(kPad + t), (unsigned)cg)) = o;
     }

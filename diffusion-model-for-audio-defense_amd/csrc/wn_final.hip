@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(512, 2) wn_final_p(WnFinalArgs a, long npos, i
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) part[nt] = fmaf(fmaxf(acc[mt][nt][r], 0.f), wz[r], part[nt]);
+                for (int r = 0; r < 4; ++r) part[nt] = fmaf(relu_nan(acc[mt][nt][r]), wz[r], part[nt]);
         }
         WNF_BARRIER_LGKM();                       // everyone is done with the y tile and the weight buffers
         float* red = (float*)smem;                // [4 wm][256 t]

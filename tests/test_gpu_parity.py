@@ -1101,3 +1101,39 @@ def test_config5_spec_domain_vote_loop(golden_dir):
         bare.spec_smooth_votes(clip, sigma, ts, q_a, q_b, c_a, c_b, c_1, c_2, c_sig, -100.0, 38.22, 2)     # no UNet / classifier loaded
     bare.close()
     eng.close()
+
+
+def test_exact_vote_queue_drains_mid_call(weights, sched, monkeypatch):
+    """The recheck queue holds a bounded number of sample indices; a call that votes more samples than fit drains it between
+    batches.  With an 8-entry queue (DMAD_RECHECK_QUEUE, a test knob) and every sample forced through the recheck tiers the
+    counts, logits and stats equal those of the default-sized queue; NaN clips are queued, reach the fp32 path and vote like
+    torch.max does."""
+    from dmad_hip import engine as E
+    hp, coef = sched
+    clip = torch.from_numpy(synth.synthetic_clip(2)).cuda()
+    sc = float(torch.tensor((1 / 1.25) ** 0.5))
+    out = {}
+    for cap in ('8', None):
+        if cap:
+            monkeypatch.setenv('DMAD_RECHECK_QUEUE', cap)
+        else:
+            monkeypatch.delenv('DMAD_RECHECK_QUEUE', raising=False)
+        eng = E.Engine(max_batch=4, precision=E.EXACT, recheck_batch=3, recheck_margin=1e30)     # nothing votes from the 16-bit pass
+        eng.load_wavenet(weights[0])
+        eng.load_vgg19_bn(weights[1])
+        c, lg, _ = eng.smooth_votes(clip, 0.5, sc, 65, *coef(65), 30, batch=4, seed=12, sample0=7, want_logits=True)
+        out[cap] = (c.cpu().tolist(), lg.cpu(), eng.recheck_stats(detail=True))
+        if cap is None:
+            eng.set_mode(E.MODE_FP32)
+            c32, lg32, _ = eng.smooth_votes(clip, 0.5, sc, 65, *coef(65), 30, batch=4, seed=12, sample0=7, want_logits=True)
+            assert c32.cpu().tolist() == out[None][0]
+            eng.set_mode(E.MODE_EXACT_VOTES)
+            eng.recheck_stats(reset=True)
+            bad = clip.clone()
+            bad[0, 100] = float('nan')                      # a NaN clip: NaN logits everywhere
+            cn, lgn, _ = eng.smooth_votes(bad, 0.5, sc, 65, *coef(65), 5, batch=4, seed=1, want_logits=True)
+            assert bool(torch.isnan(lgn).all()) and int(cn.sum()) == 5 and eng.recheck_stats(detail=True) == (5, 5, 5)
+            assert cn.cpu().tolist() == [5, 0, 0, 0, 0, 0, 0, 0, 0, 0]          # first NaN wins, as torch.max picks it
+        eng.close()
+    assert out['8'][0] == out[None][0] and torch.equal(out['8'][1], out[None][1])
+    assert out['8'][2][:2] == out[None][2][:2] == (30, 30) and sum(out[None][0]) == 30
