@@ -145,8 +145,8 @@ struct dmad_engine {
     // fp32 path
     float *wdil = nullptr, *bdil = nullptr, *wrs = nullptr, *brs = nullptr, *wf0 = nullptr;
     float *wdil_x3 = nullptr, *wrs_x3 = nullptr, *wf0_x3 = nullptr;      // the same weights in the split-f16 storage format (x3 tier)
-    float *wskip_x3 = nullptr, *bskip32 = nullptr, *gstore32 = nullptr;  // x3 tier: [NL][256][256] skip weights, sum of the skip biases,
-                                                                         // and the gate outputs of all layers [NL][maxB32 * L][256]
+    float *wskip32 = nullptr, *wskip_x3 = nullptr, *bskip32 = nullptr;   // [NL][256][256] skip weights (fp32 / split-f16), sum of the skip biases
+    float* gstore32 = nullptr;                                           // gate outputs of all layers [NL][maxB32 * L][256] (fp32 and x3 tiers)
     float tau2 = 0.f;                      // recheck bound of the x3 tier (its logit-difference error against the fp32 path)
     long long* rc_list2 = nullptr;         // samples the x3 tier leaves to the fp32 tier
     int64_t st_rechecked2 = 0;
@@ -340,20 +340,22 @@ int finalize_wavenet(dmad_engine* e) {
         }
         CHK(e->upload(&e->wdil, wdil)); CHK(e->upload(&e->bdil, bdil)); CHK(e->upload(&e->wrs, wrs)); CHK(e->upload(&e->brs, brs));
         CHK(e->upload(&e->wf0, f0w));
+        // the NL skip convs run as ONE K = NL * 256 GEMM over the stored gate outputs of all layers (as the 16-bit path does):
+        // no fp32 read-modify-write of the skip sum per layer
+        std::vector<float> ws((size_t)NL * 256 * 256), bs(256, 0.f);
+        for (int n = 0; n < NL; ++n) {
+            memcpy(&ws[(size_t)n * 256 * 256], &wrs[(size_t)n * 512 * 256 + 256 * 256], 256 * 256 * 4);
+            for (int c = 0; c < 256; ++c) bs[c] += brs[(size_t)n * 512 + 256 + c];
+        }
+        CHK(e->upload(&e->wskip32, ws));
+        CHK(e->upload(&e->bskip32, bs));
+        CHK(e->alloc(&e->gstore32, (size_t)NL * e->maxB32 * e->L * 256));      // [NL][maxB32 * L][256], shared by the fp32 and split-f16 tiers
         if (e->bf16) {                      // exact-vote engines: the middle (split-f16, three-MFMA) tier reads these
             std::vector<float> t(wdil.size());
             split_rows(wdil.data(), wdil.size(), t.data()); CHK(e->upload(&e->wdil_x3, t));
             t.resize(wrs.size()); split_rows(wrs.data(), wrs.size(), t.data()); CHK(e->upload(&e->wrs_x3, t));
             t.resize(f0w.size()); split_rows(f0w.data(), f0w.size(), t.data()); CHK(e->upload(&e->wf0_x3, t));
-            // the 36 skip convs as ONE K = NL * 256 GEMM over the stored gate outputs (as the 16-bit path does): no fp32
-            // read-modify-write of the skip sum per layer
-            std::vector<float> ws((size_t)NL * 256 * 256), bs(256, 0.f);
-            for (int n = 0; n < NL; ++n) {
-                memcpy(&ws[(size_t)n * 256 * 256], &wrs[(size_t)n * 512 * 256 + 256 * 256], 256 * 256 * 4);
-                for (int c = 0; c < 256; ++c) bs[c] += brs[(size_t)n * 512 + 256 + c];
-            }
             t.resize(ws.size()); split_rows(ws.data(), ws.size(), t.data()); CHK(e->upload(&e->wskip_x3, t));
-            CHK(e->upload(&e->bskip32, bs));
         }
     }
     return 0;
@@ -813,13 +815,13 @@ int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipS
     } else {
         const long N = (long)B * L;
         launch_wn_init_f32(x_t, e->init_w, e->init_b, e->emb_table, e->hA32, B, L, LP, s, x3);
-        const size_t slab = (size_t)e->maxB32 * L * 256;          // x3: one gate-output slab per layer
+        const size_t slab = (size_t)e->maxB32 * L * 256;          // one gate-output slab per layer
         for (int n = 0; n < NL; ++n) {
             float* hin = (n & 1) ? e->hB32 : e->hA32;
             float* hout = (n & 1) ? e->hA32 : e->hB32;
             const int d = 1 << (n % e->cfg.dilation_cycle);
             const bool last = n == NL - 1;
-            float* gout = x3 ? e->gstore32 + (size_t)n * slab : e->g32;
+            float* gout = e->gstore32 + (size_t)n * slab;
             GemmF32Args g{};
             g.A = (x3 ? e->wdil_x3 : e->wdil) + (size_t)n * 3 * 512 * 256; g.X = hin + (size_t)kPad * kC; g.scale = nullptr;
             g.x3 = x3;
@@ -827,26 +829,19 @@ int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipS
             g.rows_per_batch = L; g.batch_stride = (long)LP * kC; g.row_stride = kC; g.tap_stride = (long)d * kC;
             g.epi = 1; g.C = gout;               // tanh * sigmoid in the epilogue: H never goes to HBM
             launch_gemm_f32(g, s);
-            if (x3) {                            // res conv + residual update only: the skip convs run as one GEMM after the loop
-                if (last) continue;              // the last layer's residual output is never consumed (WaveNet.py:131-135)
-                GemmF32Args u = plain_gemm(e->wrs_x3 + (size_t)n * 512 * 256, gout, nullptr, nullptr, e->brs + (size_t)n * 512, 256, 256, N, 256, 256, 0);
-                u.epi = 2; u.res_rows = 256; u.first = 0; u.L = L; u.LP = LP;
-                u.hin = hin; u.hout = hout; u.skip = nullptr; u.emb_next = e->emb_table + (size_t)(n + 1) * 256;
-                u.x3 = 1;
-                launch_gemm_f32(u, s);
-                continue;
-            }
-            // res || skip convs with the residual update and the skip accumulation in the epilogue (2 launches per layer)
-            GemmF32Args u = plain_gemm(e->wrs + (size_t)n * 512 * 256 + (last ? 256 * 256 : 0), e->g32, nullptr, nullptr,
-                                       e->brs + (size_t)n * 512 + (last ? 256 : 0), last ? 256 : 512, 256, N, 256, 256, 0);
-            u.epi = 2; u.res_rows = last ? 0 : 256; u.first = n == 0; u.L = L; u.LP = LP;
-            u.hin = hin; u.hout = hout; u.skip = e->skip32; u.emb_next = e->emb_table + (size_t)((n + 1 < NL) ? n + 1 : n) * 256;
+            if (last) continue;                  // the last layer's residual output is never consumed (WaveNet.py:131-135)
+            // res conv with the residual update in its epilogue; the skip convs run as one GEMM after the loop
+            GemmF32Args u = plain_gemm((x3 ? e->wrs_x3 : e->wrs) + (size_t)n * 512 * 256, gout, nullptr, nullptr, e->brs + (size_t)n * 512, 256, 256,
+                                       N, 256, 256, 0);
+            u.epi = 2; u.res_rows = 256; u.first = 0; u.L = L; u.LP = LP;
+            u.hin = hin; u.hout = hout; u.skip = nullptr; u.emb_next = e->emb_table + (size_t)(n + 1) * 256;
+            u.x3 = x3;
             launch_gemm_f32(u, s);
         }
-        if (x3) {   // skip = sum_n W_skip_n g_n + sum_n b_skip_n: taps = layers, tap stride = one slab (taps are centred on NL / 2)
+        {   // skip = sum_n W_skip_n g_n + sum_n b_skip_n: taps = layers, tap stride = one slab (taps are centred on NL / 2)
             GemmF32Args k{};
-            k.A = e->wskip_x3; k.X = e->gstore32 + (size_t)(NL >> 1) * slab; k.C = e->skip32; k.scale = nullptr; k.shift = e->bskip32;
-            k.M = 256; k.K = 256; k.taps = NL; k.ldc = 256; k.relu = 0; k.N = N; k.mode = 0; k.x3 = 1;
+            k.A = x3 ? e->wskip_x3 : e->wskip32; k.X = e->gstore32 + (size_t)(NL >> 1) * slab; k.C = e->skip32; k.scale = nullptr;
+            k.shift = e->bskip32; k.M = 256; k.K = 256; k.taps = NL; k.ldc = 256; k.relu = 0; k.N = N; k.mode = 0; k.x3 = x3;
             k.rows_per_batch = N; k.batch_stride = 0; k.row_stride = 256; k.tap_stride = (long)slab;
             launch_gemm_f32(k, s);
         }
@@ -981,7 +976,6 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
             }
             if ((r = e->alloc(&e->rc_list, (size_t)e->rc_cap))) break;
             if ((r = e->alloc(&e->rc_list2, (size_t)e->rc_cap))) break;
-            if ((r = e->alloc(&e->gstore32, NL * B32 * L * 256))) break;
             if ((r = e->alloc(&e->rc_n, 1, true))) break;
             hipError_t he = hipHostMalloc((void**)&e->rc_n_host, sizeof(unsigned long long), hipHostMallocDefault);
             if (he != hipSuccess) { r = fail(DMAD_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(he)); break; }
