@@ -61,6 +61,8 @@ def build_parser():
     # additions
     parser.add_argument('--resume', action='store_true', help='continue after the last record of an existing file')
     parser.add_argument('--noise_source', choices=['device', 'torch_cpu'], default='device')
+    parser.add_argument('--calibrate_margins', type=int, default=1024,
+                        help='exact-vote engine: samples used to measure the recheck bounds for the loaded checkpoints (0 = engine defaults)')
     return parser
 
 
@@ -91,7 +93,7 @@ def run(args, classifier=None, denoiser=None, log=print):
     if args.defense_method == 'randsmooth':
         denoiser = None
     RC = RobustCertificate(classifier=classifier, transform=MelSpectrogramDB(), denoiser=denoiser,
-                           noise_source=args.noise_source)
+                           noise_source=args.noise_source, calibrate=getattr(args, 'calibrate_margins', 0))
 
     records = CertificationRecords(args.save_path, args.sigma, args.num_sampling, resume=args.resume)
     done, seen = len(records), 0

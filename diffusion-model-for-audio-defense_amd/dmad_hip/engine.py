@@ -255,6 +255,42 @@ class Engine:
         check(self.lib.dmad_recheck_stats(self._h, C.byref(a), C.byref(b), C.byref(c), 1 if reset else 0))
         return (int(a.value), int(b.value), int(c.value)) if detail else (int(a.value), int(b.value))
 
+    def calibrate_recheck(self, clip: torch.Tensor, sigma: float, sqrt_abar_star: float, t: int, c_a: float, c_b: float,
+                          n: int = 1024, n_fp32: int = 128, headroom: float = 1.5, seed: int = 0xCA11B):
+        """Measure, for THE RESIDENT WEIGHTS, what the defaults were measured for on the synthetic VGG19_bn (see
+        DEFAULT_RECHECK_MARGIN): the largest error the 16-bit pass makes on a logit difference (against the split-f16 tier, n
+        Philox samples of `clip` at this sigma) and the largest error of the split-f16 tier (against the exact-fp32 path,
+        n_fp32 samples), and set the two recheck bounds to `headroom` x those (the tier-1 bound also covers tier 2's own error,
+        since tier 1 is measured against tier 2).  The logit sensitivity of a classifier — hence the error a given eps error
+        turns into — is a property of its weights: call this once per (WaveNet, classifier, sigma) before certifying with
+        checkpoints other than the ones the defaults were measured on.  Returns (tau1, tau2, e1, e2)."""
+        if self.precision != EXACT:
+            raise DmadError('calibrate_recheck needs an EXACT engine')
+        mode, tau1, tau2 = self.mode, self.recheck_margin, self.recheck_margin2
+        args = (clip, sigma, sqrt_abar_star, t, c_a, c_b)
+
+        def pair_err(a, b):
+            d = (a[:, :, None] - a[:, None, :]) - (b[:, :, None] - b[:, None, :])
+            return float(d.abs().max())
+        try:
+            self.set_mode(MODE_FAST)
+            _, fast, _ = self.smooth_votes(*args, n, seed=seed, want_logits=True)
+            self.set_mode(MODE_EXACT_VOTES)
+            self.set_recheck_margin(1e30); self.set_recheck_margin2(0.0)       # every sample through tier 2, none beyond
+            _, mid, _ = self.smooth_votes(*args, n, seed=seed, want_logits=True)
+            self.set_mode(MODE_FP32)
+            _, ref, _ = self.smooth_votes(*args, n_fp32, seed=seed, want_logits=True)
+        finally:
+            self.set_mode(mode); self.set_recheck_margin(tau1); self.set_recheck_margin2(tau2)
+        self.recheck_stats(reset=True)
+        if not (bool(torch.isfinite(fast).all()) and bool(torch.isfinite(mid).all()) and bool(torch.isfinite(ref).all())):
+            raise DmadError('calibrate_recheck: non-finite logits')
+        e1, e2 = pair_err(fast.double(), mid.double()), pair_err(mid[:n_fp32].double(), ref.double())
+        new2 = max(headroom * e2, 1e-6)
+        new1 = headroom * e1 + new2
+        self.set_recheck_margin(new1); self.set_recheck_margin2(new2)
+        return new1, new2, e1, e2
+
     def wavenet_eps_path(self, x_t: torch.Tensor, t: int, path: int) -> torch.Tensor:
         """eps-network on an explicit path of an EXACT engine: 0 mode default, 1 exact fp32, 2 split-f16 (three MFMAs per product)."""
         x = self._wave(x_t)

@@ -34,7 +34,7 @@ def _dist():
 class RobustCertificate():
 
     def __init__(self, classifier: torch.nn.Module, transform=None, denoiser=None, one_shot_rev: bool = False,
-                 num_classes=10, noise_source: str = 'device', seed: int = None, shard: bool = True) -> None:
+                 num_classes=10, noise_source: str = 'device', seed: int = None, shard: bool = True, calibrate: int = 0) -> None:
         self.classifier = classifier
         self.transform = transform
         self.denoiser = denoiser
@@ -45,6 +45,11 @@ class RobustCertificate():
         self.seed = seed
         self.shard = shard
         self._calls = 0
+        # calibrate = n > 0: before the first fused smooth_predict at each sigma, measure the recheck bounds of the exact-vote
+        # engine for the resident weights on n samples of the clip at hand (Engine.calibrate_recheck) instead of using the
+        # defaults measured on the synthetic VGG19_bn; the certification driver switches it on (real checkpoints)
+        self.calibrate = int(calibrate)
+        self._calibrated = {}
 
     # ------------------------------------------------------------------------------------------
     def _fused(self):
@@ -132,6 +137,11 @@ class RobustCertificate():
                       float(torch.tensor(alpha_bar_star ** 0.5, dtype=torch.float32)))
 
         fused = self._fused()
+        if fused and self.calibrate > 0:
+            eng = self.denoiser.engine
+            if getattr(eng, 'precision', None) == 2 and coeffs[0] not in self._calibrated:      # EXACT engines, once per t*
+                self._calibrated[coeffs[0]] = eng.calibrate_recheck(x, sigma, coeffs[3], coeffs[0], coeffs[1], coeffs[2], n=self.calibrate,
+                                                                    n_fp32=max(16, self.calibrate // 8))
         if self.noise_source == 'torch_cpu':
             # The reference's stream: one CPU torch.normal draw per batch (ref l.47).  The stream is batch-split invariant,
             # so every rank draws the whole stream, keeps its own slice of each batch and feeds it to the engine batch by

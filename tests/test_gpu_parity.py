@@ -1137,3 +1137,31 @@ def test_exact_vote_queue_drains_mid_call(weights, sched, monkeypatch):
         eng.close()
     assert out['8'][0] == out[None][0] and torch.equal(out['8'][1], out[None][1])
     assert out['8'][2][:2] == out[None][2][:2] == (30, 30) and sum(out[None][0]) == 30
+
+
+def test_recheck_bounds_are_calibrated_for_the_resident_weights(exact_engine, sched):
+    """Engine.calibrate_recheck measures the two bounds of the exact-vote mode for the weights that are loaded (the defaults were
+    measured on the synthetic VGG19_bn; a checkpoint with another logit sensitivity needs its own): on the synthetic pair it lands
+    near the committed defaults, it restores mode and statistics, and RobustCertificate(calibrate=n) runs it once per sigma."""
+    from audio_models.ConvNets_SpeechCommands.models.vgg import vgg19_bn  # noqa: F401
+    from diffusion_models.diffwave_ddpm import DiffWave, WaveNetHIP
+    from dmad_hip import engine as E
+    from dmad_hip.transforms import MelSpectrogramDB
+    from robustness_eval.certified_robust import RobustCertificate
+    eng = exact_engine
+    hp, coef = sched
+    clip = torch.from_numpy(synth.synthetic_clip(1)).cuda()
+    sc = float(torch.tensor((1 / 1.25) ** 0.5))
+    old = (eng.recheck_margin, eng.recheck_margin2)
+    t1, t2, e1, e2 = eng.calibrate_recheck(clip, 0.5, sc, 65, *coef(65), n=256, n_fp32=32)
+    assert 0.004 < e1 < 0.04 and 1e-5 < e2 < 1e-3, (e1, e2)              # the defaults' regime: 0.0286 / 3.3e-4 at N = 36 864 / 9 216
+    assert abs(t2 - 1.5 * e2) < 1e-7 and abs(t1 - (1.5 * e1 + t2)) < 1e-6 and eng.recheck_margin == pytest.approx(t1)
+    assert eng.mode == E.MODE_EXACT_VOTES and eng.recheck_stats() == (0, 0)
+    eng.set_recheck_margin(old[0]); eng.set_recheck_margin2(old[1])
+    den = DiffWave(WaveNetHIP(eng), hp)
+    rc = RobustCertificate(classifier=synth_vgg().bind_engine(eng), transform=MelSpectrogramDB(eng), denoiser=den, seed=2, calibrate=64)
+    a = rc.smooth_predict(clip, num_sampling=32, sigma=0.5, batch_size=16)
+    assert int(a.sum()) == 32 and list(rc._calibrated) == [65] and eng.recheck_margin == pytest.approx(rc._calibrated[65][0])
+    rc.smooth_predict(clip, num_sampling=8, sigma=0.5, batch_size=8)
+    assert list(rc._calibrated) == [65]                                     # once per t*
+    eng.set_recheck_margin(old[0]); eng.set_recheck_margin2(old[1])
