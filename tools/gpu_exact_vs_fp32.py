@@ -22,8 +22,13 @@ for sigma in SIGMAS:
     for name, mode in (('exact', E.MODE_EXACT_VOTES), ('fp32', E.MODE_FP32), ('fast', E.MODE_FAST)):
         eng.set_mode(mode); eng.recheck_stats(reset=True)
         torch.cuda.synchronize(); t0 = time.time()
-        c, _, _ = eng.smooth_votes(*args, seed=4242, sample0=0)
-        torch.cuda.synchronize()
+        c, done = None, 0
+        while done < N:                     # chunks: a progress line every ~45 s of fp32 work keeps the run visibly alive
+            k = min(8192, N - done)
+            c, _, _ = eng.smooth_votes(*args[:-1], k, seed=4242, sample0=done, counts=c)
+            done += k
+            torch.cuda.synchronize()
+            print('  %s: %d / %d samples, %.0f s' % (name, done, N, time.time() - t0), flush=True)
         rec[name] = {'counts': c.cpu().tolist(), 'seconds': time.time() - t0, 'stats': eng.recheck_stats(detail=True)}
     rec['exact_equals_fp32'] = rec['exact']['counts'] == rec['fp32']['counts']
     rec['fast_differs_by'] = sum(abs(a - b) for a, b in zip(rec['fast']['counts'], rec['fp32']['counts'])) // 2
