@@ -25,8 +25,9 @@ so the vote counts equal the fp32 path's.  The line also carries
   roofline_final — the tail kernel (wn_final_p, HBM-bound: reads the 295 MB/clip gate store once) against 8 TB/s;
   cpu_baseline   — the CPU oracle (a restatement of the reference's arithmetic, kind "port") timed on the host cores of
                    the same box on a bounded sample (rank 0, N = 1 only);
-  certify_full   — with --full: RobustCertificate.certify(x, n_0=100, n=100000, sigma) through the host mirror (the
-                   surface the reference's driver calls, scripts/certified_robust_eval.sh:3-6), timed end to end.
+  certify_full   — RobustCertificate.certify(x, n_0=100, n, sigma) through the host mirror (the surface the reference's
+                   driver calls, scripts/certified_robust_eval.sh:3-6), timed end to end: n = 8192 in the default run (N = 1),
+                   n = 100000 with --full.
 """
 import argparse
 import json
@@ -133,8 +134,10 @@ def main():
     ap.add_argument('--side-steps', type=int, default=None, help='steps of the two side measurements (fast / exact, fp32); 0 = skip')
     ap.add_argument('--cpu-samples', type=int, default=6)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--full', action='store_true', help='also time certify(n_0=100, n=100000) through the host mirror (about 80 s)')
-    ap.add_argument('--full-n', type=int, default=100000)
+    ap.add_argument('--full', action='store_true', help='time the full certify(n_0=100, n=100000) through the host mirror (about 70 s) '
+                                                        'instead of the short n=8192 one the default run carries')
+    ap.add_argument('--full-n', type=int, default=None, help='n of the certify() run through the host mirror (default 8192; --full: 100000)')
+    ap.add_argument('--no-certify', action='store_true', help='skip the certify() run through the host mirror')
     ap.add_argument('--classifier', choices=['vgg19_bn', 'resnext29'], default='vgg19_bn',
                     help='vgg19_bn = the configuration BASELINE.json names; resnext29 = the reference script\'s default classifier')
     args = ap.parse_args()
@@ -267,7 +270,9 @@ def main():
                 side[mode]["frac_of_fp32_matrix_peak"] = side[mode]["tflops"] / PEAK_FP32_TFLOPS
 
     full = None
-    if args.full and args.classifier == 'vgg19_bn':
+    if args.full_n is None:
+        args.full_n = 100000 if args.full else 8192
+    if not args.no_certify and args.classifier == 'vgg19_bn' and (world == 1 or args.full):
         # the surface the reference's driver calls: RobustCertificate.certify through the host mirror, n_0 pass included
         from audio_models.ConvNets_SpeechCommands.models.vgg import vgg19_bn
         from diffusion_models.diffwave_ddpm import DiffWave, WaveNetHIP
@@ -281,7 +286,7 @@ def main():
         rc = RobustCertificate(classifier=clf, transform=MelSpectrogramDB(eng), denoiser=den, seed=2024)
         assert rc._fused()
         x = clip.reshape(1, 1, L)
-        rc.certify(x, torch.tensor([0], device='cuda'), sigma=sigma, n_0=100, n=1024, batch_size=args.max_batch)   # warm-up
+        rc.certify(x, torch.tensor([0], device='cuda'), sigma=sigma, n_0=100, n=min(1024, args.full_n), batch_size=args.max_batch)   # warm-up
         eng.recheck_stats(reset=True)
         fence()
         t0 = time.perf_counter()

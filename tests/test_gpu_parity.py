@@ -783,7 +783,7 @@ def test_bench_contract():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--samples-per-step', '8',
-                        '--max-batch', '8', '--cpu-samples', '2'], capture_output=True, text=True, timeout=600, cwd=root)
+                        '--max-batch', '8', '--cpu-samples', '2', '--full-n', '64'], capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -803,6 +803,8 @@ def test_bench_contract():
     assert 'exact-vote' in j['config']['mode'] and 0.0 <= j['recheck']['frac_fp32'] <= j['recheck']['frac'] <= 1.0 and j['recheck']['margin'] > 0
     assert j['fast_mode']['clips_per_s'] > 0 and j['fp32_mode']['clips_per_s'] > 0 and 0 < j['fp32_mode']['frac_of_fp32_matrix_peak'] < 1
     assert sum(j['fast_mode']['votes']) == 8 * j['fast_mode']['steps'] and sum(j['fp32_mode']['votes']) == 8 * j['fp32_mode']['steps']
+    cf = j['certify_full']                 # RobustCertificate.certify through the host mirror, timed end to end
+    assert cf['n_0'] == 100 and cf['n'] == 64 and cf['clips_per_s'] > 0 and cf['y_pred'] in range(-1, 10) and cf['radius'] >= 0
     ff = j['roofline_final']
     assert ff['bound'] == 'hbm' and ff['unit'] == 'GB/s' and ff['peak'] == 8000.0 and ff['launches_timed'] == 1 and 0 < ff['frac'] < 1.5
     # a rank count the box cannot serve is refused loudly, never run as fewer ranks
