@@ -20,9 +20,6 @@ void launch_lincomb(int op, const float* x, const float* y, const float* z, floa
                     hipStream_t s);
 void launch_wn_init_f32(const float* x, const float* w, const float* bias, const float* emb0, float* h, int B, int L, int LP,
                         hipStream_t s, bool split = false);
-void launch_wn_gate_f32(const float* H, float* g, long N, hipStream_t s);
-void launch_wn_update_f32(const float* RS, const float* hin, float* hout, float* skip, const float* emb_next, int first,
-                          int last, int B, int L, int LP, hipStream_t s);
 void launch_scale(const float* x, float c, float* y, long n, hipStream_t s, bool split = false);
 void launch_dot256(const float* f, const float* w, float bias, float* out, long N, hipStream_t s);
 void launch_mel_pad(const float* x, float* xp, int B, int L, int LPm, hipStream_t s);

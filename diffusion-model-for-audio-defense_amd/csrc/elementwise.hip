@@ -216,49 +216,6 @@ __global__ void wn_init_f32_kernel(const float* __restrict__ x, const float* __r
     else *(float4*)(h + ((bb * LP + kPad + t) * kC + c4 * 4)) = o;
 }
 
-// g = tanh(H[:, :256]) * sigmoid(H[:, 256:])   (WaveNet.py:89), H is [N][512]
-__global__ void wn_gate_f32_kernel(const float* __restrict__ H, float* __restrict__ g, long total4) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total4) return;
-    const long n = idx >> 6;
-    const int c4 = (int)(idx & 63);
-    const float4 a = *(const float4*)(H + n * 512 + c4 * 4);
-    const float4 b = *(const float4*)(H + n * 512 + 256 + c4 * 4);
-    float4 o;
-    o.x = tanhf(a.x) * (1.f / (1.f + expf(-b.x))); o.y = tanhf(a.y) * (1.f / (1.f + expf(-b.y)));
-    o.z = tanhf(a.z) * (1.f / (1.f + expf(-b.z))); o.w = tanhf(a.w) * (1.f / (1.f + expf(-b.w)));
-    *(float4*)(g + n * 256 + c4 * 4) = o;
-}
-
-// h' = (h + RS[:, :256]) * sqrt(.5) + emb_next ; skip (+)= RS[:, 256:]     (WaveNet.py:97,131-133)
-__global__ void wn_update_f32_kernel(const float* __restrict__ RS, const float* __restrict__ hin, float* __restrict__ hout,
-                                     float* __restrict__ skip, const float* __restrict__ emb_next, int first, int last,
-                                     int L, int LP, long total4) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total4) return;
-    const long n = idx >> 6, bb = n / L, t = n - bb * L;
-    const int c4 = (int)(idx & 63);
-    const float4 s = *(const float4*)(RS + n * 512 + 256 + c4 * 4);
-    float4* ps = (float4*)(skip + n * 256 + c4 * 4);
-    if (first) {
-        *ps = s;
-    } else {
-        float4 o = *ps;
-        o.x = __fadd_rn(o.x, s.x); o.y = __fadd_rn(o.y, s.y); o.z = __fadd_rn(o.z, s.z); o.w = __fadd_rn(o.w, s.w);
-        *ps = o;
-    }
-    if (last) return;
-    const long hoff = (bb * LP + kPad + t) * kC + c4 * 4;
-    const float4 r = *(const float4*)(RS + n * 512 + c4 * 4);
-    const float4 h = *(const float4*)(hin + hoff);
-    const float4 e = *(const float4*)(emb_next + c4 * 4);
-    const float k = 0.70710678118654752440f;
-    float4 o;
-    o.x = __fadd_rn(__fmul_rn(__fadd_rn(h.x, r.x), k), e.x); o.y = __fadd_rn(__fmul_rn(__fadd_rn(h.y, r.y), k), e.y);
-    o.z = __fadd_rn(__fmul_rn(__fadd_rn(h.z, r.z), k), e.z); o.w = __fadd_rn(__fmul_rn(__fadd_rn(h.w, r.w), k), e.w);
-    *(float4*)(hout + hoff) = o;
-}
-
 template <bool SPLIT>
 __global__ void scale_kernel(const float* __restrict__ x, float c, float* __restrict__ y, long n4) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -461,15 +418,6 @@ void launch_wn_init_f32(const float* x, const float* w, const float* bias, const
     const long total = (long)B * L * 64;
     if (split) hipLaunchKernelGGL(wn_init_f32_kernel<true>, dim3(nblk(total, 256)), dim3(256), 0, s, x, w, bias, emb0, h, L, LP, total);
     else hipLaunchKernelGGL(wn_init_f32_kernel<false>, dim3(nblk(total, 256)), dim3(256), 0, s, x, w, bias, emb0, h, L, LP, total);
-}
-void launch_wn_gate_f32(const float* H, float* g, long N, hipStream_t s) {
-    hipLaunchKernelGGL(wn_gate_f32_kernel, dim3(nblk(N * 64, 256)), dim3(256), 0, s, H, g, N * 64);
-}
-void launch_wn_update_f32(const float* RS, const float* hin, float* hout, float* skip, const float* emb_next, int first,
-                          int last, int B, int L, int LP, hipStream_t s) {
-    const long total = (long)B * L * 64;
-    hipLaunchKernelGGL(wn_update_f32_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, RS, hin, hout, skip, emb_next, first, last,
-                       L, LP, total);
 }
 void launch_scale(const float* x, float c, float* y, long n, hipStream_t s, bool split) {
     if (split) hipLaunchKernelGGL(scale_kernel<true>, dim3(nblk(n / 4, 256)), dim3(256), 0, s, x, c, y, n / 4);
