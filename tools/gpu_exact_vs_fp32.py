@@ -13,12 +13,13 @@ eng = E.Engine(max_batch=256, precision=E.EXACT, recheck_batch=64)
 eng.load_wavenet(synth.wavenet_state_dict(1234))
 eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321))
 ab = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)['Alpha_bar']
-clip = torch.from_numpy(synth.synthetic_clip(0)).cuda()
+CLIP = int(os.environ.get('CLIP', 0))
+clip = torch.from_numpy(synth.synthetic_clip(CLIP)).cuda()
 out = []
 for sigma in SIGMAS:
     t = int(torch.abs(ab - 1 / (1 + sigma ** 2)).min(0, keepdim=True)[1].item())
     args = (clip, sigma, float(torch.tensor((1 / (1 + sigma ** 2)) ** 0.5, dtype=torch.float32)), t, float((1 / ab).sqrt()[t]), float((1 / ab - 1).sqrt()[t]), N)
-    rec = {'sigma': sigma, 't_star': t + 1, 'n': N}
+    rec = {'clip': CLIP, 'sigma': sigma, 't_star': t + 1, 'n': N}
     for name, mode in (('exact', E.MODE_EXACT_VOTES), ('fp32', E.MODE_FP32), ('fast', E.MODE_FAST)):
         eng.set_mode(mode); eng.recheck_stats(reset=True)
         torch.cuda.synchronize(); t0 = time.time()
@@ -34,5 +35,5 @@ for sigma in SIGMAS:
     rec['fast_differs_by'] = sum(abs(a - b) for a, b in zip(rec['fast']['counts'], rec['fp32']['counts'])) // 2
     print(json.dumps(rec), flush=True)
     out.append(rec)
-    json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'exact_vs_fp32.json'), 'w'), indent=1)
+    json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'exact_vs_fp32_clip%d.json' % CLIP), 'w'), indent=1)
 assert all(r['exact_equals_fp32'] for r in out)
