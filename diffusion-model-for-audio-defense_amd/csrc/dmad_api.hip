@@ -974,6 +974,7 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
                 const long v = atol(q);
                 if (v >= 1 && v < e->rc_cap) e->rc_cap = v;
             }
+            if (e->rc_cap < (long)e->maxB) e->rc_cap = e->maxB;    // one batch always fits: the drain condition needs no more
             if ((r = e->alloc(&e->rc_list, (size_t)e->rc_cap))) break;
             if ((r = e->alloc(&e->rc_list2, (size_t)e->rc_cap))) break;
             if ((r = e->alloc(&e->rc_n, 1, true))) break;
