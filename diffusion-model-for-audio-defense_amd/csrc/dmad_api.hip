@@ -178,7 +178,7 @@ struct dmad_engine {
         float *gn1w = nullptr, *gn1b = nullptr, *w1 = nullptr, *b1 = nullptr;       // res: in_layers; attn: norm, qkv; down/up/conv_in: conv
         float *embw = nullptr, *embb = nullptr, *gn2w = nullptr, *gn2b = nullptr, *w2 = nullptr, *b2 = nullptr;   // res: emb, out_layers; attn: proj_out
         float *skw = nullptr, *skb = nullptr;                                       // res: 1x1 skip_connection
-        float* ss = nullptr;               // res: this step's (scale, shift) row [2 * cout]
+        size_t ss_off = 0;                 // res: offset of its (scale, shift) row [2 * cout] inside a step's row of un_ss_table
     };
     std::vector<std::vector<UnOp>> un_in, un_out;
     std::vector<UnOp> un_mid;
@@ -186,6 +186,14 @@ struct dmad_engine {
     std::vector<float*> un_hs;
     bool un_final = false;
     int un_t = -1;
+    // Every ResBlock's emb_layers output depends on the step t alone (unet.py:186-199), and a sampler walks the same few steps for
+    // every batch: row t of un_ss_table caches all of them (kUnSsSteps = diffusion_steps rows of un_ss_total floats, ~54 MB, plus
+    // one scratch row for steps beyond the schedule), filled the first time a step is seen — 24 small launches, ~1 ms, per step
+    // instead of per network evaluation.
+    size_t un_ss_total = 0;
+    float* un_ss_table = nullptr;
+    const float* un_ss_cur = nullptr;
+    std::vector<char> un_ss_have;
     float *un_te0w = nullptr, *un_te0b = nullptr, *un_te2w = nullptr, *un_te2b = nullptr, *un_outgw = nullptr, *un_outgb = nullptr;
     float *un_outw = nullptr, *un_outb = nullptr, *un_temb = nullptr, *un_emb1 = nullptr, *un_emb = nullptr, *un_semb = nullptr;
     float* un_buf[8] = {nullptr};          // work maps: 3 rotating block outputs, T1, T2, skip, qkv / cat, attention
@@ -547,6 +555,7 @@ int classify_resnext(dmad_engine* e, const float* spec, int B, float* logits, hi
 // state-dict names.  Every conv / linear is a gemm_f32 launch over NHWC maps.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kUnMC = 128, kUnTE = 512, kUnHeads = 4, kUnRes = 3;
+constexpr int kUnSsSteps = 1000;         // cached steps (create_improved_diffusion: diffusion_steps = 1000)
 const int kUnMult[4] = {1, 2, 2, 2};
 inline bool un_attn_at(int ds) { return ds == 2 || ds == 4; }
 
@@ -581,7 +590,8 @@ int un_load_op(dmad_engine* e, const std::string& p, dmad_engine::UnOp& o) {
         CHK(un_dense(e, p + ".out_layers.0", o.cout, 1, &o.gn2w, &o.gn2b));
         CHK(un_conv3(e, p + ".out_layers.3", o.cout, o.cout, &o.w2, &o.b2));
         if (o.cin != o.cout) CHK(un_dense(e, p + ".skip_connection", o.cout, o.cin, &o.skw, &o.skb));
-        CHK(e->alloc(&o.ss, (size_t)2 * o.cout));
+        o.ss_off = e->un_ss_total;
+        e->un_ss_total += (size_t)2 * o.cout;
     } else if (o.kind == 2) {
         CHK(un_dense(e, p + ".norm", o.cin, 1, &o.gn1w, &o.gn1b));
         CHK(un_dense(e, p + ".qkv", 3 * o.cin, o.cin, &o.w1, &o.b1));
@@ -645,6 +655,9 @@ int finalize_unet(dmad_engine* e) {
     }
     for (int i = 0; i < 8; ++i) CHK(e->alloc(&e->un_buf[i], B * 1024 * 384));     // largest map: 32x32 x (256 + 128) concat
     CHK(e->alloc(&e->un_eps, B * 1024));
+    CHK(e->alloc(&e->un_ss_table, (size_t)(kUnSsSteps + 1) * e->un_ss_total));
+    e->un_ss_have.assign(kUnSsSteps, 0);
+    e->un_t = -1;
     CHK(e->alloc(&e->un_temb, kUnMC)); CHK(e->alloc(&e->un_emb1, kUnTE)); CHK(e->alloc(&e->un_emb, kUnTE)); CHK(e->alloc(&e->un_semb, kUnTE));
     return 0;
 }
@@ -652,6 +665,11 @@ int finalize_unet(dmad_engine* e) {
 // emb = time_embed(timestep_embedding(t)) (unet.py:466, nn.py:103-121), SiLU(emb), and every ResBlock's (scale, shift) row
 int unet_prepare_step(dmad_engine* e, int t, hipStream_t s) {
     if (e->un_t == t) return 0;
+    const int slot = t < kUnSsSteps ? t : kUnSsSteps;
+    float* row = e->un_ss_table + (size_t)slot * e->un_ss_total;
+    e->un_ss_cur = row;
+    e->un_t = t;
+    if (slot < kUnSsSteps && e->un_ss_have[slot]) return 0;
     float te[kUnMC];
     const float a = (float)(-log(10000.0));
     for (int i = 0; i < kUnMC / 2; ++i) {
@@ -668,12 +686,12 @@ int unet_prepare_step(dmad_engine* e, int t, hipStream_t s) {
     launch_silu(e->un_emb, e->un_semb, kUnTE, s);
     auto each = [&](dmad_engine::UnOp& o) {
         if (o.kind == 1)
-            launch_gemm_f32(plain_gemm(o.embw, e->un_semb, o.ss, nullptr, o.embb, 2 * o.cout, kUnTE, 1, 2 * o.cout, kUnTE, 0), s);
+            launch_gemm_f32(plain_gemm(o.embw, e->un_semb, row + o.ss_off, nullptr, o.embb, 2 * o.cout, kUnTE, 1, 2 * o.cout, kUnTE, 0), s);
     };
     for (auto& b : e->un_in) for (auto& o : b) each(o);
     for (auto& o : e->un_mid) each(o);
     for (auto& b : e->un_out) for (auto& o : b) each(o);
-    e->un_t = t;
+    if (slot < kUnSsSteps) e->un_ss_have[slot] = 1;
     return 0;
 }
 
@@ -686,28 +704,36 @@ GemmF32Args un_conv_args(const float* A, const float* bias, const float* X, floa
     return g;
 }
 
+const float* gn_fail(int HW, int C) { fail(DMAD_ERR_STATE, "GroupNorm: no kernel for a %d-pixel x %d-channel map", HW, C); return nullptr; }
+
 // applies one module; `in` [B][H*H][cin] -> returns the buffer holding [B][Ho*Ho][cout].  `dst`: where the result must
 // land (a saved-skip buffer) or nullptr (take a rotating work buffer).
-const float* unet_apply(dmad_engine* e, const dmad_engine::UnOp& o, const float* in, int B, int& H, float* dst, int& rot, hipStream_t s) {
+// `in2` != nullptr (ResBlocks of the output path only): the module's input is th.cat([in, in2], dim=1) (unet.py:473), `in` holding
+// c1 channels and `in2` the rest — GroupNorm and the 1x1 skip conv read the two parts in place, nothing is concatenated.
+const float* unet_apply(dmad_engine* e, const dmad_engine::UnOp& o, const float* in, int B, int& H, float* dst, int& rot, hipStream_t s,
+                        const float* in2 = nullptr, int c1 = 0) {
     float *T1 = e->un_buf[3], *T2 = e->un_buf[4], *SK = e->un_buf[5], *QKV = e->un_buf[6], *ATT = e->un_buf[7];
     auto next = [&]() { float* p = e->un_buf[rot]; rot = (rot + 1) % 3; if (p == in) { p = e->un_buf[rot]; rot = (rot + 1) % 3; } return p; };
     float* out = dst ? dst : next();
     const long nref = (long)e->maxB * H * H;
     if (o.kind == 1) {                      // ResBlock._forward, unet.py:186-199
-        launch_groupnorm_nhwc(in, o.gn1w, o.gn1b, nullptr, 1, T1, B, H * H, o.cin, s);
+        if (in2 && o.cin == o.cout) { fail(DMAD_ERR_STATE, "a concatenated input needs the ResBlock's skip conv"); return nullptr; }
+        if (launch_groupnorm_nhwc(in, o.gn1w, o.gn1b, nullptr, 1, T1, B, H * H, o.cin, s, in2, c1)) return gn_fail(H * H, o.cin);
         launch_gemm_f32(un_conv_args(o.w1, o.b1, T1, T2, o.cout, o.cin, 9, B, H, 1, nullptr), s, e->slab, e->slab_floats, nref);
-        launch_groupnorm_nhwc(T2, o.gn2w, o.gn2b, o.ss, 1, T1, B, H * H, o.cout, s);
+        if (launch_groupnorm_nhwc(T2, o.gn2w, o.gn2b, e->un_ss_cur + o.ss_off, 1, T1, B, H * H, o.cout, s)) return gn_fail(H * H, o.cout);
         const float* skip = in;
         if (o.cin != o.cout) {
-            launch_gemm_f32(un_conv_args(o.skw, o.skb, in, SK, o.cout, o.cin, 1, B, H, 1, nullptr), s, e->slab, e->slab_floats, nref);
+            GemmF32Args g = un_conv_args(o.skw, o.skb, in, SK, o.cout, o.cin, 1, B, H, 1, nullptr);
+            if (in2) { g.ldx = c1; g.X2 = in2; g.ksplit = c1; g.ldx2 = o.cin - c1; }
+            launch_gemm_f32(g, s, e->slab, e->slab_floats, nref);
             skip = SK;
         }
         launch_gemm_f32(un_conv_args(o.w2, o.b2, T1, out, o.cout, o.cout, 9, B, H, 1, skip), s, e->slab, e->slab_floats, nref);
     } else if (o.kind == 2) {               // AttentionBlock._forward + QKVAttention, unet.py:225-258
         const int C = o.cin, T = H * H;
-        launch_groupnorm_nhwc(in, o.gn1w, o.gn1b, nullptr, 0, T1, B, T, C, s);
+        if (launch_groupnorm_nhwc(in, o.gn1w, o.gn1b, nullptr, 0, T1, B, T, C, s)) return gn_fail(T, C);
         launch_gemm_f32(plain_gemm(o.w1, T1, QKV, nullptr, o.b1, 3 * C, C, (long)B * T, 3 * C, C, 0), s, e->slab, e->slab_floats, nref);
-        launch_qkv_attention(QKV, ATT, B, T, kUnHeads, s);
+        if (int rc = launch_qkv_attention(QKV, ATT, B, T, kUnHeads, s)) { fail(rc > 0 ? DMAD_ERR_HIP : DMAD_ERR_STATE, "UNet attention (T = %d): %s", T, rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported map size"); return nullptr; }
         GemmF32Args g = plain_gemm(o.w2, ATT, out, nullptr, o.b2, C, C, (long)B * T, C, C, 0);
         g.res = in;
         launch_gemm_f32(g, s, e->slab, e->slab_floats, nref);
@@ -734,20 +760,21 @@ int unet_eps(dmad_engine* e, const float* x, int t, int B, float* eps, hipStream
     const float* h = x;
     for (size_t i = 0; i < e->un_in.size(); ++i)
         for (size_t j = 0; j < e->un_in[i].size(); ++j)
-            h = unet_apply(e, e->un_in[i][j], h, B, H, j + 1 == e->un_in[i].size() ? e->un_hs[i] : nullptr, rot, s);
-    for (auto& o : e->un_mid) h = unet_apply(e, o, h, B, H, nullptr, rot, s);
+            if (!(h = unet_apply(e, e->un_in[i][j], h, B, H, j + 1 == e->un_in[i].size() ? e->un_hs[i] : nullptr, rot, s))) return DMAD_ERR_STATE;
+    for (auto& o : e->un_mid) if (!(h = unet_apply(e, o, h, B, H, nullptr, rot, s))) return DMAD_ERR_STATE;
     size_t top = e->un_hs.size();
     for (auto& blk : e->un_out) {
         --top;
-        const int c1 = blk[0].cin - e->un_hs_ch[top], c2 = e->un_hs_ch[top];
-        float* cat = e->un_buf[6];          // the qkv map is dead between modules
-        launch_copy_channels(h, c1, cat, c1 + c2, c1, (long)B * H * H, s);
-        launch_copy_channels(e->un_hs[top], c2, cat + c1, c1 + c2, c2, (long)B * H * H, s);
-        h = cat;
-        for (auto& o : blk) h = unet_apply(e, o, h, B, H, nullptr, rot, s);
+        const int c1 = blk[0].cin - e->un_hs_ch[top];          // th.cat([h, hs.pop()], dim=1): h carries c1 channels, the saved map the rest
+        const float* hs = e->un_hs[top];
+        for (size_t j = 0; j < blk.size(); ++j) {
+            h = j == 0 ? unet_apply(e, blk[0], h, B, H, nullptr, rot, s, hs, c1) : unet_apply(e, blk[j], h, B, H, nullptr, rot, s);
+            if (!h) return DMAD_ERR_STATE;
+        }
     }
-    launch_groupnorm_nhwc(h, e->un_outgw, e->un_outgb, nullptr, 1, e->un_buf[3], B, 1024, kUnMC, s);
-    launch_gemm_f32(un_conv_args(e->un_outw, e->un_outb, e->un_buf[3], eps, 1, kUnMC, 9, B, 32, 1, nullptr), s);
+    if (launch_groupnorm_nhwc(h, e->un_outgw, e->un_outgb, nullptr, 1, e->un_buf[3], B, 1024, kUnMC, s)) { gn_fail(1024, kUnMC); return DMAD_ERR_STATE; }
+    static_assert(kUnMC == 128, "launch_conv3x3_c128_to1 is the 128-channel output layer");
+    launch_conv3x3_c128_to1(e->un_buf[3], e->un_outw, e->un_outb, eps, B, s);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -20,6 +20,9 @@ struct GemmF32Args {
     int stride;           // mode 2: spatial stride (0/1 = 1, 2 = output (H-1)/2+1 x (W-1)/2+1); taps == 1 is a 1x1 conv
     int groups;           // > 1: grouped conv, one group per grid.z; M, K and the A image are per group, X / C / scale /
                           //      shift / res advance by K resp. M per group (ldx / ldc = all groups); excludes split-K
+    const float* X2;      // mode 2, optional: channels [ksplit, K) of every pixel come from X2 (pixel pitch ldx2) instead of X — the
+    int ksplit, ldx2;     //   channel concatenation th.cat([h, skip], dim=1) of the UNet (unet.py:473) without materialising it;
+                          //   ksplit % 16 == 0, X then holds ksplit channels per pixel (ldx = its pitch)
     const float* res;     // optional residual [N][ldc] added before the ReLU (ResNeXt bottleneck sum)
     // Fused epilogues of the exact-fp32 WaveNet layer (Residual_block.forward, WaveNet.py:86-97); M = 512, no split-K:
     //   epi 1  gate: the rows of A / shift are permuted so that every wave holds a gate channel's tanh row (accumulator

@@ -37,7 +37,8 @@ __device__ __attribute__((aligned(64))) float g_zero_page[16];                 /
     } while (0)
 }  // namespace
 
-template <int BM>
+template <int BM, bool TWO>               // TWO: the input channels come from two maps (GemmF32Args::X2); an instantiation of its own
+                                          // because the extra test in the staging loop costs the common kernel 2 %
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
     constexpr int MT = BM / 32;            // 16-row accumulator tiles per wave along M (2 M-waves)
     __shared__ __attribute__((aligned(16))) char smem[3 * SLOT];
@@ -102,8 +103,10 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
             if (xok[p]) {
                 if (a.mode == 2) {
                     const int yy = xy[p] + (a.taps == 9 ? tap / 3 - 1 : 0), xq = xx[p] + (a.taps == 9 ? tap % 3 - 1 : 0);
-                    if ((unsigned)yy < (unsigned)a.H && (unsigned)xq < (unsigned)a.W)
-                        src = a.X + (xbase[p] + (long)yy * a.W + xq) * ldx + kc + chunk4;
+                    if ((unsigned)yy < (unsigned)a.H && (unsigned)xq < (unsigned)a.W) {
+                        const long pix = xbase[p] + (long)yy * a.W + xq;
+                        src = (TWO && kc >= a.ksplit) ? a.X2 + pix * a.ldx2 + (kc - a.ksplit) + chunk4 : a.X + pix * ldx + kc + chunk4;
+                    }
                 } else {
                     src = a.X + xbase[p] + (long)(tap - (a.taps >> 1)) * a.tap_stride + kc + chunk4;
                 }
@@ -444,13 +447,15 @@ void launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long sla
         hipLaunchKernelGGL(gemm_x3_kernel, dim3((unsigned)((a.N + BN - 1) / BN), (unsigned)(a.M / X3_BM)), dim3(512), X3_LDS, s, a);
         return;
     }
+    if (a.X2 && (a.mode != 2 || a.groups > 1 || a.M <= 64 || (a.ksplit % BK) || a.ksplit <= 0 || a.ksplit >= a.K)) abort();   // two-part input: plain NHWC convs only
     const int BM = a.M <= 64 ? 64 : 128;          // 64-row tiles where a 128-row tile would be half empty
     const unsigned gx = (unsigned)((a.N + BN - 1) / BN), gy = (unsigned)((a.M + BM - 1) / BM);
     const int nks = a.taps * (a.K / BK);
     int S = 1;
     auto launch = [&](dim3 grid) {
-        if (BM == 64) hipLaunchKernelGGL(gemm_f32_kernel<64>, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(gemm_f32_kernel<128>, grid, dim3(256), 0, s, a);
+        if (a.X2) hipLaunchKernelGGL((gemm_f32_kernel<128, true>), grid, dim3(256), 0, s, a);
+        else if (BM == 64) hipLaunchKernelGGL((gemm_f32_kernel<64, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_f32_kernel<128, false>), grid, dim3(256), 0, s, a);
     };
     if (a.groups > 1) {
         a.splits = 1;

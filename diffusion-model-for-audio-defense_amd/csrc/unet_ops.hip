@@ -24,52 +24,104 @@ __global__ void conv1ch_3x3_kernel(const float* __restrict__ in, const float* __
     out[i] = s + bias[co];
 }
 
-__device__ __forceinline__ float block_sum(float v, float* red) {   // 256 threads
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    const int wv = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[wv] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
+// conv 3x3, 128 channels -> ONE output channel, padding 1, on 32x32 maps (the network's last layer, unet.py:421): a
+// 1152-term dot product per pixel, far too thin for a matrix tile (the 64-row GEMM tile spends 63/64 of its MFMAs on padding).
+// One lane per pixel; the weights are wave-uniform (scalar loads), each lane streams the 512-byte rows of its 9 neighbours.
+__global__ void __launch_bounds__(256) conv3x3_c128_to1_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ out, long total) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const int y = (int)((p >> 5) & 31), x = (int)(p & 31);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if ((unsigned)yy >= 32u || (unsigned)xx >= 32u) continue;
+        const float4* row = (const float4*)(in + (((p >> 10) << 10) + yy * 32 + xx) * 128);
+        const float4* wr = (const float4*)(w + tap * 128);
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) {
+            const float4 v = row[c], k = wr[c];
+            acc[0] = fmaf(v.x, k.x, acc[0]); acc[1] = fmaf(v.y, k.y, acc[1]); acc[2] = fmaf(v.z, k.z, acc[2]); acc[3] = fmaf(v.w, k.w, acc[3]);
+        }
+    }
+    out[p] = (acc[0] + acc[1]) + (acc[2] + acc[3]) + bias[0];
 }
 
-// one workgroup per (group, sample): the group's C/32 channels x HW pixels (at most 12288 floats in this network) are read
-// once into LDS as float4 (C/32 is a multiple of 4), then mean, biased variance of the deviations, and the affine /
-// scale-shift / SiLU pass run from LDS
-constexpr int GN_MAX = 12288;
-__global__ void __launch_bounds__(256) groupnorm_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, const float* __restrict__ ss, int silu,
-                                                             float* __restrict__ y, int HW, int C) {
-    __shared__ float red[4];
-    __shared__ __attribute__((aligned(16))) float buf[GN_MAX];
-    const int g = blockIdx.x, cg = C >> 5, c4 = cg >> 2, n4 = c4 * HW, n = cg * HW;
-    const long base = (long)blockIdx.y * HW * C + g * cg;
+// GroupNorm32(32, C) over an NHWC map.  One workgroup per (sample, G neighbouring groups), G chosen so that the G groups'
+// slice of a pixel is whole 128-byte lines (C/32 = 4, 8, 12 or 16 channels per group -> G = 8, 4, 8 or 4, 2): every load and
+// store of a wave is then full cache lines (a single group's slice is only 16..64 bytes of its line).  The slab — HW pixels x
+// R = G * C/128 float4s — stays in REGISTERS: thread t owns float4s t, t + NT, ... (PER of them) and, because NT is a
+// multiple of R, all of them belong to the same group and the same 4 channels.  All loads are in flight at once; then the
+// mean, the biased variance of the deviations (two-pass, like torch) and the affine / scale-shift / SiLU pass run without
+// touching memory again.  Group sums: per-thread partials to LDS, wave w adds the partials of group w in a fixed order
+// (deterministic: no atomics), everybody reads the G results.
+template <int PER>
+__global__ void __launch_bounds__(1024) groupnorm_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ ss, int silu,
+                                                              float* __restrict__ y, int HW, int C, int G,
+                                                              const float* __restrict__ x2, int c1) {
+    __shared__ float part[1024];
+    __shared__ float gsum[8];
+    const int NT = blockDim.x, t = threadIdx.x, lane = t & 63, wv = t >> 6, nwaves = NT >> 6;
+    const int c4 = C >> 7, R = G * c4, upb = 32 / G;          // upb: workgroups per sample
+    const int b = blockIdx.x / upb, g0 = (blockIdx.x % upb) * G;
+    const int j = t % R, grp = j / c4, c = (g0 + grp) * (C >> 5) + (j % c4) * 4;
+    const long base = (long)b * HW * C + c;                                  // + pixel * C   (c = g0 * C/32 + 4 j)
+    // input: one map of C channels, or the concatenation [x (c1 channels) | x2 (C - c1 channels)] read in place
+    const bool second = x2 && c >= c1;
+    const int pitch = x2 ? (second ? C - c1 : c1) : C;
+    const float* src = second ? x2 + (long)b * HW * pitch + (c - c1) : x + (long)b * HW * pitch + c;
+    const int p0 = t / R, pstep = NT / R;
+    const float n = (float)((C >> 5) * HW);
+    auto group_sum = [&](float v) -> float {
+        __syncthreads();
+        part[t] = v;
+        __syncthreads();
+        const int members = c4 * pstep;
+        for (int w = wv; w < G; w += nwaves) {
+            float a = 0.f;
+            for (int i = lane; i < members; i += 64) a += part[(i / c4) * R + w * c4 + (i % c4)];
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            if (lane == 0) gsum[w] = a;
+        }
+        __syncthreads();
+        return gsum[grp];
+    };
+    float4 v[PER];
     float s = 0.f;
-    for (int i = threadIdx.x; i < n4; i += 256) {
-        const float4 v = *(const float4*)(x + base + (long)(i / c4) * C + (i % c4) * 4);
-        ((float4*)buf)[i] = v;
-        s += (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int pix = p0 + k * pstep;
+        v[k] = pix < HW ? *(const float4*)(src + (long)pix * pitch) : float4{0.f, 0.f, 0.f, 0.f};
     }
-    const float mean = block_sum(s, red) / (float)n;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    const float mean = group_sum(s) / n;
     float q = 0.f;
-    for (int i = threadIdx.x; i < n4; i += 256) {
-        const float4 v = ((const float4*)buf)[i];
-        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    }
-    const float rstd = 1.0f / sqrtf(block_sum(q, red) / (float)n + 1e-5f);
-    for (int i = threadIdx.x; i < n4; i += 256) {
-        const int c = g * cg + (i % c4) * 4;
-        const float4 v = ((const float4*)buf)[i];
-        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (p0 + k * pstep < HW) {
+            const float d0 = v[k].x - mean, d1 = v[k].y - mean, d2 = v[k].z - mean, d3 = v[k].w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    const float rstd = 1.0f / sqrtf(group_sum(q) / n + 1e-5f);
+    const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
+    float4 s1 = float4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    if (ss) { s1 = *(const float4*)(ss + c); s2 = *(const float4*)(ss + C + c); }
+    const float gaa[4] = {ga.x, ga.y, ga.z, ga.w}, bea[4] = {be.x, be.y, be.z, be.w}, s1a[4] = {s1.x, s1.y, s1.z, s1.w}, s2a[4] = {s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int pix = p0 + k * pstep;
+        if (pix >= HW) continue;
+        float o[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float t = (o[r] - mean) * rstd * gamma[c + r] + beta[c + r];
-            if (ss) t = t * (1.f + ss[c + r]) + ss[C + c + r];
-            if (silu) t = t / (1.f + expf(-t));
-            o[r] = t;
+            float u = (o[r] - mean) * rstd * gaa[r] + bea[r];
+            if (ss) u = u * (1.f + s1a[r]) + s2a[r];
+            if (silu) u = u / (1.f + expf(-u));
+            o[r] = u;
         }
-        *(float4*)(y + base + (long)(i / c4) * C + (i % c4) * 4) = float4{o[0], o[1], o[2], o[3]};
+        *(float4*)(y + base + (long)pix * C) = float4{o[0], o[1], o[2], o[3]};
     }
 }
 
@@ -89,54 +141,79 @@ __global__ void upsample2x_nhwc_kernel(const float* __restrict__ in, float* __re
     ((float4*)out)[i] = ((const float4*)in)[((b * H + (yo >> 1)) * W + (xo >> 1)) * C4 + c];
 }
 
-__global__ void copy_channels_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst, int C4, long total4) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total4) return;
-    const long r = i / C4;
-    const int c = (int)(i - r * C4);
-    *(float4*)(dst + r * ld_dst + c * 4) = *(const float4*)(src + r * ld_src + c * 4);
-}
-
-// one thread per query; keys / values of one (sample, head) stream through LDS in chunks of 64 with an online softmax
-constexpr int HD = 64, KCH = 64;
-__global__ void __launch_bounds__(256) qkv_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int heads) {
-    __shared__ float Ks[KCH][HD];
-    __shared__ float Vs[KCH][HD];
-    const int h = blockIdx.x, b = blockIdx.y, t = blockIdx.z * blockDim.x + threadIdx.x;
+// QKVAttention on the fp32 matrix cores, transposed so that no fragment ever changes layout:
+//   S^T = K Q^T   (A = key rows, B = query rows, contraction over the 64 head channels)
+//   O^T = V^T P^T (A = V read column-wise from LDS, B = the softmax weights exactly where the first product left them)
+// A 16x16 tile of S^T leaves lane (c, g) (c = lane & 15, g = lane >> 4) with keys 4g + r (r = 0..3) of query c: query = lane
+// column, so the softmax over keys is a reduction over this lane's registers and the 4 lanes sharing c (two xor-shuffles),
+// and register r of that tile is at once the B operand of the second product for the k-slot assignment
+// "MFMA j contracts keys {4g + j}".  One workgroup per (head, sample): K and V of the head in LDS (rows of 68 floats: the
+// ds_read_b128 of a key row and the ds_read_b32 of a V column are both conflict free), each wave owns query tiles of 16,
+// holds the whole S^T column block (T / 16 tiles) in registers and does the exact two-pass softmax torch does.
+constexpr int HD = 64, AROW = 68;
+template <int KT>                                       // T = 16 * KT keys / queries
+__global__ void __launch_bounds__(KT >= 8 ? 512 : 64 * KT) qkv_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int heads) {
+    extern __shared__ __attribute__((aligned(16))) float att_lds[];
+    constexpr int T = 16 * KT, NW = KT >= 8 ? 8 : KT;
+    float* Ks = att_lds;
+    float* Vs = att_lds + T * AROW;
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C3 = 3 * HD * heads;
     const float* base = qkv + (long)b * T * C3 + h * 3 * HD;
-    float q[HD], acc[HD];
-    const bool live = t < T;
-#pragma unroll
-    for (int c = 0; c < HD; ++c) { q[c] = live ? base[(long)t * C3 + c] * 0.125f : 0.f; acc[c] = 0.f; }   // (q*s).(k*s), s^2 = 1/8
-    float m = -INFINITY, l = 0.f;
-    for (int k0 = 0; k0 < T; k0 += KCH) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < KCH * HD; i += blockDim.x) {
-            const int r = i / HD, c = i % HD;
-            const bool ok = k0 + r < T;
-            Ks[r][c] = ok ? base[(long)(k0 + r) * C3 + HD + c] : 0.f;
-            Vs[r][c] = ok ? base[(long)(k0 + r) * C3 + 2 * HD + c] : 0.f;
-        }
-        __syncthreads();
-        const int kn = (T - k0) < KCH ? (T - k0) : KCH;
-        for (int r = 0; r < kn; ++r) {
-            float d = 0.f;
-#pragma unroll
-            for (int c = 0; c < HD; ++c) d = fmaf(q[c], Ks[r][c], d);
-            const float mn = fmaxf(m, d);
-            const float corr = expf(m - mn), p = expf(d - mn);
-            l = l * corr + p;
-#pragma unroll
-            for (int c = 0; c < HD; ++c) acc[c] = fmaf(p, Vs[r][c], acc[c] * corr);
-            m = mn;
-        }
+    for (int i = tid; i < T * 16; i += NW * 64) {
+        const int r = i >> 4, c4 = (i & 15) * 4;
+        *(float4*)(Ks + r * AROW + c4) = *(const float4*)(base + (long)r * C3 + HD + c4);
+        *(float4*)(Vs + r * AROW + c4) = *(const float4*)(base + (long)r * C3 + 2 * HD + c4);
     }
-    if (live) {
-        const float inv = 1.f / l;
-        float* o = out + ((long)b * T + t) * (HD * heads) + h * HD;
+    __syncthreads();
+    for (int qt = wv; qt < KT; qt += NW) {
+        f32x4 qf[4];                                    // query row c of the tile, channels 16 cc + 4 g + j, times scale^2 = 1/8
 #pragma unroll
-        for (int c = 0; c < HD; ++c) o[c] = acc[c] * inv;
+        for (int cc = 0; cc < 4; ++cc) {
+            const float4 v = *(const float4*)(base + (long)(qt * 16 + c) * C3 + cc * 16 + g * 4);
+            qf[cc] = f32x4{v.x * 0.125f, v.y * 0.125f, v.z * 0.125f, v.w * 0.125f};
+        }
+        f32x4 sacc[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) sacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const f32x4 kf = *(const f32x4*)(Ks + (kt * 16 + c) * AROW + cc * 16 + g * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j], qf[cc][j], sacc[kt], 0, 0, 0);
+                if (kt & 1) __builtin_amdgcn_sched_barrier(0);           // keep the fragment reads next to their MFMAs (register budget)
+            }
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) m = fmaxf(fmaxf(fmaxf(sacc[kt][0], sacc[kt][1]), fmaxf(sacc[kt][2], sacc[kt][3])), m);
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float p = expf(sacc[kt][r] - m); sacc[kt][r] = p; l += p; }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        f32x4 oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* vrow = Vs + (kt * 16 + g * 4 + j) * AROW + c;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[dt * 16], sacc[kt][j], oacc[dt], 0, 0, 0);
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        const float inv = 1.f / l;
+        float* o = out + ((long)b * T + qt * 16 + c) * (HD * heads) + h * HD + g * 4;       // O^T tile dt: channels dt * 16 + 4 g + r of query c
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *(float4*)(o + dt * 16) = float4{oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv};
     }
 }
 
@@ -180,10 +257,35 @@ void launch_conv1ch_3x3(const float* in, const float* w, const float* bias, floa
     const long total = (long)B * 1024 * Cout;
     hipLaunchKernelGGL(conv1ch_3x3_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, in, w, bias, out, Cout, total);
 }
-void launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* ss, int silu, float* y, int B, int HW,
-                           int C, hipStream_t s) {
-    // C is a multiple of 128 and (C / 32) * HW <= GN_MAX for every map of this network (checked by the caller's shapes)
-    hipLaunchKernelGGL(groupnorm_nhwc_kernel, dim3(32, (unsigned)B), dim3(256), 0, s, x, gamma, beta, ss, silu, y, HW, C);
+void launch_conv3x3_c128_to1(const float* in, const float* w, const float* bias, float* out, int B, hipStream_t s) {
+    const long total = (long)B * 1024;
+    hipLaunchKernelGGL(conv3x3_c128_to1_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, in, w, bias, out, total);
+}
+int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* ss, int silu, float* y, int B, int HW,
+                          int C, hipStream_t s, const float* x2, int c1) {
+    const int c4 = C >> 7;
+    if (C % 128 || c4 < 1 || c4 > 4 || B < 1 || HW < 1) return -1;
+    if (x2 && (c1 < 4 || c1 >= C || (c1 & 3))) return -1;       // 32 groups of 4, 8, 12 or 16 channels
+    // groups per workgroup: whole 128-byte lines per pixel; the largest map (32x32, 12 channels per group) takes 4 groups
+    // (192 bytes) to keep the slab at 16 float4s per thread
+    const int G = c4 == 1 ? 8 : c4 == 2 ? 4 : c4 == 3 ? (HW > 256 ? 4 : 8) : 2;
+    const int R = G * c4;
+    const long n4 = (long)HW * R;
+    int NT = R * (1024 / R);                        // largest multiple of R (8, 12 or 24) and of 64 not above 1024: 1024 or 768
+    if (R == 12 || R == 24) NT = 768;
+    int per = (int)((n4 + NT - 1) / NT);
+    const int want = HW >= 1024 ? 8 : HW >= 256 ? 4 : 2;          // float4s per thread: small maps are latency bound and want more threads
+    while (per < want && NT > 64 && (NT / 2) % R == 0 && (NT / 2) % 64 == 0) { NT /= 2; per = (int)((n4 + NT - 1) / NT); }
+    const dim3 grid((unsigned)(B * (32 / G)));
+#define GN_LAUNCH(PER) hipLaunchKernelGGL(groupnorm_nhwc_kernel<PER>, grid, dim3(NT), 0, s, x, gamma, beta, ss, silu, y, HW, C, G, x2, c1)
+    if (per <= 1) GN_LAUNCH(1);
+    else if (per <= 2) GN_LAUNCH(2);
+    else if (per <= 4) GN_LAUNCH(4);
+    else if (per <= 8) GN_LAUNCH(8);
+    else if (per <= 16) GN_LAUNCH(16);
+    else return -1;                                 // larger than any map of this network (32x32 x 384 channels)
+#undef GN_LAUNCH
+    return 0;
 }
 void launch_silu(const float* x, float* y, long n, hipStream_t s) {
     hipLaunchKernelGGL(silu_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, x, y, n);
@@ -192,14 +294,20 @@ void launch_upsample2x_nhwc(const float* in, float* out, int B, int H, int W, in
     const long total4 = (long)B * 4 * H * W * (C / 4);
     hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3(nblk(total4, 256)), dim3(256), 0, s, in, out, H, W, C / 4, total4);
 }
-void launch_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, int C, long rows, hipStream_t s) {
-    const long total4 = rows * (C / 4);
-    hipLaunchKernelGGL(copy_channels_kernel, dim3(nblk(total4, 256)), dim3(256), 0, s, src, ld_src, dst, ld_dst, C / 4, total4);
-}
-void launch_qkv_attention(const float* qkv, float* out, int B, int T, int heads, hipStream_t s) {
-    const int threads = T >= 256 ? 256 : (T >= 64 ? 64 * ((T + 63) / 64) : 64);
-    hipLaunchKernelGGL(qkv_attention_kernel, dim3((unsigned)heads, (unsigned)B, (unsigned)((T + threads - 1) / threads)), dim3(threads), 0, s,
-                       qkv, out, T, heads);
+int launch_qkv_attention(const float* qkv, float* out, int B, int T, int heads, hipStream_t s) {
+    const size_t lds = (size_t)2 * T * AROW * sizeof(float);
+    if (T == 256) {
+        static const hipError_t once = hipFuncSetAttribute((const void*)qkv_attention_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (once != hipSuccess) return (int)once;
+        hipLaunchKernelGGL(qkv_attention_kernel<16>, dim3((unsigned)heads, (unsigned)B), dim3(512), lds, s, qkv, out, heads);
+    } else if (T == 64) {
+        hipLaunchKernelGGL(qkv_attention_kernel<4>, dim3((unsigned)heads, (unsigned)B), dim3(256), lds, s, qkv, out, heads);
+    } else if (T == 16) {
+        hipLaunchKernelGGL(qkv_attention_kernel<1>, dim3((unsigned)heads, (unsigned)B), dim3(64), lds, s, qkv, out, heads);
+    } else {
+        return -1;                  // this network attends at 16x16, 8x8 (script_util.py attention_resolutions "16,8") and 4x4 (middle block)
+    }
+    return 0;
 }
 void launch_unet_p_sample(const float* x, const float* eps, const float* z, float ca, float cb, float c1, float c2, float sig,
                           float* out, float* x0_out, long n, hipStream_t s) {

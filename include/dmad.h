@@ -7,7 +7,10 @@
  * in, device pointers out, an explicit hipStream_t, no hidden allocation on the data path after
  * dmad_create() / dmad_finalize_weights() (the two diagnostic hooks at the end create HIP events), no torch types.  Every function returns 0 on success or a negative dmad_status; dmad_last_error()
  * gives the message (thread-local).  One engine per process per GPU; calls on one engine must come
- * from one thread at a time.
+ * from one thread at a time, and work given to one engine is ordered by the stream it is given on: an
+ * engine owns ONE set of work buffers and per-step tables (activations, step embeddings, the recheck
+ * queue), so two streams must not have calls on the same engine in flight together — switch streams
+ * only after synchronising the previous one, or create one engine per stream.
  */
 #ifndef DMAD_H
 #define DMAD_H

@@ -35,8 +35,7 @@ def launches():
     ops(mid)
     for b in outp:
         ops(b)
-    out.append(('out conv 128->1', 2.0 * B * 1024 * 128 * 9))
-    return out
+    return out              # the 128 -> 1 output conv is a direct kernel (conv3x3_c128_to1), not a gemm_f32 launch
 
 
 if len(sys.argv) > 2 and sys.argv[1] == '--analyse':
@@ -54,10 +53,22 @@ if len(sys.argv) > 2 and sys.argv[1] == '--analyse':
         print('%-52s %9.1f us  %6.1f TFLOP/s' % (name, us, tf))
     print('total gemm %.1f us over %d launches; flops %.2f T -> %.1f TFLOP/s' % (tot, len(L), sum(f for _, f in L) / 1e12, sum(f for _, f in L) / tot / 1e6))
 else:
+    import time
     import torch
+    from dmad_hip import _lib
+    if os.environ.get('DMAD_LIB'):               # A/B of two builds on one box: DMAD_LIB=/path/to/other/libdmad_hip.so
+        _lib.LIB_PATH = os.environ['DMAD_LIB']
     from dmad_hip import engine as E, synth
     eng = E.Engine(max_batch=B, precision=E.BF16, with_classifier=False)
     eng.load_unet(synth.unet_state_dict(5252))
     x = torch.randn(B, 32, 32, device='cuda') * 0.5
     eng.unet_eps(x, 40); torch.cuda.synchronize()
     eng.unet_eps(x, 40); torch.cuda.synchronize()
+    if len(sys.argv) > 1 and sys.argv[1] == '--time':          # wall time of REPS evaluations (alternating steps, as in the sampler)
+        reps = int(os.environ.get('REPS', 20))
+        t0 = time.time()
+        for i in range(reps):
+            eng.unet_eps(x, 40 - (i & 1))
+        torch.cuda.synchronize()
+        ms = (time.time() - t0) / reps * 1e3
+        print('%s: %.3f ms per evaluation of %d spectrograms -> %.1f TFLOP/s fp32' % (os.environ.get('DMAD_LIB', 'in-tree build'), ms, B, sum(f for _, f in launches()) / ms / 1e9), flush=True)
