@@ -47,6 +47,7 @@ L = 16000
 LAYER_FLOP_PER_CLIP = 2.0 * L * (512 * 768 + 256 * 256)       # dilated conv + res conv of one layer
 FINAL_BYTES_PER_CLIP = 36 * 256 * 2.0 * L + 4.0 * L            # gate store read once + eps written
 CLIP_FLOP = 606.94e9
+UNET_FLOP_PER_SPEC = 16.76e9                                    # one Improved-Diffusion UNet evaluation of a 32x32 spectrogram (convs, linears, attention)
 
 
 def layer_traffic_per_clip():
@@ -138,6 +139,8 @@ def main():
                                                         'instead of the short n=8192 one the default run carries')
     ap.add_argument('--full-n', type=int, default=None, help='n of the certify() run through the host mirror (default 8192; --full: 100000)')
     ap.add_argument('--no-certify', action='store_true', help='skip the certify() run through the host mirror')
+    ap.add_argument('--c5-n', type=int, default=1024, help='Monte Carlo samples of the BASELINE C5 side measurement (spec-domain vote loop, '
+                                                           'Improved-Diffusion UNet purifier, t* = 25); 0 = skip; single-GPU runs only')
     ap.add_argument('--classifier', choices=['vgg19_bn', 'resnext29'], default='vgg19_bn',
                     help='vgg19_bn = the configuration BASELINE.json names; resnext29 = the reference script\'s default classifier')
     args = ap.parse_args()
@@ -298,6 +301,29 @@ def main():
                 "y_pred": int(y_pred[0]), "radius": float(radius[0]), "recheck_frac": rechecked / max(voted, 1),
                 "vs_steady_state": ((100 + args.full_n) / fdt) / (clips / dt)}
 
+    c5 = None
+    if args.c5_n > 0 and world == 1 and args.classifier == 'vgg19_bn':
+        # BASELINE configuration C5 beside the headline: the same vote loop with the spec-domain purifier (dmad_spec_smooth_votes:
+        # mel-dB -> standardise -> q_sample(t*) -> 26 UNet evaluations -> classifier), exact fp32 throughout, its own small engine
+        from diffusion_models.improved_diffusion_ddpm import create_improved_diffusion
+        c5_b, c5_t = 128, 25
+        eng5 = E.Engine(max_batch=c5_b, precision=E.FP32, recheck_batch=0)
+        eng5.load_vgg19_bn(csd)
+        pur = create_improved_diffusion(None, reverse_timestep=c5_t, state_dict=synth.unet_state_dict(31), engine=eng5)
+        c5_args = (clip, sigma) + tuple(pur.purify_coefficients()) + (-100.0, 38.22)
+        eng5.spec_smooth_votes(*c5_args, 2 * c5_b, seed=1)                   # warm-up: fills the per-step tables of all 26 steps
+        fence()
+        t0 = time.perf_counter()
+        c5_counts, _, _ = eng5.spec_smooth_votes(*c5_args, args.c5_n, seed=2024)
+        fence()
+        c5_dt = time.perf_counter() - t0
+        unet_tf = args.c5_n * (c5_t + 1) * UNET_FLOP_PER_SPEC / c5_dt / 1e12
+        c5 = {"workload": "BASELINE C5: certified smoothing sigma=%.2f, spec-domain purifier (Improved-Diffusion UNet, t*=%d: %d network "
+                          "evaluations per sample) + VGG19_bn" % (sigma, c5_t, c5_t + 1),
+              "samples_per_s": args.c5_n / c5_dt, "n": args.c5_n, "seconds": c5_dt, "engine_batch": c5_b, "dtype": "f32",
+              "votes": c5_counts.cpu().tolist(), "unet_tflops": unet_tf, "frac_of_fp32_matrix_peak": unet_tf / PEAK_FP32_TFLOPS}
+        eng5.close()
+
     if rank == 0:
         out = {
             "metric": "purified+classified 1s clips/sec at N=100k sigma=0.5; 1/2/4/8 GPUs",
@@ -348,6 +374,8 @@ def main():
             out[mode + "_mode"] = rec
         if full is not None:
             out["certify_full"] = full
+        if c5 is not None:
+            out["c5_spec_mode"] = c5
         if world == 1 and not args.no_cpu_baseline and args.classifier == 'vgg19_bn':
             out["cpu_baseline"] = cpu_baseline(args.cpu_samples)
         print(json.dumps(out), flush=True)

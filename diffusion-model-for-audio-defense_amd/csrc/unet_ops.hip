@@ -6,22 +6,30 @@ namespace dmad {
 namespace {
 inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1) / b); }
 
-__global__ void conv1ch_3x3_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
-                                   float* __restrict__ out, int Cout, long total) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one (b, y, x, co) each
-    if (i >= total) return;
-    const int co = (int)(i % Cout);
-    const long p = i / Cout, b = p >> 10;
-    const int y = (int)((p >> 5) & 31), x = (int)(p & 31);
-    float s = 0.f;
+// one workgroup per image row, one thread per output channel: its 9 weights live in registers, the 3 x 34 input values the
+// row needs are wave-uniform (scalar loads), every store instruction writes whole 256-byte channel rows
+__global__ void __launch_bounds__(128) conv1ch_3x3_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int Cout) {
+    const int co = threadIdx.x, y = blockIdx.x & 31;
+    const long b = blockIdx.x >> 5;
+    if (co >= Cout) return;
+    float k[9];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int t = 0; t < 9; ++t) k[t] = w[co * 9 + t];
+    const float bv = bias[co];
+    const float* img = in + (b << 10);
+    float* o = out + ((b << 10) + y * 32) * Cout + co;
+    for (int x = 0; x < 32; ++x) {
+        float s = 0.f;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int yy = y + ky - 1, xx = x + kx - 1;
-            if ((unsigned)yy < 32u && (unsigned)xx < 32u) s = fmaf(w[co * 9 + ky * 3 + kx], in[(b << 10) + yy * 32 + xx], s);
-        }
-    out[i] = s + bias[co];
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yy = y + ky - 1, xx = x + kx - 1;
+                if ((unsigned)yy < 32u && (unsigned)xx < 32u) s = fmaf(k[ky * 3 + kx], img[yy * 32 + xx], s);
+            }
+        o[(long)x * Cout] = s + bv;
+    }
 }
 
 // conv 3x3, 128 channels -> ONE output channel, padding 1, on 32x32 maps (the network's last layer, unet.py:421): a
@@ -254,8 +262,8 @@ void launch_spec_unstandardize(const float* x, float lo, float hi, float* spec, 
 }
 
 void launch_conv1ch_3x3(const float* in, const float* w, const float* bias, float* out, int B, int Cout, hipStream_t s) {
-    const long total = (long)B * 1024 * Cout;
-    hipLaunchKernelGGL(conv1ch_3x3_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, in, w, bias, out, Cout, total);
+    if (Cout > 128) abort();                       // one thread per output channel (this network: 128)
+    hipLaunchKernelGGL(conv1ch_3x3_kernel, dim3((unsigned)B * 32u), dim3(128), 0, s, in, w, bias, out, Cout);
 }
 void launch_conv3x3_c128_to1(const float* in, const float* w, const float* bias, float* out, int B, hipStream_t s) {
     const long total = (long)B * 1024;

@@ -783,7 +783,7 @@ def test_bench_contract():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--samples-per-step', '8',
-                        '--max-batch', '8', '--cpu-samples', '2', '--full-n', '64'], capture_output=True, text=True, timeout=600, cwd=root)
+                        '--max-batch', '8', '--cpu-samples', '2', '--full-n', '64', '--c5-n', '16'], capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -807,6 +807,8 @@ def test_bench_contract():
     assert cf['n_0'] == 100 and cf['n'] == 64 and cf['clips_per_s'] > 0 and cf['y_pred'] in range(-1, 10) and cf['radius'] >= 0
     ff = j['roofline_final']
     assert ff['bound'] == 'hbm' and ff['unit'] == 'GB/s' and ff['peak'] == 8000.0 and ff['launches_timed'] == 1 and 0 < ff['frac'] < 1.5
+    c5 = j['c5_spec_mode']                 # BASELINE C5 beside the headline: the spec-domain vote loop on its own fp32 engine
+    assert c5['n'] == 16 and sum(c5['votes']) == 16 and c5['samples_per_s'] > 0 and c5['dtype'] == 'f32' and 0 < c5['frac_of_fp32_matrix_peak'] < 1
     # a rank count the box cannot serve is refused loudly, never run as fewer ranks
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(torch.cuda.device_count() + 1), '--steps', '1'],
