@@ -112,6 +112,12 @@ def test_error_behaviour(engines):
     with pytest.raises(DmadError):
         E.Engine(wavenet_config=dict(res_channels=128), max_batch=2)    # only the 256-channel WaveNet is built
     bare.close()
+    # an empty Monte Carlo loop is legal and votes nothing (certified_robust.py:59-65 with num = 0); a negative count is refused
+    clip = torch.from_numpy(synth.synthetic_clip(0)).cuda()
+    counts, _, _ = eng.smooth_votes(clip, 0.5, 0.9, 10, 1.0, 0.5, 0)
+    assert counts.tolist() == [0] * 10
+    with pytest.raises(DmadError):
+        eng.smooth_votes(clip, 0.5, 0.9, 10, 1.0, 0.5, -1)
 
 
 # ------------------------------------------------------------------------------------------ noise

@@ -53,7 +53,7 @@ def main():
     ap.add_argument('--fetch'); ap.add_argument('--write'); ap.add_argument('--mfma')
     ap.add_argument('--bench-line')
     ap.add_argument('--clips-per-launch', type=int, default=128)
-    ap.add_argument('--command', default='python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline')
+    ap.add_argument('--command', default='python3 bench.py --no-cpu-baseline --side-steps 0 --c5-n 0 --no-certify --steps 5 --warmup 1')
     a = ap.parse_args()
     prof = os.path.join(ROOT, 'profiles')
     os.makedirs(prof, exist_ok=True)
