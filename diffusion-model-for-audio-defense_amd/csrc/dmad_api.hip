@@ -970,7 +970,7 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     if (e->maxB32 > cfg->max_batch) e->maxB32 = cfg->max_batch;
     e->mode = cfg->precision == DMAD_EXACT ? DMAD_MODE_EXACT_VOTES : (cfg->precision == DMAD_FP32 ? DMAD_MODE_FP32 : DMAD_MODE_FAST);
     e->tau = cfg->half_type == DMAD_HALF_F16 ? 0.04f : 0.30f;   // measured logit-difference error of the 16-bit path x 1.4 (see dmad.h)
-    e->tau2 = 2e-3f;                        // the same for the split-f16 tier (dmad_set_recheck_margin2)
+    e->tau2 = 1e-3f;                        // the same for the split-f16 tier (dmad_set_recheck_margin2)
     if (e->bf16 && !wn_final_p_supported(cfg->num_res_layers)) {
         delete e;
         return fail(DMAD_ERR_INVALID, "bf16 path does not support num_res_layers = %d", cfg->num_res_layers);

@@ -26,7 +26,7 @@ HALF_BF16, HALF_F16 = 0, 1                        # enum dmad_half_type: operand
 DEFAULT_RECHECK_MARGIN = {1: 0.04, 0: 0.30}           # by dmad_half_type: HALF_F16, HALF_BF16
 # The queued samples first go through the split-f16 tier (fp32 pipeline, three f16 MFMAs per product, ~22 significant bits);
 # only those whose margin is inside ITS error bound reach the exact-fp32 path.
-DEFAULT_RECHECK_MARGIN2 = 2e-3
+DEFAULT_RECHECK_MARGIN2 = 1e-3
 VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
 
 

@@ -178,7 +178,7 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
  * The queued samples pass through two tiers.  Tier 2 is the fp32 pipeline on SPLIT-f16 operands: every fp32 value is kept
  * as hi = f16(x), lo = f16((x - hi) * 2^11) and every product is three f16 MFMAs (hi*hi + (hi*lo + lo*hi) * 2^-11, fp32
  * accumulate) — about 22 significant bits at several times the fp32 matrix rate.  It settles every queued sample whose
- * margin exceeds ITS error bound tau2 (dmad_set_recheck_margin2; default 2e-3, tau2 < 0 switches the tier off); the rest
+ * margin exceeds ITS error bound tau2 (dmad_set_recheck_margin2; default 1e-3, tau2 < 0 switches the tier off); the rest
  * (margins inside tau2) are evaluated on the exact-fp32 path, tier 3.  dmad_recheck_stats: samples voted, samples that
  * left the 16-bit pass, samples that reached the fp32 path.  dmad_wavenet_eps_path evaluates the eps-network on an
  * explicit path (0: the mode's default, 1: exact fp32, 2: split-f16) — test / measurement hook for the tiers. */

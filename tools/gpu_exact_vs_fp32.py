@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Evidence: the exact-vote mode's per-class counts against the exact-fp32 path's on the same Philox keys, at an N the fp32 path
-can still run (N = 16 384 per sigma by default).  Writes gpurun_out/exact_vs_fp32.json."""
+can still run (N = 16 384 per sigma by default).  Writes gpurun_out/exact_vs_fp32_clipC.json.
+REF=profiles/earlier_record.json: take the fp32 (and 16-bit) counts of the same (clip, sigma, n) from an earlier record of this tool
+instead of running those paths again (the fp32 path is the slow one: 546 s at N = 100 000) — for re-validating a new build or bound."""
 import json, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,12 +17,19 @@ eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321))
 ab = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)['Alpha_bar']
 CLIP = int(os.environ.get('CLIP', 0))
 clip = torch.from_numpy(synth.synthetic_clip(CLIP)).cuda()
+REF = json.load(open(os.environ['REF'])) if os.environ.get('REF') else None
 out = []
 for sigma in SIGMAS:
     t = int(torch.abs(ab - 1 / (1 + sigma ** 2)).min(0, keepdim=True)[1].item())
     args = (clip, sigma, float(torch.tensor((1 / (1 + sigma ** 2)) ** 0.5, dtype=torch.float32)), t, float((1 / ab).sqrt()[t]), float((1 / ab - 1).sqrt()[t]), N)
-    rec = {'clip': CLIP, 'sigma': sigma, 't_star': t + 1, 'n': N}
-    for name, mode in (('exact', E.MODE_EXACT_VOTES), ('fp32', E.MODE_FP32), ('fast', E.MODE_FAST)):
+    rec = {'clip': CLIP, 'sigma': sigma, 't_star': t + 1, 'n': N, 'margins': [eng.recheck_margin, eng.recheck_margin2]}
+    ref = next((r for r in (REF or []) if r.get('clip', 0) == CLIP and r['sigma'] == sigma and r['n'] == N), None)
+    if REF is not None and ref is None:
+        raise SystemExit('no record for clip %d sigma %g n %d in %s' % (CLIP, sigma, N, os.environ['REF']))
+    if ref is not None:
+        rec['fp32'], rec['fast'] = ref['fp32'], ref['fast']
+        rec['fp32_and_fast_counts_from'] = os.environ['REF']
+    for name, mode in (('exact', E.MODE_EXACT_VOTES),) + ((('fp32', E.MODE_FP32), ('fast', E.MODE_FAST)) if ref is None else ()):
         eng.set_mode(mode); eng.recheck_stats(reset=True)
         torch.cuda.synchronize(); t0 = time.time()
         c, done = None, 0
