@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Development probe for the GPU box: runs each stage of the HIP path against the golden fixtures /
-the oracle and prints error statistics (keeps going after a failing stage).  Not part of the product."""
+the oracle and prints error statistics (keeps going after a failing stage).  Test infrastructure (it imports the oracle, which
+only tests/, smoke() and bench.py's cpu_baseline may do): `python tests/gpu_probe.py [stage ...]`; not collected by pytest."""
 import os
 import sys
 import time
