@@ -10,7 +10,9 @@ tests/golden/ that were produced by importing the reference itself in the build 
 (tests/golden/make_golden.py, committed).  Exception — the mel front-end: the reference calls
 torchaudio==0.11.0 (requirements.txt:13; certified_robustness_eval.py:85-87) which is neither vendored
 nor installed, and the reference has no test for it, so `mel_db` is a restatement of torchaudio's
-documented algorithm and its parity is UNPINNED (pinned only by float64 numpy.fft known-answer tests).
+documented algorithm and its parity is UNPINNED (no reference-produced vector exists).  What anchors it instead: float64 numpy.fft
+known-answer tests, and a cross-check against an independent implementation of the same published algorithm
+(transformers.audio_utils: filterbank equal to 3.5e-17, the whole dB chain to 2.5e-6 dB; tests/test_oracle_vs_golden.py).
 
 Each function cites the reference file:line (relative to the reference repo root) that it follows.
 """

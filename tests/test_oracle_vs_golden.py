@@ -157,6 +157,29 @@ def test_mel_frontend_known_answers():
     assert abs(fb.sum(0)[0] - fb.sum(0)[5]) < 1e-9 * 0 + 1  # slaney area norm sanity (finite)
 
 
+def test_mel_frontend_vs_independent_implementation():
+    """a8 has no reference-produced vector (torchaudio 0.11 is absent), so the restatement is cross-checked against an INDEPENDENT
+    implementation of the same published algorithm: transformers.audio_utils (mel_filter_bank documents itself as matching
+    torchaudio's melscale_fbanks / librosa for norm='slaney', mel_scale='slaney'; spectrogram = framed, windowed, centred,
+    zero-padded one-sided power STFT -> mel -> 10 log10 with a 1e-10 floor, in float64).  This is not the reference's own output:
+    the row stays 'parity unpinned' in the strict sense; it rules out an error of the restatement itself."""
+    au = pytest.importorskip('transformers.audio_utils')
+    fb_t = au.mel_filter_bank(num_frequency_bins=1025, num_mel_filters=32, min_frequency=0.0, max_frequency=8000.0, sampling_rate=16000,
+                              norm='slaney', mel_scale='slaney')
+    assert np.abs(orc.mel_filterbank(1025, 0.0, 8000.0, 32, 16000) - fb_t).max() < 1e-12          # measured 3.5e-17
+    win = au.window_function(2048, 'hann', periodic=True)
+    rng = np.random.RandomState(7)
+    t = np.arange(16000) / 16000.0
+    for x in (0.1 * rng.randn(16000), 0.3 * np.sin(2 * np.pi * 440 * t) + 0.01 * rng.randn(16000), np.clip(2.0 * rng.randn(16000), -1, 1)):
+        x = x.astype(np.float32)
+        ref = au.spectrogram(x.astype(np.float64), win, frame_length=2048, hop_length=512, fft_length=2048, power=2.0, center=True,
+                             pad_mode='constant', onesided=True, mel_filters=fb_t, mel_floor=1e-10, log_mel='dB', reference=1.0,
+                             min_value=1e-10, db_range=None)
+        got = orc.mel_db(torch.from_numpy(x)[None, None, :]).numpy()[0, 0]
+        assert got.shape == ref.shape == (32, 32)
+        assert np.abs(got - ref).max() < 2e-4                                                      # dB; fp32 chain vs f64: measured 2.5e-6
+
+
 def test_smooth_predict_matches_reference_loop(golden_dir):
     """Votes through the reference's own loop (M5 real weights, seeded CPU noise), first batch only
     on CPU to bound the run time; the full N is checked on the GPU side."""
