@@ -5,6 +5,9 @@ import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'diffusion-model-for-audio-defense_amd')]
+from dmad_hip import _lib
+if os.environ.get('DMAD_LIB'):                   # A/B of two builds on one box
+    _lib.LIB_PATH = os.environ['DMAD_LIB']
 from dmad_hip import engine as E, synth
 B = int(os.environ.get('B', 16))
 PATHS = [int(p) for p in os.environ.get('PATHS', '1,2').split(',')]
@@ -18,4 +21,4 @@ for path in PATHS:
         eng.wavenet_eps_path(x, 65, path)
     torch.cuda.synchronize()
     dt = (time.time() - t0) / 3
-    print('path %d B=%d: %.1f ms -> %.1f clips/s, %.1f TFLOP/s fp32-equivalent (606.1 GFLOP/clip)' % (path, B, dt * 1e3, B / dt, B * 606.1e9 / dt / 1e12), flush=True)
+    print(os.environ.get('DMAD_LIB', 'in-tree'), 'path %d B=%d: %.1f ms -> %.1f clips/s, %.1f TFLOP/s fp32-equivalent (606.1 GFLOP/clip)' % (path, B, dt * 1e3, B / dt, B * 606.1e9 / dt / 1e12), flush=True)
