@@ -969,7 +969,7 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     e->maxB32 = cfg->precision == DMAD_FP32 ? cfg->max_batch : (cfg->recheck_batch > 0 ? cfg->recheck_batch : 32);
     if (e->maxB32 > cfg->max_batch) e->maxB32 = cfg->max_batch;
     e->mode = cfg->precision == DMAD_EXACT ? DMAD_MODE_EXACT_VOTES : (cfg->precision == DMAD_FP32 ? DMAD_MODE_FP32 : DMAD_MODE_FAST);
-    e->tau = cfg->half_type == DMAD_HALF_F16 ? 0.04f : 0.30f;   // measured logit-difference error of the 16-bit path x 1.4 (see dmad.h)
+    e->tau = cfg->half_type == DMAD_HALF_F16 ? 0.034f : 0.30f;  // measured logit-difference error (against the leader) of the 16-bit path x 1.4 (see dmad.h)
     e->tau2 = 1e-3f;                        // the same for the split-f16 tier (dmad_set_recheck_margin2)
     if (e->bf16 && !wn_final_p_supported(cfg->num_res_layers)) {
         delete e;

@@ -171,9 +171,10 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
  * the bound tau: a sample whose bf16 logits have (largest - second largest) < tau (or any NaN) does not vote from the bf16
  * logits; its global sample index is queued and the sample is re-evaluated from the SAME noise (Philox key (seed, index),
  * or its row of `delta`) on the exact-fp32 WaveNet, and that result votes (and replaces its row of logits_out / x0_out).
- * With tau >= the largest error the 16-bit path makes on a logit DIFFERENCE the counts equal the fp32 path's exactly
- * (robustness_eval/certified_robust.py:59-65 is an arg-max: it only depends on the order of the logits).  Defaults:
- * 0.04 for f16 operands (measured error 0.029 over 36 864 samples), 0.30 for bf16 operands (0.22).
+ * With tau >= the largest error the 16-bit path makes on a logit DIFFERENCE AGAINST THE EXACT LEADER (E = max_j |e_j - e_i|,
+ * e = 16-bit minus exact logits, i = the exact arg-max: a 16-bit leader j != i with margin >= tau would need e_j - e_i >= tau)
+ * the counts equal the fp32 path's exactly (robustness_eval/certified_robust.py:59-65 is an arg-max: it only depends on the
+ * order of the logits).  Defaults: 0.034 for f16 operands (measured E = 0.0244 over 36 864 samples), 0.30 for bf16 (0.207).
  *
  * The queued samples pass through two tiers.  Tier 2 is the fp32 pipeline on SPLIT-f16 operands: every fp32 value is kept
  * as hi = f16(x), lo = f16((x - hi) * 2^11) and every product is three f16 MFMAs (hi*hi + (hi*lo + lo*hi) * 2^-11, fp32
