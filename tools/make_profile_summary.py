@@ -52,7 +52,7 @@ def main():
     ap.add_argument('--stats', required=True)
     ap.add_argument('--fetch'); ap.add_argument('--write'); ap.add_argument('--mfma')
     ap.add_argument('--bench-line')
-    ap.add_argument('--clips-per-launch', type=int, default=128)
+    ap.add_argument('--clips-per-launch', type=int, default=None, help='clips one layer launch carries (default: engine_batch of the bench line, else 512)')
     ap.add_argument('--command', default='python3 bench.py --no-cpu-baseline --side-steps 0 --c5-n 0 --no-certify --steps 5 --warmup 1')
     a = ap.parse_args()
     prof = os.path.join(ROOT, 'profiles')
@@ -68,6 +68,9 @@ def main():
         shutil.copy(a.bench_line, os.path.join(prof, a.name + '_profiled_bench_line.json'))
         md += ['bench line of the profiled run: %.1f %s, roofline.achieved %.0f %s (layer kernel by HIP events).' % (
             j['value'], j['unit'], j['roofline']['achieved'], j['roofline']['unit']), '']
+    if a.clips_per_launch is None:
+        a.clips_per_launch = int(j['config']['engine_batch']) if (a.bench_line and os.path.exists(a.bench_line)) else 512
+    layer_us = next((float(r['AverageNs']) / 1e3 for r in rows if any(all(p in r['Name'] for p in alt) for alt in LAYER)), None)
     md += ['| kernel | calls | total ms | avg us | % |', '|---|---|---|---|---|']
     for r in rows[:18]:
         md.append('| %s | %s | %.3f | %.1f | %s |' % (r['Name'].split('(')[0][:60], r['Calls'], float(r['TotalDurationNs']) / 1e6,
@@ -92,6 +95,9 @@ def main():
         if busy and gui:
             md += ['', 'MFMA (layer kernel, per launch): SQ_VALU_MFMA_BUSY_CYCLES %.4g, GRBM_GUI_ACTIVE %.4g (sum over 8 XCDs).' % (busy, gui),
                    'MfmaUtil = MFMA_BUSY / (GUI_ACTIVE / 8 x 1024 SIMDs) = %.1f %%' % (100 * busy / (gui / 8 * 1024))]
+            if layer_us:
+                md += ['Effective clock = (GUI_ACTIVE / 8) cycles per launch / %.1f us (average launch of the --stats pass) = %.2f GHz'
+                       % (layer_us, gui / 8 / layer_us / 1e3)]
     open(os.path.join(prof, a.name + '_kernel_stats.md'), 'w').write('\n'.join(md) + '\n')
     print('\n'.join(md))
 
