@@ -11,7 +11,8 @@ from dmad_hip import engine as E, synth
 from diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
 N = int(os.environ.get('N', 16384))
 SIGMAS = [float(s) for s in os.environ.get('SIGMAS', '0.5,0.25').split(',')]
-eng = E.Engine(max_batch=256, precision=E.EXACT, recheck_batch=64)
+HALF = os.environ.get('HALF', 'f16')           # operand format of tier 1 (bf16: bound 0.30 instead of 0.034, far more rechecks)
+eng = E.Engine(max_batch=256, precision=E.EXACT, recheck_batch=64, half_type=E.HALF_F16 if HALF == 'f16' else E.HALF_BF16)
 eng.load_wavenet(synth.wavenet_state_dict(1234))
 eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321))
 ab = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)['Alpha_bar']
@@ -22,12 +23,12 @@ out = []
 for sigma in SIGMAS:
     t = int(torch.abs(ab - 1 / (1 + sigma ** 2)).min(0, keepdim=True)[1].item())
     args = (clip, sigma, float(torch.tensor((1 / (1 + sigma ** 2)) ** 0.5, dtype=torch.float32)), t, float((1 / ab).sqrt()[t]), float((1 / ab - 1).sqrt()[t]), N)
-    rec = {'clip': CLIP, 'sigma': sigma, 't_star': t + 1, 'n': N, 'margins': [eng.recheck_margin, eng.recheck_margin2]}
+    rec = {'clip': CLIP, 'half': HALF, 'sigma': sigma, 't_star': t + 1, 'n': N, 'margins': [eng.recheck_margin, eng.recheck_margin2]}
     ref = next((r for r in (REF or []) if r.get('clip', 0) == CLIP and r['sigma'] == sigma and r['n'] == N), None)
     if REF is not None and ref is None:
         raise SystemExit('no record for clip %d sigma %g n %d in %s' % (CLIP, sigma, N, os.environ['REF']))
     if ref is not None:
-        rec['fp32'], rec['fast'] = ref['fp32'], ref['fast']
+        rec['fp32'], rec['fast'] = ref['fp32'], ref['fast']          # (the stored 16-bit counts are those of the REF run's operand format)
         rec['fp32_and_fast_counts_from'] = os.environ['REF']
     for name, mode in (('exact', E.MODE_EXACT_VOTES),) + ((('fp32', E.MODE_FP32), ('fast', E.MODE_FAST)) if ref is None else ()):
         eng.set_mode(mode); eng.recheck_stats(reset=True)
