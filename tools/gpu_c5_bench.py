@@ -2,7 +2,7 @@
 """BASELINE configuration C5 on one GPU: certified smoothing with the Improved-Diffusion UNet purifier on mel spectrograms
 (dmad_spec_smooth_votes), N = 10 000 Monte Carlo samples of one clip.  Prints / writes one JSON record.
 
-    N=10000 TSTAR=25 B=128 python tools/gpu_c5_bench.py
+    N=10000 TSTAR=25 B=512 python tools/gpu_c5_bench.py        (engine batch: 128 -> 208 samples/s, 512 -> 227, 2048 -> 234)
 """
 import json, os, sys, time
 import torch
@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'diffusion-model-for-audio-defense_amd')]
 from dmad_hip import engine as E, synth
 from diffusion_models.improved_diffusion_ddpm import create_improved_diffusion
-N, TSTAR, B = int(os.environ.get('N', 10000)), int(os.environ.get('TSTAR', 25)), int(os.environ.get('B', 128))
+N, TSTAR, B = int(os.environ.get('N', 10000)), int(os.environ.get('TSTAR', 25)), int(os.environ.get('B', 512))
 eng = E.Engine(max_batch=B, precision=E.FP32, recheck_batch=0)
 eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321))
 pur = create_improved_diffusion(None, reverse_timestep=TSTAR, state_dict=synth.unet_state_dict(31), engine=eng)
