@@ -16,18 +16,24 @@ all-reduce (RCCL int64[10]) — weak scaling: every rank works on its own shard 
 512 samples are one full N = 100 000 certification on one GPU.  Clip and weights are resident in HBM before the timed region.
 
 `value` is measured in the engine's EXACT-VOTE mode (the drop-in default): f16-operand MFMA WaveNet, and every sample
-whose top-2 logit margin is below the recheck bound is re-evaluated on the exact-fp32 WaveNet from the same Philox key,
-so the vote counts equal the fp32 path's.  The line also carries
+whose top-2 logit margin is below the recheck bound is re-evaluated on the split-f16 / exact-fp32 tiers from the same
+Philox key.  The bound is a measured one, so the equality of the counts with the fp32 path's is an
+empirical guarantee — and the line itself checks it: `exact_equals_fp32` re-runs the first timed steps' sample range in
+the exact-vote mode and on the exact-fp32 path and prints both vote vectors.  The line also carries
   fast_mode / fp32_mode — the same step with the recheck off (16-bit path alone) and on the exact-fp32 path alone;
+  c2_ddpm_mode   — BASELINE C2: DiffWave DDPM purification t* = 5 of a batch of 256 clips + mel-dB + VGG19_bn on a bf16
+                   engine (dmad_query_logits, sampler 1): clips/s, network evaluations/s, layer-kernel roofline fraction;
+  c3_certify_n1000 — BASELINE C3: RobustCertificate.certify(n_0=100, n=1000) through the host mirror, clips/s;
   roofline       — the dominant kernel (wn_layer_p): algorithmic FLOPs per launch / average launch duration measured
                    live with HIP event pairs on the launch stream over the timed steps, against the dense 16-bit MFMA peak
                    (MI355X_MICROARCH.md: ~2.5 PFLOP/s);
   roofline_final — the tail kernel (wn_final_p, HBM-bound: reads the 295 MB/clip gate store once) against 8 TB/s;
   cpu_baseline   — the CPU oracle (a restatement of the reference's arithmetic, kind "port") timed on the host cores of
                    the same box on a bounded sample (rank 0, N = 1 only);
-  certify_full   — RobustCertificate.certify(x, n_0=100, n, sigma) through the host mirror (the surface the reference's
-                   driver calls, scripts/certified_robust_eval.sh:3-6), timed end to end: n = 8192 in the default run (N = 1),
-                   n = 100000 with --full.
+  certify_full   — RobustCertificate.certify(x, n_0=100, n = 100000, sigma) through the host mirror (the surface the
+                   reference's driver calls, scripts/certified_robust_eval.sh:3-6), timed end to end on every GPU count: the
+                   N = 100 000 samples of ONE clip sharded over the ranks + one int64[10] all-reduce per pass — the strong-scaling
+                   quantity BASELINE.json's metric names (--full-n to shorten it).
 """
 import argparse
 import json
@@ -135,9 +141,13 @@ def main():
     ap.add_argument('--side-steps', type=int, default=None, help='steps of the two side measurements (fast / exact, fp32); 0 = skip')
     ap.add_argument('--cpu-samples', type=int, default=6)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--full', action='store_true', help='time the full certify(n_0=100, n=100000) through the host mirror (about 70 s) '
-                                                        'instead of the short n=8192 one the default run carries')
-    ap.add_argument('--full-n', type=int, default=None, help='n of the certify() run through the host mirror (default 8192; --full: 100000)')
+    ap.add_argument('--full', action='store_true', help='kept for older command lines: the default run already times certify(n_0=100, n=100000)')
+    ap.add_argument('--full-n', type=int, default=100000, help='n of the certify() run through the host mirror (about 65 s / n_gpus at 100000)')
+    ap.add_argument('--check-steps', type=int, default=2, help='steps of the timed sample range re-run in the exact-vote mode and on the '
+                                                               'exact-fp32 path to print exact_equals_fp32 (0 = skip; fp32 costs ~2.8 s per step)')
+    ap.add_argument('--c2-iters', type=int, default=4, help='timed iterations of the BASELINE C2 leg (DDPM t*=5, B=256, bf16); 0 = skip')
+    ap.add_argument('--c2-batch', type=int, default=256, help='clips per batch of the C2 leg (BASELINE C2 names 256)')
+    ap.add_argument('--c3-clips', type=int, default=4, help='clips certified with n=1000 for the BASELINE C3 leg; 0 = skip')
     ap.add_argument('--no-certify', action='store_true', help='skip the certify() run through the host mirror')
     ap.add_argument('--c5-n', type=int, default=1024, help='Monte Carlo samples of the BASELINE C5 side measurement (spec-domain vote loop, '
                                                            'Improved-Diffusion UNet purifier, t* = 25); 0 = skip; single-GPU runs only')
@@ -252,6 +262,7 @@ def main():
         voted, rechecked, rechecked32 = eng.recheck_stats(detail=True)
         return dt, votes, ((rechecked / voted, rechecked32 / voted) if voted else (0.0, 0.0)), prof
 
+    recheck_margin, recheck_margin2 = eng.recheck_margin, eng.recheck_margin2
     # ---- the measured region: exactly --steps steps after --warmup untimed ones, in --mode --------------------------
     dt, votes, recheck_frac, prof = timed(args.mode, args.steps, args.warmup, 0, profile=(args.mode != 'fp32'))
     clips = args.steps * S * world
@@ -272,10 +283,25 @@ def main():
                 side[mode]["tflops"] = k * S / sdt * CLIP_FLOP / 1e12
                 side[mode]["frac_of_fp32_matrix_peak"] = side[mode]["tflops"] / PEAK_FP32_TFLOPS
 
+    # ---- exact == fp32 on the SAME keys: the first --check-steps timed steps' sample range, once per mode -------------------
+    check = None
+    if args.check_steps > 0 and args.mode == 'exact':
+        k = min(args.check_steps, args.steps)
+
+        def votes_of(mode):
+            eng.set_mode(MODES[mode])
+            total.zero_()
+            for i in range(k):
+                step(args.warmup + i)            # the global sample range of timed steps 0..k-1
+            fence()
+            return total.cpu().tolist()
+        v_exact, v_fp32 = votes_of('exact'), votes_of('fp32')
+        check = {"exact_equals_fp32": v_exact == v_fp32, "votes_exact": v_exact, "votes_fp32": v_fp32, "samples": k * S * world,
+                 "sample_range": [args.warmup * S * world, (args.warmup + k) * S * world],
+                 "note": "the same Philox keys as the first %d timed steps, evaluated in the exact-vote mode and on the exact-fp32 path" % k}
+
     full = None
-    if args.full_n is None:
-        args.full_n = 100000 if args.full else 8192
-    if not args.no_certify and args.classifier == 'vgg19_bn' and (world == 1 or args.full):
+    if not args.no_certify and args.classifier == 'vgg19_bn':
         # the surface the reference's driver calls: RobustCertificate.certify through the host mirror, n_0 pass included
         from audio_models.ConvNets_SpeechCommands.models.vgg import vgg19_bn
         from diffusion_models.diffwave_ddpm import DiffWave, WaveNetHIP
@@ -297,12 +323,66 @@ def main():
         fence()
         fdt = time.perf_counter() - t0
         voted, rechecked = eng.recheck_stats()
+        if dist is not None:
+            tmax = torch.tensor([fdt], dtype=torch.float64, device='cpu' if backend == 'gloo' else 'cuda')
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            fdt = float(tmax.item())
         full = {"seconds": fdt, "clips_per_s": (100 + args.full_n) * 1.0 / fdt, "n_0": 100, "n": args.full_n, "n_gpus": world,
+                "scaling": "strong: one clip's %d samples sharded over %d rank(s)" % (args.full_n, world),
                 "y_pred": int(y_pred[0]), "radius": float(radius[0]), "recheck_frac": rechecked / max(voted, 1),
                 "vs_steady_state": ((100 + args.full_n) / fdt) / (clips / dt)}
 
+        # BASELINE C3: certify(n_0 = 100, n = 1000) per clip through the same mirror (scripts' N = 1 000 setting), a few clips
+        c3 = None
+        if args.c3_clips > 0:
+            xs = [torch.from_numpy(synth.synthetic_clip(10 + i)).cuda().reshape(1, 1, L) for i in range(args.c3_clips)]
+            rc.certify(xs[0], torch.tensor([0], device='cuda'), sigma=sigma, n_0=100, n=1000, batch_size=args.max_batch)
+            fence()
+            t0 = time.perf_counter()
+            outs = [rc.certify(xc, torch.tensor([0], device='cuda'), sigma=sigma, n_0=100, n=1000, batch_size=args.max_batch) for xc in xs]
+            fence()
+            c3dt = time.perf_counter() - t0
+            c3 = {"workload": "BASELINE C3: certify(n_0=100, n=1000, sigma=%.2f) per clip through RobustCertificate, %d clips, %d rank(s)"
+                              % (sigma, args.c3_clips, world),
+                  "clips_per_s": args.c3_clips * 1100 / c3dt, "seconds_per_certified_clip": c3dt / args.c3_clips,
+                  "y_pred": [int(o[0][0]) for o in outs], "radius": [float(o[1][0]) for o in outs]}
+
+    # BASELINE C2: DiffWave DDPM purification t* = 5 of 256 clips + mel-dB + VGG19_bn on a bf16 engine of its own (the main engine
+    # is released first: 512-clip exact-vote engine 172 GB + 256-clip bf16 engine 85 GB would not leave room for C5's)
+    c2 = None
+    if args.c2_iters > 0 and args.classifier == 'vgg19_bn':
+        eng.close()
+        c2_b, c2_t = args.c2_batch, 5
+        eng2 = E.Engine(max_batch=c2_b, precision=E.BF16, half_type=E.HALF_BF16)
+        eng2.load_wavenet(wsd)
+        eng2.load_vgg19_bn(csd)
+        xb = torch.stack([torch.from_numpy(synth.synthetic_clip(100 + i)) for i in range(c2_b)]).cuda()
+        from diffusion_models.diffwave_ddpm import DiffWave as _DW, WaveNetHIP as _WN
+        ts2, ca2, cb2, ce2, cd2, cs2 = _DW(_WN(eng2), hp, reverse_timestep=c2_t).purify_coefficients()      # the fp32 tables, as DiffWave.forward uses them
+        q = dict(sampler=1, t_star=ts2, c_a=ca2, c_b=cb2, c_eps=ce2, c_div=cd2, c_sig=cs2)
+        eng2.query_logits(xb, 1, seed=7, **q)                                  # warm-up: step embeddings of t = 0..4
+        fence()
+        eng2.profile_layers(args.c2_iters * c2_t * 35)
+        t0 = time.perf_counter()
+        for it in range(args.c2_iters):
+            lg2, dec2 = eng2.query_logits(xb, 1, seed=7, sample0=it * c2_b, **q)
+        fence()
+        c2dt = time.perf_counter() - t0
+        eng2.profile_read_final()
+        lms, ln = eng2.profile_read()
+        c2_ach = LAYER_FLOP_PER_CLIP * c2_b / (lms / ln * 1e-3) / 1e12 if ln else float('nan')
+        c2 = {"workload": "BASELINE C2: DiffWave DDPM purify t*=%d (diffusion + %d reverse steps) of %d clips + mel-dB + VGG19_bn, bf16 MFMA engine, "
+                          "one dmad_query_logits call per batch" % (c2_t, c2_t, c2_b),
+              "clips_per_s": args.c2_iters * c2_b / c2dt, "network_evals_per_s": args.c2_iters * c2_b * c2_t / c2dt,
+              "ms_per_batch": c2dt / args.c2_iters * 1e3, "dtype": "bf16", "batch": c2_b, "t_star": c2_t, "iters": args.c2_iters,
+              "end_to_end_tflops": args.c2_iters * c2_b * (c2_t * 606.10e9 + 1.10e9) / c2dt / 1e12,
+              "roofline": {"bound": "mfma", "kernel": "wn_layer_p<__bf16>", "achieved": c2_ach, "peak": PEAK_MFMA16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": c2_ach / PEAK_MFMA16_TFLOPS, "avg_launch_ms": lms / ln if ln else None, "launches_timed": ln},
+              "decisions_histogram": torch.bincount(dec2.long().cpu(), minlength=10).tolist()}
+        eng2.close()
+
     c5 = None
-    if args.c5_n > 0 and world == 1 and args.classifier == 'vgg19_bn':
+    if args.c5_n > 0 and args.classifier == 'vgg19_bn':
         # BASELINE configuration C5 beside the headline: the same vote loop with the spec-domain purifier (dmad_spec_smooth_votes:
         # mel-dB -> standardise -> q_sample(t*) -> 26 UNet evaluations -> classifier), exact fp32 throughout, its own small engine
         from diffusion_models.improved_diffusion_ddpm import create_improved_diffusion
@@ -314,14 +394,25 @@ def main():
         eng5.spec_smooth_votes(*c5_args, c5_b, seed=1)                       # warm-up: one batch fills the per-step tables of all 26 steps
         fence()
         t0 = time.perf_counter()
-        c5_counts, _, _ = eng5.spec_smooth_votes(*c5_args, args.c5_n, seed=2024)
+        # every rank takes c5_n samples of the global index range (weak scaling), one int64[10] all-reduce at the end
+        c5_counts, _, _ = eng5.spec_smooth_votes(*c5_args, args.c5_n, seed=2024, sample0=rank * args.c5_n)
+        if dist is not None:
+            if backend == 'gloo':
+                cc = c5_counts.cpu(); dist.all_reduce(cc); c5_counts = cc
+            else:
+                dist.all_reduce(c5_counts)
         fence()
         c5_dt = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([c5_dt], dtype=torch.float64, device='cpu' if backend == 'gloo' else 'cuda')
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            c5_dt = float(tmax.item())
         unet_tf = args.c5_n * (c5_t + 1) * UNET_FLOP_PER_SPEC / c5_dt / 1e12
         c5 = {"workload": "BASELINE C5: certified smoothing sigma=%.2f, spec-domain purifier (Improved-Diffusion UNet, t*=%d: %d network "
                           "evaluations per sample) + VGG19_bn" % (sigma, c5_t, c5_t + 1),
-              "samples_per_s": args.c5_n / c5_dt, "n": args.c5_n, "seconds": c5_dt, "engine_batch": c5_b, "dtype": "f32",
-              "votes": c5_counts.cpu().tolist(), "unet_tflops": unet_tf, "frac_of_fp32_matrix_peak": unet_tf / PEAK_FP32_TFLOPS}
+              "samples_per_s": args.c5_n * world / c5_dt, "n": args.c5_n * world, "n_gpus": world, "seconds": c5_dt, "engine_batch": c5_b,
+              "dtype": "f32", "votes": c5_counts.cpu().tolist(), "unet_tflops_per_gpu": unet_tf,
+              "frac_of_fp32_matrix_peak": unet_tf / PEAK_FP32_TFLOPS}
         eng5.close()
 
     if rank == 0:
@@ -334,8 +425,9 @@ def main():
                                    "+ mel-dB + %s + votes; step = %d Monte Carlo samples per GPU, %d steps = one "
                                    "N=100000 clip" % (sigma, t + 1, 'VGG19_bn' if args.classifier == 'vgg19_bn' else 'ResNeXt29', S, -(-100000 // S)),
                        "samples_per_step_per_gpu": S, "engine_batch": args.max_batch, "sigma": sigma, "t_star": t + 1,
-                       "mode": {"exact": "exact-vote: %s MFMA WaveNet + exact-fp32 re-evaluation of samples with top-2 logit margin < %.3g "
-                                         "(counts equal the fp32 path's)" % (args.half, eng.recheck_margin),
+                       "mode": {"exact": "exact-vote: %s MFMA WaveNet + split-f16 / exact-fp32 re-evaluation of samples with top-2 logit margin < %.3g "
+                                         "(empirical bound: no vote differed from the fp32 path's on 36 864 + 100 000 samples; this "
+                                         "line's own check: exact_equals_fp32)" % (args.half, recheck_margin),
                                 "fast": "%s MFMA WaveNet alone (no recheck)" % args.half, "fp32": "exact-fp32 WaveNet alone"}[args.mode],
                        "noise": "device Philox4x32-10", "classifier": "VGG19_bn (synthetic seed 4321)" if args.classifier == 'vgg19_bn' else "ResNeXt29 8x64d (synthetic seed 2929)",
                        "parallelism": "mc-samples sharded x%d, one int64[10] all-reduce per step" % world},
@@ -343,10 +435,13 @@ def main():
             "votes": votes,
         }
         if args.mode == 'exact':
-            out["recheck"] = {"margin": eng.recheck_margin, "frac": recheck_frac[0], "margin_split_f16_tier": eng.recheck_margin2,
+            out["recheck"] = {"margin": recheck_margin, "frac": recheck_frac[0], "margin_split_f16_tier": recheck_margin2,
                               "frac_fp32": recheck_frac[1], "batch": min(args.recheck_batch, args.max_batch),
                               "tiers": "16-bit MFMA -> (margin < %.3g) split-f16 three-MFMA fp32 pipeline -> (margin < %.3g) exact fp32"
-                                       % (eng.recheck_margin, eng.recheck_margin2)}
+                                       % (recheck_margin, recheck_margin2)}
+            if check is not None:
+                out["exact_equals_fp32"] = check["exact_equals_fp32"]
+                out["exact_vs_fp32_check"] = check
         if prof is not None:
             (layer_ms, launches), (final_ms, flaunches) = prof
             # launches of a step's last (possibly smaller) chunk and of the recheck passes carry fewer clips; the recheck
@@ -374,12 +469,16 @@ def main():
             out[mode + "_mode"] = rec
         if full is not None:
             out["certify_full"] = full
+            if c3 is not None:
+                out["c3_certify_n1000"] = c3
+        if c2 is not None:
+            out["c2_ddpm_mode"] = c2
         if c5 is not None:
             out["c5_spec_mode"] = c5
         if world == 1 and not args.no_cpu_baseline and args.classifier == 'vgg19_bn':
             out["cpu_baseline"] = cpu_baseline(args.cpu_samples)
         print(json.dumps(out), flush=True)
-    eng.close()
+    eng.close()                                # (a no-op when the C2 leg already released it)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -62,7 +62,12 @@ def build_parser():
     parser.add_argument('--resume', action='store_true', help='continue after the last record of an existing file')
     parser.add_argument('--noise_source', choices=['device', 'torch_cpu'], default='device')
     parser.add_argument('--calibrate_margins', type=int, default=1024,
-                        help='exact-vote engine: samples used to measure the recheck bounds for the loaded checkpoints (0 = engine defaults)')
+                        help='exact-vote engine: samples per clip used to measure the recheck bounds for the loaded checkpoints on the first '
+                             '--calibrate_clips clips of a sigma (bounds only widen, never below the engine defaults; 0 = engine defaults)')
+    parser.add_argument('--calibrate_clips', type=int, default=3)
+    parser.add_argument('--audit', type=int, default=0,
+                        help='exact-vote engine: per example, re-evaluate this many samples that voted on the 16-bit tier on the split-f16 tier '
+                             'and write the outcome into the record (key "audit")')
     return parser
 
 
@@ -93,7 +98,8 @@ def run(args, classifier=None, denoiser=None, log=print):
     if args.defense_method == 'randsmooth':
         denoiser = None
     RC = RobustCertificate(classifier=classifier, transform=MelSpectrogramDB(), denoiser=denoiser,
-                           noise_source=args.noise_source, calibrate=getattr(args, 'calibrate_margins', 0))
+                           noise_source=args.noise_source, calibrate=getattr(args, 'calibrate_margins', 0),
+                           calibrate_clips=getattr(args, 'calibrate_clips', 3), log=(log if rank == 0 else None))
 
     records = CertificationRecords(args.save_path, args.sigma, args.num_sampling, resume=args.resume)
     done, seen = len(records), 0
@@ -107,9 +113,12 @@ def run(args, classifier=None, denoiser=None, log=print):
         keep = slice(max(done - seen, 0), n)
         seen += n
         waveforms, targets = waveforms[keep].cuda(), targets[keep].cuda()
+        n_audits = len(RC.audit_log)
         y_certified, r_certified = RC.certify(x=waveforms, y=targets, sigma=args.sigma, n_0=100, n=args.num_sampling,
-                                              batch_size=args.batch_size)
-        records.append_batch(targets.tolist(), y_certified.tolist(), r_certified.tolist())
+                                              batch_size=args.batch_size, audit=getattr(args, 'audit', 0))
+        audits = RC.audit_log[n_audits:]
+        records.append_batch(targets.tolist(), y_certified.tolist(), r_certified.tolist(),
+                             extra=[{'audit': a} for a in audits] if len(audits) == len(targets) else None)
         if rank == 0:
             records.flush()
             log('certified %d / %d examples' % (len(records), len(test_dataset)))

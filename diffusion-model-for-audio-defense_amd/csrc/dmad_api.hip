@@ -21,7 +21,7 @@ using namespace dmad;
 
 namespace {
 
-thread_local std::string g_err;
+thread_local std::string g_err, g_warn;
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -42,6 +42,12 @@ int fail(int code, const char* fmt, ...) {
     do {                       \
         int _r = (x);          \
         if (_r != 0) return _r; \
+    } while (0)
+// end of an entry point's launch sequence: a failed launch, or a GEMM argument block no kernel serves (gemm_f32.h)
+#define LASTCHK()                                                                                   \
+    do {                                                                                            \
+        HIPCHK(hipGetLastError());                                                                  \
+        if (int _b = gemm_take_bad_shapes()) return fail(DMAD_ERR_INVALID, "%d GEMM launch(es) refused: unsupported shape", _b); \
     } while (0)
 
 uint16_t f2bf(float f) {   // round-to-nearest-even, NaN stays NaN
@@ -65,6 +71,17 @@ uint16_t f2h(float f) {    // fp32 -> IEEE half, round-to-nearest-even (subnorma
     if (rem > half || (rem == half && (h & 1u))) ++h;
     if (e < -14) return (uint16_t)(sign | h);                                // subnormal (a carry into 0x400 is the smallest normal)
     return (uint16_t)(sign | (uint32_t)(((e + 15) << 10) + (h - 0x400u)));   // a significand carry bumps the exponent
+}
+
+// f2h with a census of what leaves the f16 normal range (dmad_finalize_weights warns: a folded weight below 2^-14 keeps
+// fewer than 11 significant bits as an f16 subnormal, one above 65504 becomes inf and shows up as NaN logits)
+thread_local long g_h_sub = 0, g_h_ovf = 0, g_h_n = 0;
+uint16_t f2h_census(float f) {
+    const float a = fabsf(f);
+    ++g_h_n;
+    if (a != 0.f && a < 6.103515625e-05f) ++g_h_sub;
+    if (a >= 65520.f) ++g_h_ovf;
+    return f2h(f);
 }
 
 float h2f(uint16_t h) {    // IEEE half -> fp32 (exact)
@@ -123,6 +140,8 @@ struct dmad_engine {
     unsigned long long* rc_n_host = nullptr;   // ... and its pinned host mirror
     long rc_cap = 0;
     int64_t st_samples = 0, st_rechecked = 0;
+    int diag[5] = {0, 0, 0, 0, 0};         // dmad_debug_rounding: GemmF32Args::diag of the x3 tier's dil / res / skip / f0 launches, init hi-only
+    std::string warn;                      // dmad_last_warning
     std::map<std::string, HostW> hw;
     std::vector<void*> allocs;
     int64_t bytes = 0;
@@ -288,7 +307,8 @@ int finalize_wavenet(dmad_engine* e) {
     CHK(e->alloc(&e->emb_table, (size_t)NL * 256)); CHK(e->alloc(&e->emb2, 512)); CHK(e->alloc(&e->epi_c, (size_t)NL * 256, true));
 
     if (e->bf16) {
-        uint16_t (*cvt)(float) = e->f16 ? f2h : f2bf;
+        uint16_t (*cvt)(float) = e->f16 ? f2h_census : f2bf;
+        g_h_sub = g_h_ovf = g_h_n = 0;
         int rmap[512];
         // tile row R = wm*128 + half*64 + mt*16 + i  <->  gate row half*256 + (mt*64 + wm*16 + i): channel ownership is
         // interleaved over the M-waves so that GEMM2 can start on channels [64 mt, 64 mt + 64) as soon as tiles mt are gated
@@ -321,6 +341,13 @@ int finalize_wavenet(dmad_engine* e) {
         CHK(e->upload_bf(&e->w1p, w1p)); CHK(e->upload_bf(&e->w2p, w2p)); CHK(e->upload_bf(&e->wsp, wsp));
         CHK(e->upload_bf(&e->wf0p, wf0p));
         CHK(e->upload(&e->b1p, b1p)); CHK(e->upload(&e->b2, b2)); CHK(e->upload(&e->bskip_sum, bsum));
+        if (e->f16 && (g_h_sub || g_h_ovf)) {
+            char buf[384];
+            snprintf(buf, sizeof buf, "WaveNet weights on the f16 MFMA path: %ld of %ld folded values are f16 subnormals (|w| < 6.1e-5: fewer "
+                     "than 11 significant bits) and %ld overflow to inf (|w| > 65504); the 16-bit tier's error bound was not measured for "
+                     "such weights: calibrate the recheck margins on these weights or use half_type = bf16", g_h_sub, g_h_n, g_h_ovf);
+            e->warn = buf;
+        }
     }
     if (e->f32) {
         std::vector<float> wdil((size_t)NL * 3 * 512 * 256), bdil((size_t)NL * 512), wrs((size_t)NL * 512 * 256), brs((size_t)NL * 512);
@@ -544,7 +571,7 @@ int classify_resnext(dmad_engine* e, const float* spec, int B, float* logits, hi
     launch_avgpool_nhwc(X, e->rxT2, B, H * H, 1024, s);
     launch_gemm_f32(plain_gemm(e->rxfcw, e->rxT2, logits, nullptr, e->rxfcb, e->cfg.num_classes, 1024, B, e->cfg.num_classes, 1024, 0), s,
                     e->slab, e->slab_floats, (long)e->maxB);
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
@@ -775,7 +802,7 @@ int unet_eps(dmad_engine* e, const float* x, int t, int B, float* eps, hipStream
     if (launch_groupnorm_nhwc(h, e->un_outgw, e->un_outgb, nullptr, 1, e->un_buf[3], B, 1024, kUnMC, s)) { gn_fail(1024, kUnMC); return DMAD_ERR_STATE; }
     static_assert(kUnMC == 128, "launch_conv3x3_c128_to1 is the 128-channel output layer");
     launch_conv3x3_c128_to1(e->un_buf[3], e->un_outw, e->un_outb, eps, B, s);
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
@@ -841,7 +868,7 @@ int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipS
         if (timed_f) (void)hipEventRecord(e->prof_ev_f[e->prof_used_f++], s);
     } else {
         const long N = (long)B * L;
-        launch_wn_init_f32(x_t, e->init_w, e->init_b, e->emb_table, e->hA32, B, L, LP, s, x3);
+        launch_wn_init_f32(x_t, e->init_w, e->init_b, e->emb_table, e->hA32, B, L, LP, s, x3, x3 && e->diag[4]);
         const size_t slab = (size_t)e->maxB32 * L * 256;          // one gate-output slab per layer
         for (int n = 0; n < NL; ++n) {
             float* hin = (n & 1) ? e->hB32 : e->hA32;
@@ -851,7 +878,7 @@ int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipS
             float* gout = e->gstore32 + (size_t)n * slab;
             GemmF32Args g{};
             g.A = (x3 ? e->wdil_x3 : e->wdil) + (size_t)n * 3 * 512 * 256; g.X = hin + (size_t)kPad * kC; g.scale = nullptr;
-            g.x3 = x3;
+            g.x3 = x3; g.diag = x3 ? e->diag[0] : 0;
             g.shift = e->bdil + (size_t)n * 512; g.M = 512; g.K = 256; g.taps = 3; g.ldc = 512; g.relu = 0; g.N = N; g.mode = 0;
             g.rows_per_batch = L; g.batch_stride = (long)LP * kC; g.row_stride = kC; g.tap_stride = (long)d * kC;
             g.epi = 1; g.C = gout;               // tanh * sigmoid in the epilogue: H never goes to HBM
@@ -862,23 +889,23 @@ int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipS
                                        N, 256, 256, 0);
             u.epi = 2; u.res_rows = 256; u.first = 0; u.L = L; u.LP = LP;
             u.hin = hin; u.hout = hout; u.skip = nullptr; u.emb_next = e->emb_table + (size_t)(n + 1) * 256;
-            u.x3 = x3;
+            u.x3 = x3; u.diag = x3 ? e->diag[1] : 0;
             launch_gemm_f32(u, s);
         }
         {   // skip = sum_n W_skip_n g_n + sum_n b_skip_n: taps = layers, tap stride = one slab (taps are centred on NL / 2)
             GemmF32Args k{};
             k.A = x3 ? e->wskip_x3 : e->wskip32; k.X = e->gstore32 + (size_t)(NL >> 1) * slab; k.C = e->skip32; k.scale = nullptr;
-            k.shift = e->bskip32; k.M = 256; k.K = 256; k.taps = NL; k.ldc = 256; k.relu = 0; k.N = N; k.mode = 0; k.x3 = x3;
+            k.shift = e->bskip32; k.M = 256; k.K = 256; k.taps = NL; k.ldc = 256; k.relu = 0; k.N = N; k.mode = 0; k.x3 = x3; k.diag = x3 ? e->diag[2] : 0;
             k.rows_per_batch = N; k.batch_stride = 0; k.row_stride = 256; k.tap_stride = (long)slab;
             launch_gemm_f32(k, s);
         }
         launch_scale(e->skip32, (float)sqrt(1.0 / NL), e->g32, N * 256, s, x3);
         GemmF32Args f = plain_gemm(x3 ? e->wf0_x3 : e->wf0, e->g32, e->H32, nullptr, e->bf0, 256, 256, N, 256, 256, 1);
-        f.x3 = x3;
+        f.x3 = x3; f.diag = x3 ? e->diag[3] : 0;
         launch_gemm_f32(f, s);
         launch_dot256(e->H32, e->wz, e->bz, eps, N, s);
     }
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
@@ -895,7 +922,7 @@ int mel_db(dmad_engine* e, const float* x, int B, float* spec, hipStream_t s, in
     launch_mel_power(e->dftD, e->melP, kDftLd, kMelLd, rows, s);
     launch_gemm_f32(plain_gemm(e->fbA, e->melP, e->melM, nullptr, nullptr, 32, kMelLd, rows, 32, kMelLd, 0), s);
     launch_mel_db(e->melM, spec, B, to_db, s);
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
@@ -930,7 +957,7 @@ int classify(dmad_engine* e, const float* spec, int B, float* logits, hipStream_
                         e->slab_floats, (long)e->maxB);
         float* t = cur; cur = nxt; nxt = t;
     }
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
@@ -939,10 +966,14 @@ int classify(dmad_engine* e, const float* spec, int B, float* logits, hipStream_
 extern "C" {
 
 const char* dmad_last_error(void) { return g_err.c_str(); }
-const char* dmad_version(void) { return "dmad-hip 0.1 (gfx950)"; }
+const char* dmad_version(void) { return "dmad-hip 0.3 (gfx950)"; }
+const char* dmad_last_warning(void) { return g_warn.c_str(); }
 
 int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     if (!cfg || !out) return fail(DMAD_ERR_INVALID, "null argument");
+    if (cfg->struct_size != (int32_t)sizeof(dmad_config))       // a caller built against another revision of dmad.h
+        return fail(DMAD_ERR_INVALID, "dmad_config.struct_size is %d, this library's dmad_config has %d bytes (%s)", cfg->struct_size,
+                    (int)sizeof(dmad_config), dmad_version());
     if (cfg->res_channels != 256 || cfg->skip_channels != 256)
         return fail(DMAD_ERR_INVALID, "only res_channels = skip_channels = 256 is supported (got %d/%d)", cfg->res_channels, cfg->skip_channels);
     if (cfg->embed_dim_in != 128 || cfg->embed_dim_mid != 512 || cfg->embed_dim_out != 512)
@@ -994,6 +1025,7 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
             if ((r = e->alloc(&e->H32, B32 * L * 512))) break;
             if ((r = e->alloc(&e->g32, B32 * L * 256))) break;
             if ((r = e->alloc(&e->skip32, B32 * L * 256))) break;
+            if (e->bf16 && (r = gemm_x3_configure())) { r = fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS, split-f16 tier) failed: %d", r); break; }
         }
         if (e->bf16 && e->f32) {             // recheck queue of the exact-vote mode
             e->rc_cap = 1l << 20;
@@ -1124,6 +1156,8 @@ int dmad_finalize_weights(dmad_engine* e) {
     }
     if (!did) return fail(DMAD_ERR_STATE, "nothing to finalise: no complete weight set was loaded");
     e->hw.clear();
+    g_warn = e->warn;                       // dmad_last_warning(): empty unless this call found something to say
+    e->warn.clear();
     return 0;
 }
 
@@ -1136,7 +1170,7 @@ int dmad_one_shot(dmad_engine* e, const float* x_t, int32_t t, float c_a, float 
     if (!e || !x_t || !x0) return fail(DMAD_ERR_INVALID, "null argument");
     CHK(wavenet_eps(e, x_t, t, B, e->eps, (hipStream_t)s));
     launch_lincomb(0, x_t, e->eps, nullptr, c_a, c_b, 0.f, x0, (long)B * e->L, (hipStream_t)s);
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
@@ -1153,7 +1187,7 @@ int dmad_ddpm_step(dmad_engine* e, float* x, int32_t t, float c_eps, float c_div
         }
     }
     launch_lincomb(2, x, e->eps, zz, c_eps, c_div, c_sig, x, (long)B * e->L, (hipStream_t)s);
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
@@ -1167,7 +1201,7 @@ int dmad_diffuse(dmad_engine* e, const float* x0, float c_a, float c_b, const fl
         zz = e->znoise;
     }
     launch_lincomb(1, x0, nullptr, zz, c_a, c_b, 0.f, x_t, (long)B * e->L, (hipStream_t)s);
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
@@ -1189,7 +1223,7 @@ int dmad_unet_p_sample(dmad_engine* e, float* x, int32_t t, float c_a, float c_b
         }
     }
     launch_unet_p_sample(x, e->un_eps, zz, c_a, c_b, c_1, c_2, c_sig, x, x0_out, (long)B * 1024, (hipStream_t)s);
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
@@ -1216,7 +1250,7 @@ int dmad_mel_power(dmad_engine* e, const float* x, int32_t B, float* mel, dmad_s
 int dmad_power_to_db(dmad_engine* e, const float* x, int64_t n, float* y, dmad_stream s) {
     if (!e || !x || !y || n < 0) return fail(DMAD_ERR_INVALID, "bad argument");
     if (n) launch_power_to_db(x, y, (long)n, (hipStream_t)s);
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
@@ -1228,7 +1262,7 @@ int dmad_classify(dmad_engine* e, const float* spec, int32_t B, float* logits, d
 int dmad_vote(dmad_engine* e, const float* logits, int32_t B, int64_t* counts, dmad_stream s) {
     if (!e || !logits || !counts || B < 1) return fail(DMAD_ERR_INVALID, "bad argument to dmad_vote");
     launch_vote(logits, B, e->cfg.num_classes, (unsigned long long*)counts, nullptr, (hipStream_t)s);
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
@@ -1274,6 +1308,42 @@ int dmad_wavenet_eps_path(dmad_engine* e, const float* x_t, int32_t t, int32_t B
     return wavenet_eps(e, x_t, t, B, eps, (hipStream_t)s, path);
 }
 
+int dmad_debug_rounding(dmad_engine* e, const int32_t masks[5]) {
+    if (!e || !masks) return fail(DMAD_ERR_INVALID, "null argument");
+    if (!(e->bf16 && e->f32)) return fail(DMAD_ERR_STATE, "dmad_debug_rounding needs a DMAD_EXACT engine (it acts on the split-f16 tier)");
+    for (int i = 0; i < 5; ++i) {
+        if (masks[i] < 0 || masks[i] > 7) return fail(DMAD_ERR_INVALID, "mask %d = %d outside [0, 7]", i, masks[i]);
+        e->diag[i] = masks[i];
+    }
+    return 0;
+}
+
+int dmad_eval_samples(dmad_engine* e, const float* clip, float sigma, float sqrt_alpha_bar_star, int32_t t, float c_a, float c_b,
+                      uint64_t seed, uint64_t sample0, const float* delta, const int64_t* idx, int64_t n, int32_t path, float* logits_out,
+                      float* x0_out, dmad_stream s) {
+    if (!e || !clip || !idx || (!logits_out && !x0_out)) return fail(DMAD_ERR_INVALID, "null argument");
+    if (n < 0) return fail(DMAD_ERR_INVALID, "n < 0");
+    if (path != PATH_DEFAULT && path != PATH_FP32 && path != PATH_X3) return fail(DMAD_ERR_INVALID, "unknown path %d", path);
+    if (path != PATH_DEFAULT && !(e->bf16 && e->f32)) return fail(DMAD_ERR_STATE, "explicit WaveNet paths need a DMAD_EXACT engine");
+    if (logits_out && !e->cfg.with_classifier) return fail(DMAD_ERR_STATE, "engine was created with with_classifier = 0");
+    hipStream_t st = (hipStream_t)s;
+    const int L = e->L, C = e->cfg.num_classes;
+    const int cap = path == PATH_DEFAULT ? e->maxB : e->maxB32;
+    for (int64_t done = 0; done < n; done += cap) {
+        const int B = (int)(n - done < cap ? n - done : cap);
+        launch_mc_noise_scale_idx(clip, delta, sigma, sqrt_alpha_bar_star, seed, sample0, (const long long*)idx + done, e->xt, B, L, st);
+        CHK(wavenet_eps(e, e->xt, t, B, e->eps, st, path));
+        float* x0 = x0_out ? x0_out + done * L : e->x0;
+        launch_lincomb(0, e->xt, e->eps, nullptr, c_a, c_b, 0.f, x0, (long)B * L, st);
+        if (logits_out) {
+            CHK(mel_db(e, x0, B, e->spec, st));
+            CHK(classify(e, e->spec, B, logits_out + done * C, st));
+        }
+    }
+    LASTCHK();
+    return 0;
+}
+
 }  // extern "C"
 
 namespace {
@@ -1298,10 +1368,10 @@ int recheck_pass(dmad_engine* e, const RecheckJob& j, const long long* list, lon
         CHK(mel_db(e, e->x0, B, e->spec, st));
         CHK(classify(e, e->spec, B, e->logits, st));
         if (j.logits_out) launch_scatter_rows(e->logits, idx, (long long)j.sample0, j.logits_out, B, C, st);
-        if (tau >= 0.f) launch_vote_margin(e->logits, B, C, (unsigned long long*)j.counts, tau, 0, idx, next, e->rc_n, nullptr, st);
+        if (tau >= 0.f) launch_vote_margin(e->logits, B, C, (unsigned long long*)j.counts, tau, 0, idx, next, e->rc_n, e->rc_cap, nullptr, st);
         else launch_vote(e->logits, B, C, (unsigned long long*)j.counts, nullptr, st);
     }
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
@@ -1354,6 +1424,8 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
     const int L = e->L, C = e->cfg.num_classes;
     const bool recheck = e->bf16 && e->f32 && e->mode == DMAD_MODE_EXACT_VOTES && e->cfg.with_classifier;
     int64_t queued_from = 0;               // first sample (relative) of the current recheck segment
+    // an earlier call that failed between queueing and draining must not leave its indices to this one
+    if (recheck) HIPCHK(hipMemsetAsync(e->rc_n, 0, sizeof(unsigned long long), st));
     for (int64_t done = 0; done < n; done += batch) {
         const int B = (int)((n - done < batch) ? (n - done) : batch);
         launch_mc_noise_scale(clip, delta ? delta + done * L : nullptr, sigma, sqrt_alpha_bar_star, seed, sample0 + (uint64_t)done,
@@ -1367,7 +1439,7 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
             CHK(classify(e, e->spec, B, lg, st));
             if (recheck) {
                 launch_vote_margin(lg, B, C, (unsigned long long*)counts, e->tau, (long long)(sample0 + (uint64_t)done), nullptr, e->rc_list,
-                                   e->rc_n, nullptr, st);
+                                   e->rc_n, e->rc_cap, nullptr, st);
                 // the queue holds at most rc_cap indices: drain it before the samples voted since the last drain could overflow it
                 if (done + B - queued_from + batch > e->rc_cap && done + B < n) {
                     CHK(run_recheck(e, RecheckJob{clip, delta, sigma, sqrt_alpha_bar_star, t, c_a, c_b, seed, sample0, counts, logits_out, x0_out}, st));
@@ -1381,7 +1453,7 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
     if (recheck && n > 0)
         CHK(run_recheck(e, RecheckJob{clip, delta, sigma, sqrt_alpha_bar_star, t, c_a, c_b, seed, sample0, counts, logits_out, x0_out}, st));
     if (e->cfg.with_classifier) e->st_samples += n;
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
@@ -1412,7 +1484,7 @@ int dmad_spec_smooth_votes(dmad_engine* e, const float* clip, float sigma, int32
         CHK(classify(e, sp, B, lg, st));
         launch_vote(lg, B, C, (unsigned long long*)counts, nullptr, st);
     }
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
@@ -1444,21 +1516,21 @@ int dmad_query_logits(dmad_engine* e, const float* x, int32_t B, int32_t repeats
         CHK(classify(e, e->spec, nb, logits + r0 * C, st));
         if (decisions) launch_vote(logits + r0 * C, nb, C, nullptr, decisions + r0, st);
     }
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
 int dmad_philox_raw(dmad_engine* e, uint64_t seed, uint64_t sample, uint32_t stream, uint32_t nblocks, uint32_t* out, dmad_stream s) {
     if (!e || !out) return fail(DMAD_ERR_INVALID, "null argument");
     launch_philox_raw(seed, sample, stream, nblocks, out, (hipStream_t)s);
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 
 int dmad_philox_normal(dmad_engine* e, uint64_t seed, uint64_t sample0, uint32_t stream, int32_t B, float* z, dmad_stream s) {
     if (!e || !z || B < 1) return fail(DMAD_ERR_INVALID, "bad argument");
     launch_philox_normal(seed, sample0, stream, z, B, e->L, (hipStream_t)s);
-    HIPCHK(hipGetLastError());
+    LASTCHK();
     return 0;
 }
 

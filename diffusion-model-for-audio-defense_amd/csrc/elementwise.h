@@ -13,13 +13,13 @@ void launch_mc_noise_scale_idx(const float* clip, const float* delta, float sigm
 void launch_scatter_rows(const float* src, const long long* idx, long long base, float* dst, int B, int W, hipStream_t s);
 void launch_repeat_rows(const float* x, float* out, int B, long row0, int nrows, int L, hipStream_t s);
 void launch_vote_margin(const float* logits, int B, int C, unsigned long long* counts, float tau, long long sample_base,
-                        const long long* idx, long long* list, unsigned long long* list_n, int* pred_out, hipStream_t s);
+                        const long long* idx, long long* list, unsigned long long* list_n, long long list_cap, int* pred_out, hipStream_t s);
 void launch_embed_table(float t, const float* w1, const float* b1, const float* w2, const float* b2, const float* wt,
                         const float* bt, float* table, float* emb2_out, const float* b_res, float* epi_c, int NL, hipStream_t s);
 void launch_lincomb(int op, const float* x, const float* y, const float* z, float c0, float c1, float c2, float* out, long n,
                     hipStream_t s);
 void launch_wn_init_f32(const float* x, const float* w, const float* bias, const float* emb0, float* h, int B, int L, int LP,
-                        hipStream_t s, bool split = false);
+                        hipStream_t s, bool split = false, bool hi_only = false);
 void launch_scale(const float* x, float c, float* y, long n, hipStream_t s, bool split = false);
 void launch_dot256(const float* f, const float* w, float bias, float* out, long N, hipStream_t s);
 void launch_mel_pad(const float* x, float* xp, int B, int L, int LPm, hipStream_t s);

@@ -199,7 +199,7 @@ __global__ void lincomb_kernel(int op, const float* __restrict__ x, const float*
 // ----------------------------------------------------------------------------------------------
 template <bool SPLIT>      // SPLIT: write the split-f16 storage format (dmad_common.h) for the x3 GEMM tier
 __global__ void wn_init_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                   const float* __restrict__ emb0, float* __restrict__ h, int L, int LP, long total) {
+                                   const float* __restrict__ emb0, float* __restrict__ h, int L, int LP, long total, int hi_only) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 (4 channels) each
     if (idx >= total) return;
     const int c4 = (int)(idx & 63);
@@ -212,8 +212,11 @@ __global__ void wn_init_f32_kernel(const float* __restrict__ x, const float* __r
         const int c = c4 * 4 + j;
         po[j] = __fadd_rn(relu_nan(__fadd_rn(__fmul_rn(w[c], xv), bias[c])), emb0[c]);
     }
-    if (SPLIT) *(u32x4_t*)(h + ((bb * LP + kPad + t) * kC + c4 * 4)) = split4(o.x, o.y, o.z, o.w);
-    else *(float4*)(h + ((bb * LP + kPad + t) * kC + c4 * 4)) = o;
+    if (SPLIT) {
+        u32x4_t v = split4(o.x, o.y, o.z, o.w);
+        if (hi_only) { v[2] = 0u; v[3] = 0u; }      // error-attribution runs: the stored stream is f16 (GemmF32Args::diag bit 2)
+        *(u32x4_t*)(h + ((bb * LP + kPad + t) * kC + c4 * 4)) = v;
+    } else *(float4*)(h + ((bb * LP + kPad + t) * kC + c4 * 4)) = o;
 }
 
 template <bool SPLIT>
@@ -353,7 +356,7 @@ __global__ void vote_kernel(const float* __restrict__ logits, int B, int C, unsi
 // index sample_base + b is queued for the exact-fp32 re-evaluation (any NaN fails the comparison and is queued too).
 __global__ void vote_margin_kernel(const float* __restrict__ logits, int B, int C, unsigned long long* __restrict__ counts,
                                    float tau, long long sample_base, const long long* __restrict__ idx, long long* __restrict__ list,
-                                   unsigned long long* __restrict__ list_n, int* __restrict__ pred_out) {
+                                   unsigned long long* __restrict__ list_n, long long list_cap, int* __restrict__ pred_out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     int best = 0;
@@ -369,8 +372,9 @@ __global__ void vote_margin_kernel(const float* __restrict__ logits, int B, int 
     if (!nan && (C == 1 || bv - second >= tau)) {
         atomicAdd(&counts[best], 1ull);
     } else {
+        // the counter keeps counting past the capacity (the host reads it and reports the overflow); nothing is written there
         const unsigned long long slot = atomicAdd(list_n, 1ull);
-        list[slot] = idx ? idx[b] : sample_base + b;     // row b is global sample idx[b] (a recheck pass) or sample_base + b
+        if (slot < (unsigned long long)list_cap) list[slot] = idx ? idx[b] : sample_base + b;     // row b is global sample idx[b] (a recheck pass) or sample_base + b
     }
 }
 
@@ -401,9 +405,9 @@ void launch_repeat_rows(const float* x, float* out, int B, long row0, int nrows,
     hipLaunchKernelGGL(repeat_rows_kernel, dim3(nblk(total4, 256)), dim3(256), 0, s, x, out, B, row0, L, total4);
 }
 void launch_vote_margin(const float* logits, int B, int C, unsigned long long* counts, float tau, long long sample_base,
-                        const long long* idx, long long* list, unsigned long long* list_n, int* pred_out, hipStream_t s) {
+                        const long long* idx, long long* list, unsigned long long* list_n, long long list_cap, int* pred_out, hipStream_t s) {
     hipLaunchKernelGGL(vote_margin_kernel, dim3(nblk(B, 64)), dim3(64), 0, s, logits, B, C, counts, tau, sample_base, idx, list, list_n,
-                       pred_out);
+                       list_cap, pred_out);
 }
 void launch_embed_table(float t, const float* w1, const float* b1, const float* w2, const float* b2, const float* wt,
                         const float* bt, float* table, float* emb2_out, const float* b_res, float* epi_c, int NL, hipStream_t s) {
@@ -414,10 +418,10 @@ void launch_lincomb(int op, const float* x, const float* y, const float* z, floa
     hipLaunchKernelGGL(lincomb_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, op, x, y, z, c0, c1, c2, out, n);
 }
 void launch_wn_init_f32(const float* x, const float* w, const float* bias, const float* emb0, float* h, int B, int L, int LP,
-                        hipStream_t s, bool split) {
+                        hipStream_t s, bool split, bool hi_only) {
     const long total = (long)B * L * 64;
-    if (split) hipLaunchKernelGGL(wn_init_f32_kernel<true>, dim3(nblk(total, 256)), dim3(256), 0, s, x, w, bias, emb0, h, L, LP, total);
-    else hipLaunchKernelGGL(wn_init_f32_kernel<false>, dim3(nblk(total, 256)), dim3(256), 0, s, x, w, bias, emb0, h, L, LP, total);
+    if (split) hipLaunchKernelGGL(wn_init_f32_kernel<true>, dim3(nblk(total, 256)), dim3(256), 0, s, x, w, bias, emb0, h, L, LP, total, hi_only ? 1 : 0);
+    else hipLaunchKernelGGL(wn_init_f32_kernel<false>, dim3(nblk(total, 256)), dim3(256), 0, s, x, w, bias, emb0, h, L, LP, total, 0);
 }
 void launch_scale(const float* x, float c, float* y, long n, hipStream_t s, bool split) {
     if (split) hipLaunchKernelGGL(scale_kernel<true>, dim3(nblk(n / 4, 256)), dim3(256), 0, s, x, c, y, n / 4);

@@ -41,12 +41,17 @@ struct GemmF32Args {
     // storage format (dmad_common.h) and every product is three v_mfma_f32_16x16x32_f16; outputs that feed another GEMM
     // (epi 1: the gate, epi 2: hout) are written in that format, everything else (plain C, the skip sum) stays fp32.
     int x3;
+    int diag;             // x3 only, error-attribution builds: bit 0 weights = f16(w), bit 1 the MFMA eats f16(x), bit 2 split-format outputs keep hi only
     int splits;           // > 1: split-K over grid.z; partial sums go to `slab` [splits][N][ldc] (fixed-order reduce)
     float* slab;
 };
 
 // `slab` (device workspace of `slab_floats` floats) enables deterministic split-K for launches that would not
 // fill the chip (deep VGG layers at small spatial size, batch-sized Linear layers); pass nullptr to disable.
-void launch_gemm_f32(const GemmF32Args& a, hipStream_t s, float* slab = nullptr, long slab_floats = 0, long n_ref = 0);
+// Returns 0, or kGemmBadShape for an argument block no kernel serves (nothing is launched; the caller reports it).
+constexpr int kGemmBadShape = -1;
+int launch_gemm_f32(const GemmF32Args& a, hipStream_t s, float* slab = nullptr, long slab_floats = 0, long n_ref = 0);
+int gemm_take_bad_shapes();   // number of launches refused on this thread since the last call (reset to 0)
+int gemm_x3_configure();      // per device, from dmad_create: dynamic-LDS attribute of the split-f16 kernel (0 or a hipError_t)
 
 }  // namespace dmad

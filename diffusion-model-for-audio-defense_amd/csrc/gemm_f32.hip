@@ -17,8 +17,6 @@
 // MFMA j in BOTH operands, so each MFMA still contracts 4 distinct k and the 4 together cover the 16.  Rows outside the
 // problem (conv zero padding, M / N tails) are fetched from a zero page.  3-slot LDS ring, counted vmcnt, one barrier
 // per k-step, no register staging.
-#include <stdlib.h>
-
 #include "gemm_f32.h"
 
 namespace dmad {
@@ -267,8 +265,14 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
 // X 2 x 8 KiB), 3-pair ring = 144 KiB of dynamic LDS: two pairs in flight while one is contracted, one barrier per pair.
 // ----------------------------------------------------------------------------------------------------------------
 constexpr int X3_BM = 256, X3_STAGE = 24576, X3_PAIR = 2 * X3_STAGE, X3_LDS = 3 * X3_PAIR;
+// DIAG (error-attribution builds of tools/gpu_error_attribution.py, never the product launches): GemmF32Args::diag switches
+// single roundings of the 16-bit path on inside this fp32-grade pipeline — bit 0: the weights' lo parts are ignored (weights
+// = f16(w)), bit 1: the activations' lo parts are ignored (the MFMA eats f16(x), the stored value keeps its 22 bits), bit 2:
+// outputs in the split format are written with lo = 0 (the stored gate / residual stream is f16).
+template <bool DIAG>
 __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
     constexpr int BM = X3_BM, MT = 4;
+    const bool drop_alo = DIAG && (a.diag & 1), drop_blo = DIAG && (a.diag & 2), hi_only = DIAG && (a.diag & 4);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -326,8 +330,8 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], bhi, acc[i][j], 0, 0, 0);
-                cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], blo, cor[i][j], 0, 0, 0);
-                cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[i], bhi, cor[i][j], 0, 0, 0);
+                if (!drop_blo) cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], blo, cor[i][j], 0, 0, 0);
+                if (!drop_alo) cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[i], bhi, cor[i][j], 0, 0, 0);
             }
         }
         slot = slot == 2 ? 0 : slot + 1;
@@ -361,7 +365,9 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
                     const float pp = 1.f + u, rr = fast_rcp(pp * w + pp);
                     v[r] = rr - u * rr;
                 }
-                *(u32x4_t*)(a.C + n * 256 + ch) = split4(v[0], v[1], v[2], v[3]);
+                u32x4_t gs = split4(v[0], v[1], v[2], v[3]);
+                if (hi_only) { gs[2] = 0u; gs[3] = 0u; }
+                *(u32x4_t*)(a.C + n * 256 + ch) = gs;
             }
         }
         return;
@@ -388,8 +394,10 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
                     float h[4];
                     join4(*(const u32x4_t*)(a.hin + hoff), h);
                     const float k = 0.70710678118654752440f;
-                    *(u32x4_t*)(a.hout + hoff) = split4(__fadd_rn(__fmul_rn(__fadd_rn(h[0], v[0]), k), ea[0]), __fadd_rn(__fmul_rn(__fadd_rn(h[1], v[1]), k), ea[1]),
-                                                         __fadd_rn(__fmul_rn(__fadd_rn(h[2], v[2]), k), ea[2]), __fadd_rn(__fmul_rn(__fadd_rn(h[3], v[3]), k), ea[3]));
+                    u32x4_t hs = split4(__fadd_rn(__fmul_rn(__fadd_rn(h[0], v[0]), k), ea[0]), __fadd_rn(__fmul_rn(__fadd_rn(h[1], v[1]), k), ea[1]),
+                                        __fadd_rn(__fmul_rn(__fadd_rn(h[2], v[2]), k), ea[2]), __fadd_rn(__fmul_rn(__fadd_rn(h[3], v[3]), k), ea[3]));
+                    if (hi_only) { hs[2] = 0u; hs[3] = 0u; }
+                    *(u32x4_t*)(a.hout + hoff) = hs;
                 } else {
                     float4* ps = (float4*)(a.skip + n * 256 + (m - a.res_rows));
                     if (a.first) {
@@ -433,21 +441,29 @@ __global__ void gemm_f32_reduce_kernel(GemmF32Args a) {
     a.C[n * a.ldc + m] = a.relu ? relu_nan(t) : t;
 }
 
-void launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab_floats, long n_ref) {
+namespace { thread_local int g_bad_shapes = 0; }
+// launches refused since the last call (and reset): the C ABI turns a non-zero count into DMAD_ERR_INVALID at the end of the entry point
+int gemm_take_bad_shapes() { const int n = g_bad_shapes; g_bad_shapes = 0; return n; }
+
+// once per device a process uses (dmad_create): the x3 tier's 144 KiB of dynamic LDS
+int gemm_x3_configure() {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipFuncSetAttribute((const void*)gemm_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+}
+
+int launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab_floats, long n_ref) {
     GemmF32Args a = a0;
     if (a.x3) {                                   // split-f16 operands: WaveNet shapes only (checked here, not in the kernel)
         const int nks = a.taps * (a.K / BK);
-        if (a.mode != 0 || (a.M % X3_BM) || (nks & 1) || a.scale || a.res || a.groups > 1 || (a.ldc & 3)) abort();
-        static bool configured = false;
-        if (!configured) {
-            if (hipFuncSetAttribute((const void*)gemm_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS) != hipSuccess) abort();
-            configured = true;
-        }
+        if (a.mode != 0 || (a.M % X3_BM) || (nks & 1) || a.scale || a.res || a.groups > 1 || (a.ldc & 3)) { ++g_bad_shapes; return kGemmBadShape; }
         a.splits = 1; a.slab = nullptr;
-        hipLaunchKernelGGL(gemm_x3_kernel, dim3((unsigned)((a.N + BN - 1) / BN), (unsigned)(a.M / X3_BM)), dim3(512), X3_LDS, s, a);
-        return;
+        const dim3 grid((unsigned)((a.N + BN - 1) / BN), (unsigned)(a.M / X3_BM));
+        if (a.diag) hipLaunchKernelGGL(gemm_x3_kernel<true>, grid, dim3(512), X3_LDS, s, a);
+        else hipLaunchKernelGGL(gemm_x3_kernel<false>, grid, dim3(512), X3_LDS, s, a);
+        return 0;
     }
-    if (a.X2 && (a.mode != 2 || a.groups > 1 || a.M <= 64 || (a.ksplit % BK) || a.ksplit <= 0 || a.ksplit >= a.K)) abort();   // two-part input: plain NHWC convs only
+    if (a.X2 && (a.mode != 2 || a.groups > 1 || a.M <= 64 || (a.ksplit % BK) || a.ksplit <= 0 || a.ksplit >= a.K)) { ++g_bad_shapes; return kGemmBadShape; }   // two-part input: plain NHWC convs only
     const int BM = a.M <= 64 ? 64 : 128;          // 64-row tiles where a 128-row tile would be half empty
     const unsigned gx = (unsigned)((a.N + BN - 1) / BN), gy = (unsigned)((a.M + BM - 1) / BM);
     const int nks = a.taps * (a.K / BK);
@@ -461,7 +477,7 @@ void launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long sla
         a.splits = 1;
         a.slab = nullptr;
         launch(dim3(gx, gy, (unsigned)a.groups));
-        return;
+        return 0;
     }
     if (slab) {
         // The split count is derived from the REFERENCE row count n_ref (the engine's max batch), not from the
@@ -482,6 +498,7 @@ void launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long sla
         const long total = a.N * a.M;
         hipLaunchKernelGGL(gemm_f32_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
     }
+    return 0;
 }
 
 }  // namespace dmad

@@ -1,9 +1,12 @@
 """SC09 evaluation index used by the certification driver (contract of the reference's datasets/sc_dataset.py:90-134,
 consumer certified_robustness_eval.py:99-106): `SC09Dataset(folder, transform, classes, num_per_class)` lists, for every
 digit sub-folder of `folder`, its first `num_per_class` directory entries in `os.listdir` order; item i is
-`transform({'path': ..., 'target': class index})`.  Every class but the last two must be present."""
+`transform({'path': ..., 'target': class index})`.  Every class but the last two must be present.
+`make_weights_for_balanced_classes()` (reference :136-149; its training scripts feed it to a WeightedRandomSampler,
+audio_models/M5/train.py:45) returns one float64 weight per item, N / (items of the item's class)."""
 import os
 
+import numpy as np
 from torch.utils.data import Dataset
 
 __all__ = ['CLASSES', 'SC09_CLASSES', 'SC09Dataset']
@@ -30,3 +33,9 @@ class SC09Dataset(Dataset):
         path, target = self.data[index]
         item = {'path': path, 'target': target}
         return item if self.transform is None else self.transform(item)
+
+    def make_weights_for_balanced_classes(self):
+        targets = np.fromiter((t for _, t in self.data), dtype=np.int64, count=len(self.data))
+        per_class = np.bincount(targets, minlength=len(self.classes)).astype(np.float64)
+        with np.errstate(divide='ignore'):          # an absent class gets an infinite weight nobody is assigned (as in the reference)
+            return (float(len(self.data)) / per_class)[targets]

@@ -16,9 +16,13 @@ class DmadError(RuntimeError):
 
 
 class DmadConfig(C.Structure):
+    """dmad_config of include/dmad.h; positional arguments are the fields AFTER struct_size, which is filled in here."""
     _fields_ = [(n, C.c_int32) for n in (
-        'res_channels', 'skip_channels', 'num_res_layers', 'dilation_cycle', 'embed_dim_in', 'embed_dim_mid',
+        'struct_size', 'res_channels', 'skip_channels', 'num_res_layers', 'dilation_cycle', 'embed_dim_in', 'embed_dim_mid',
         'embed_dim_out', 'clip_len', 'max_batch', 'num_classes', 'precision', 'with_classifier', 'recheck_batch', 'half_type')]
+
+    def __init__(self, *fields, **named):
+        super().__init__(C.sizeof(type(self)), *fields, **named)
 
 
 _P = C.c_void_p
@@ -27,6 +31,7 @@ _SIGNATURES = {
     'dmad_destroy': (None, [_P]),
     'dmad_last_error': (C.c_char_p, []),
     'dmad_version': (C.c_char_p, []),
+    'dmad_last_warning': (C.c_char_p, []),
     'dmad_load_weight': (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32]),
     'dmad_finalize_weights': (C.c_int, [_P]),
     'dmad_wavenet_eps': (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
@@ -48,6 +53,9 @@ _SIGNATURES = {
     'dmad_set_recheck_margin2': (C.c_int, [_P, C.c_float]),
     'dmad_recheck_stats': (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
     'dmad_wavenet_eps_path': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    'dmad_eval_samples': (C.c_int, [_P, _P, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _P, _P, C.c_int64,
+                                    C.c_int32, _P, _P, _P]),
+    'dmad_debug_rounding': (C.c_int, [_P, C.POINTER(C.c_int32)]),
     'dmad_query_logits': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P,
                                     C.c_uint64, C.c_uint64, _P, _P, _P]),
     'dmad_spec_smooth_votes': (C.c_int, [_P, _P, C.c_float, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, _P, C.c_float, C.c_float,

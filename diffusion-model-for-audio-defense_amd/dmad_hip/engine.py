@@ -7,6 +7,7 @@ from __future__ import annotations
 import ctypes as C
 import hashlib
 import os
+import warnings
 from typing import Dict, Optional
 
 import numpy as np
@@ -29,6 +30,10 @@ DEFAULT_RECHECK_MARGIN = {1: 0.034, 0: 0.30}          # by dmad_half_type: HALF_
 # The queued samples first go through the split-f16 tier (fp32 pipeline, three f16 MFMAs per product, ~22 significant bits);
 # only those whose margin is inside ITS error bound reach the exact-fp32 path.
 DEFAULT_RECHECK_MARGIN2 = 1e-3
+# Tail rule shared by the committed default and calibrate_recheck (tools/fit_recheck_tail.py): with s the
+# Gaussian scale of the per-sample leader-difference error, a bound of TAIL_Z * s keeps the modelled miss probability per
+# sample (error beyond the bound AND an exact margin small enough to be overturned) at or below 1e-9.
+TAIL_Z = 5.4
 VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
 
 
@@ -184,6 +189,7 @@ class Engine:
         self.wavenet_owner = self.classifier_owner = self.unet_owner = None
         self.classifier_kind = None
         self.mode = {BF16: MODE_FAST, FP32: MODE_FP32, EXACT: MODE_EXACT_VOTES}[precision]
+        self.calibration = None                # what the last calibrate_recheck() observed
         if precision == EXACT:
             if recheck_margin is None:
                 recheck_margin = float(os.environ.get('DMAD_RECHECK_MARGIN', DEFAULT_RECHECK_MARGIN[half_type]))
@@ -209,6 +215,9 @@ class Engine:
             shape = (C.c_int64 * a.ndim)(*a.shape)
             check(self.lib.dmad_load_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
         check(self.lib.dmad_finalize_weights(self._h))
+        note = self.lib.dmad_last_warning()
+        if note:
+            warnings.warn('dmad engine: ' + note.decode(), RuntimeWarning, stacklevel=3)
 
     def load_wavenet(self, state_dict):
         if self.has_wavenet:
@@ -257,41 +266,86 @@ class Engine:
         check(self.lib.dmad_recheck_stats(self._h, C.byref(a), C.byref(b), C.byref(c), 1 if reset else 0))
         return (int(a.value), int(b.value), int(c.value)) if detail else (int(a.value), int(b.value))
 
-    def calibrate_recheck(self, clip: torch.Tensor, sigma: float, sqrt_abar_star: float, t: int, c_a: float, c_b: float,
-                          n: int = 1024, n_fp32: int = 128, headroom: float = 1.5, seed: int = 0xCA11B):
+    def calibrate_recheck(self, clip, sigma: float, sqrt_abar_star: float, t: int, c_a: float, c_b: float,
+                          n: int = 1024, n_fp32: int = 512, headroom: float = 1.5, seed: int = 0xCA11B):
         """Measure, for THE RESIDENT WEIGHTS, what the defaults were measured for on the synthetic VGG19_bn (see
-        DEFAULT_RECHECK_MARGIN): the largest error the 16-bit pass makes on a logit difference against the leader (vs the split-f16 tier, n
-        Philox samples of `clip` at this sigma) and the largest error of the split-f16 tier (against the exact-fp32 path,
-        n_fp32 samples), and set the two recheck bounds to `headroom` x those (the tier-1 bound also covers tier 2's own error,
-        since tier 1 is measured against tier 2).  The logit sensitivity of a classifier — hence the error a given eps error
-        turns into — is a property of its weights: call this once per (WaveNet, classifier, sigma) before certifying with
-        checkpoints other than the ones the defaults were measured on.  Returns (tau1, tau2, e1, e2)."""
+        DEFAULT_RECHECK_MARGIN): the largest error the 16-bit pass makes on a logit difference against the leader (vs the split-f16
+        tier, n Philox samples per clip at this sigma) and the largest error of the split-f16 tier (against the exact-fp32 path,
+        n_fp32 samples per clip).  `clip`: one clip or a list of clips (the maxima are taken over all of them).  The bounds become
+            tau2 = max(committed default, headroom * e2),
+            tau1 = max(committed default, headroom * e1 + tau2, TAIL_Z * s1 + tau2),
+        s1 = the Gaussian scale of the per-sample error statistic read off its upper quantiles (q90, q99 of max_j |e_j - e_i|
+        ~ the maximum of 9 normal differences): TAIL_Z * s1 is where the tail model of tools/fit_recheck_tail.py puts the
+        per-sample miss probability at 1e-9 (on the committed study: 5.4 x 0.0056 = 0.030 < 0.034).
+        A calibration can only WIDEN a bound — a maximum over a few hundred samples underestimates the tail the committed
+        defaults were derived from (36 864 samples), so it is never allowed to go below them.  The logit sensitivity of a
+        classifier — hence the error a given eps error turns into — is a property of its weights: call this once per
+        (WaveNet, classifier, sigma) before certifying with checkpoints other than the ones the defaults were measured on.
+        Returns (tau1, tau2, e1, e2); the observed errors are also kept in self.calibration."""
         if self.precision != EXACT:
             raise DmadError('calibrate_recheck needs an EXACT engine')
+        clips = list(clip) if isinstance(clip, (list, tuple)) else [clip]
         mode, tau1, tau2 = self.mode, self.recheck_margin, self.recheck_margin2
-        args = (clip, sigma, sqrt_abar_star, t, c_a, c_b)
+        n_fp32 = min(n_fp32, n)
 
-        def pair_err(a, b):                  # largest error of a logit difference against the reference's leader (see DEFAULT_RECHECK_MARGIN)
+        def lead_err(a, b):                  # per-sample error of a logit difference against the reference's leader (see DEFAULT_RECHECK_MARGIN)
             e = a - b
-            return float((e - e.gather(1, b.argmax(1, keepdim=True))).abs().max())
+            return (e - e.gather(1, b.argmax(1, keepdim=True))).abs().max(1).values
+
+        def pair_err(a, b):
+            return float(lead_err(a, b).max())
+
+        def gauss_scale(le):                 # P(max of 9 |normal differences| > x) ~= 18 Q(x / s): s from the q90 and q99 points
+            zs = {0.9: 2.5392, 0.99: 3.2579}            # 18 Q(z) = 1 - q
+            return max(float(torch.quantile(le, q)) / z for q, z in zs.items())
+        e1 = e2 = s1 = 0.0
         try:
-            self.set_mode(MODE_FAST)
-            _, fast, _ = self.smooth_votes(*args, n, seed=seed, want_logits=True)
-            self.set_mode(MODE_EXACT_VOTES)
-            self.set_recheck_margin(1e30); self.set_recheck_margin2(0.0)       # every sample through tier 2, none beyond
-            _, mid, _ = self.smooth_votes(*args, n, seed=seed, want_logits=True)
-            self.set_mode(MODE_FP32)
-            _, ref, _ = self.smooth_votes(*args, n_fp32, seed=seed, want_logits=True)
+            for ci, x in enumerate(clips):
+                args = (x, sigma, sqrt_abar_star, t, c_a, c_b)
+                idx = torch.arange(n, dtype=torch.int64, device=self.device)
+                self.set_mode(MODE_FAST)
+                fast = self.eval_samples(*args, idx, path=0, seed=seed + ci)
+                mid = self.eval_samples(*args, idx, path=2, seed=seed + ci)
+                ref = self.eval_samples(*args, idx[:n_fp32], path=1, seed=seed + ci)
+                if not (bool(torch.isfinite(fast).all()) and bool(torch.isfinite(mid).all()) and bool(torch.isfinite(ref).all())):
+                    raise DmadError('calibrate_recheck: non-finite logits')
+                le1 = lead_err(fast.double(), mid.double())
+                e1, s1 = max(e1, float(le1.max())), max(s1, gauss_scale(le1))
+                e2 = max(e2, pair_err(mid[:n_fp32].double(), ref.double()))
         finally:
-            self.set_mode(mode); self.set_recheck_margin(tau1); self.set_recheck_margin2(tau2)
-        self.recheck_stats(reset=True)
-        if not (bool(torch.isfinite(fast).all()) and bool(torch.isfinite(mid).all()) and bool(torch.isfinite(ref).all())):
-            raise DmadError('calibrate_recheck: non-finite logits')
-        e1, e2 = pair_err(fast.double(), mid.double()), pair_err(mid[:n_fp32].double(), ref.double())
-        new2 = max(headroom * e2, 1e-6)
-        new1 = headroom * e1 + new2
+            self.set_mode(mode)
+        floor1 = DEFAULT_RECHECK_MARGIN[self.half_type]
+        new2 = max(DEFAULT_RECHECK_MARGIN2, headroom * e2)
+        new1 = max(floor1, headroom * e1 + new2, TAIL_Z * s1 + new2)
         self.set_recheck_margin(new1); self.set_recheck_margin2(new2)
+        self.calibration = {'e1': e1, 'e2': e2, 's1': s1, 'tau1': new1, 'tau2': new2, 'n': n, 'n_fp32': n_fp32, 'clips': len(clips),
+                            'headroom': headroom, 'floor1': floor1, 'floor2': DEFAULT_RECHECK_MARGIN2,
+                            'previous': (tau1, tau2)}
         return new1, new2, e1, e2
+
+    def eval_samples(self, clip: torch.Tensor, sigma: float, sqrt_abar_star: float, t: int, c_a: float, c_b: float,
+                     idx: torch.Tensor, path: int = 0, seed: int = 0, sample0: int = 0, delta: Optional[torch.Tensor] = None,
+                     want_x0: bool = False):
+        """dmad_eval_samples: logits [len(idx), C] (and x0 [len(idx), L] when asked) of the Monte Carlo samples with GLOBAL indices
+        `idx` (int64, device) on WaveNet path 0 (the mode's default) / 1 (exact fp32) / 2 (split-f16).  Nothing votes."""
+        clip = clip.detach().reshape(-1).contiguous().float()
+        assert clip.is_cuda and clip.numel() == self.L
+        idx = idx.detach().to(device=clip.device, dtype=torch.int64).contiguous()
+        n = idx.numel()
+        logits = torch.empty((n, self.num_classes), device=clip.device)
+        x0 = torch.empty((n, self.L), device=clip.device) if want_x0 else None
+        if delta is not None:
+            delta = delta.detach().reshape(-1, self.L).contiguous().float()
+            assert delta.is_cuda
+        check(self.lib.dmad_eval_samples(self._h, _ptr(clip), float(sigma), float(sqrt_abar_star), int(t), float(c_a), float(c_b),
+                                         int(seed), int(sample0), _ptr(delta), _ptr(idx), int(n), int(path), _ptr(logits), _ptr(x0),
+                                         _stream()))
+        return (logits, x0) if want_x0 else logits
+
+    def debug_rounding(self, dil: int = 0, res: int = 0, skip: int = 0, f0: int = 0, init: int = 0):
+        """dmad_debug_rounding (measurement hook): single roundings of the 16-bit path switched on inside the split-f16 tier."""
+        m = (C.c_int32 * 5)(int(dil), int(res), int(skip), int(f0), int(init))
+        check(self.lib.dmad_debug_rounding(self._h, m))
 
     def wavenet_eps_path(self, x_t: torch.Tensor, t: int, path: int) -> torch.Tensor:
         """eps-network on an explicit path of an EXACT engine: 0 mode default, 1 exact fp32, 2 split-f16 (three MFMAs per product)."""

@@ -34,7 +34,8 @@ def _dist():
 class RobustCertificate():
 
     def __init__(self, classifier: torch.nn.Module, transform=None, denoiser=None, one_shot_rev: bool = False,
-                 num_classes=10, noise_source: str = 'device', seed: int = None, shard: bool = True, calibrate: int = 0) -> None:
+                 num_classes=10, noise_source: str = 'device', seed: int = None, shard: bool = True, calibrate: int = 0,
+                 calibrate_clips: int = 3, log=None) -> None:
         self.classifier = classifier
         self.transform = transform
         self.denoiser = denoiser
@@ -45,11 +46,18 @@ class RobustCertificate():
         self.seed = seed
         self.shard = shard
         self._calls = 0
-        # calibrate = n > 0: before the first fused smooth_predict at each sigma, measure the recheck bounds of the exact-vote
-        # engine for the resident weights on n samples of the clip at hand (Engine.calibrate_recheck) instead of using the
-        # defaults measured on the synthetic VGG19_bn; the certification driver switches it on (real checkpoints)
+        # calibrate = n > 0: before the fused smooth_predict of the first `calibrate_clips` clips at each sigma, measure the
+        # recheck bounds of the exact-vote engine for the resident weights on n samples of the clip at hand
+        # (Engine.calibrate_recheck: it can only WIDEN a bound, never go below the committed defaults) — the defaults were
+        # measured on the synthetic VGG19_bn; the certification driver switches it on (real checkpoints).  `log`: callable
+        # that receives one line per calibration / audit (the driver passes its logger).
         self.calibrate = int(calibrate)
-        self._calibrated = {}
+        self.calibrate_clips = max(1, int(calibrate_clips))
+        self._calibrated = {}                   # t -> (tau1, tau2, e1, e2): the widest bounds / largest errors seen so far
+        self._calibrated_clips = {}             # t -> clips measured
+        self.log = log
+        self._last = None                       # (seed, sigma, coeffs, n) of the last fused smooth_predict, for audit()
+        self.audit_log = []                     # one dict per audited smooth_predict
 
     # ------------------------------------------------------------------------------------------
     def _fused(self):
@@ -139,9 +147,21 @@ class RobustCertificate():
         fused = self._fused()
         if fused and self.calibrate > 0:
             eng = self.denoiser.engine
-            if getattr(eng, 'precision', None) == 2 and coeffs[0] not in self._calibrated:      # EXACT engines, once per t*
-                self._calibrated[coeffs[0]] = eng.calibrate_recheck(x, sigma, coeffs[3], coeffs[0], coeffs[1], coeffs[2], n=self.calibrate,
-                                                                    n_fp32=max(16, self.calibrate // 8))
+            tk = coeffs[0]
+            if getattr(eng, 'precision', None) == 2 and self._calibrated_clips.get(tk, 0) < self.calibrate_clips:    # EXACT engines
+                new = eng.calibrate_recheck(x, sigma, coeffs[3], tk, coeffs[1], coeffs[2], n=self.calibrate, n_fp32=max(16, self.calibrate // 2))
+                old = self._calibrated.get(tk)
+                if old is not None:             # the bounds of a sigma only widen from clip to clip
+                    new = (max(new[0], old[0]), max(new[1], old[1]), max(new[2], old[2]), max(new[3], old[3]))
+                    eng.set_recheck_margin(new[0]); eng.set_recheck_margin2(new[1])
+                self._calibrated[tk] = new
+                self._calibrated_clips[tk] = self._calibrated_clips.get(tk, 0) + 1
+                if self.log is not None:
+                    self.log('recheck bounds at sigma=%g (t*=%d), clip %d of %d: observed 16-bit error %.4g, split-f16 error %.3g -> tau1 %.4g, tau2 %.3g'
+                             % (sigma, tk + 1, self._calibrated_clips[tk], self.calibrate_clips, new[2], new[3], new[0], new[1]))
+            elif getattr(eng, 'precision', None) == 2 and tk in self._calibrated:
+                eng.set_recheck_margin(self._calibrated[tk][0]); eng.set_recheck_margin2(self._calibrated[tk][1])    # another sigma ran in between
+        self._last = (seed, sigma, coeffs, num_sampling) if (fused and self.noise_source == 'device') else None
         if self.noise_source == 'torch_cpu':
             # The reference's stream: one CPU torch.normal draw per batch (ref l.47).  The stream is batch-split invariant,
             # so every rank draws the whole stream, keeps its own slice of each batch and feeds it to the engine batch by
@@ -215,14 +235,58 @@ class RobustCertificate():
         return counts
 
     @torch.no_grad()
+    def audit(self, x: torch.Tensor, k: int):
+        """Opt-in check of the exact-vote mode on the LAST fused smooth_predict(x, ...): k of its Monte Carlo samples (drawn
+        without replacement from the global index range, the same on every rank) are evaluated on the 16-bit tier; those that
+        VOTED there (margin >= the recheck bound) are re-evaluated on the split-f16 tier from the same Philox keys, and every
+        sample whose arg-max differs is reported.  Returns (and appends to self.audit_log) a dict: audited, voted_on_tier1,
+        disagreements [(sample index, tier-1 class, tier-2 class, tier-1 margin)], largest leader-difference error seen, tau1."""
+        if self._last is None:
+            raise RuntimeError('audit() follows a fused smooth_predict with device noise on an exact-vote engine')
+        seed, sigma, coeffs, n = self._last
+        eng = self.denoiser.engine
+        if getattr(eng, 'precision', None) != 2:
+            raise RuntimeError('audit() needs an exact-vote (DMAD_EXACT) engine')
+        k = min(int(k), n)
+        g = torch.Generator().manual_seed(seed & 0x7FFFFFFFFFFFFFFF)
+        idx = torch.randperm(n, generator=g)[:k].sort()[0].to(x.device)
+        args = (x, sigma, coeffs[3], coeffs[0], coeffs[1], coeffs[2])
+        mode = eng.mode
+        try:
+            eng.set_mode(0)                         # path 0 = the 16-bit tier
+            fast = eng.eval_samples(*args, idx, path=0, seed=seed)
+        finally:
+            eng.set_mode(mode)
+        top2 = fast.topk(2, dim=1)
+        margin = top2.values[:, 0] - top2.values[:, 1]
+        voted = (margin >= eng.recheck_margin) & torch.isfinite(fast).all(1)
+        vidx = idx[voted]
+        rec = {'audited': int(k), 'voted_on_tier1': int(vidx.numel()), 'disagreements': [], 'max_leader_diff_error': 0.0,
+               'tau1': eng.recheck_margin, 'sigma': sigma}
+        if vidx.numel():
+            mid = eng.eval_samples(*args, vidx, path=2, seed=seed)
+            f = fast[voted]
+            e = (f - mid).double()
+            rec['max_leader_diff_error'] = float((e - e.gather(1, mid.argmax(1, keepdim=True))).abs().max())
+            bad = (f.argmax(1) != mid.argmax(1)).nonzero().reshape(-1)
+            rec['disagreements'] = [(int(vidx[j]), int(f[j].argmax()), int(mid[j].argmax()), float(margin[voted][j])) for j in bad.tolist()]
+        self.audit_log.append(rec)
+        if self.log is not None:
+            self.log('audit: %d samples, %d voted on the 16-bit tier, %d disagree with the split-f16 tier, largest leader-difference error %.4g (tau1 %.4g)'
+                     % (rec['audited'], rec['voted_on_tier1'], len(rec['disagreements']), rec['max_leader_diff_error'], rec['tau1']))
+        return rec
+
+    @torch.no_grad()
     def certify(self, x: torch.Tensor, y: torch.Tensor, sigma: float = 0.25, n_0: int = 100, n: int = 100000,
-                alpha: float = 0.001, batch_size: int = 64):
+                alpha: float = 0.001, batch_size: int = 64, audit: int = 0):
         y_pred, radius = -torch.ones_like(y), torch.zeros_like(y, dtype=torch.float32)
         for i in range(x.shape[0]):
             x_in = x[i]
             counts_0 = self.smooth_predict(x_in, num_sampling=n_0, sigma=sigma, batch_size=batch_size)
             c_A = counts_0.max(0, keepdim=True)[1].item()
             counts = self.smooth_predict(x_in, num_sampling=n, sigma=sigma, batch_size=batch_size)
+            if audit > 0 and self._last is not None:       # opt-in: re-evaluate `audit` tier-1 voters of this example on tier 2
+                self.audit(x_in, audit)
             pa = self.lower_conf_bound(k=counts[c_A], n=n, alpha=alpha)
             if pa > 0.5:
                 y_pred[i] = c_A

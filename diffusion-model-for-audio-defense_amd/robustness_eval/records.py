@@ -1,7 +1,9 @@
 """Per-example certification records in the reference's format (certified_robustness_eval.py:126-146):
 a JSON list of {'id', 'y_true', 'y_pred', 'certified_radius'} at
 `<save_path>/sigma=<sigma>/sigma=<sigma>_N=<num_sampling>.json`, rewritten after every batch (indent=4).
-`resume=True` reloads an existing file so that an interrupted N = 100 000 run continues after its last record."""
+`resume=True` reloads an existing file so that an interrupted N = 100 000 run continues after its last record.
+`append_batch(..., extra=[{...}, ...])` merges one dict of additional keys into each record (the driver's opt-in
+`--audit` outcome); without it the records carry exactly the reference's four keys."""
 import json
 import os
 
@@ -21,14 +23,17 @@ class CertificationRecords:
     def __len__(self):
         return len(self.records)
 
-    def append_batch(self, targets, y_certified, r_certified):
+    def append_batch(self, targets, y_certified, r_certified, extra=None):
         """Same fields and id numbering as the reference's loop body (id = running example index)."""
         total = len(self.records)
         for i in range(len(targets)):
-            self.records.append({'id': i + total,
-                                 'y_true': int(targets[i]),
-                                 'y_pred': int(y_certified[i]),
-                                 'certified_radius': float(r_certified[i])})
+            rec = {'id': i + total,
+                   'y_true': int(targets[i]),
+                   'y_pred': int(y_certified[i]),
+                   'certified_radius': float(r_certified[i])}
+            if extra is not None:
+                rec.update(extra[i])
+            self.records.append(rec)
 
     def flush(self):
         os.makedirs(self.dir, exist_ok=True)

@@ -32,11 +32,13 @@ enum dmad_status {
 };
 
 enum dmad_precision {
-    DMAD_BF16 = 0,              /* WaveNet on bf16 MFMA (fp32 accumulate); mel + classifier fp32 */
+    DMAD_BF16 = 0,              /* WaveNet on the 16-bit MFMA path alone (operands: dmad_half_type, fp32 accumulate); mel +
+                                 * classifier fp32.  (The name is historical: the operand format is half_type's.) */
     DMAD_FP32 = 1,              /* everything on the exact-fp32 matrix path (parity mode) */
-    DMAD_EXACT = 2              /* both WaveNet paths resident: bf16 for throughput + exact-fp32 re-evaluation of every Monte
-                                 * Carlo sample whose bf16 top-2 logit margin is below the recheck bound, so that the vote
-                                 * counts of dmad_smooth_votes equal the fp32 path's (see dmad_set_mode) */
+    DMAD_EXACT = 2              /* both WaveNet paths resident: the 16-bit path for throughput + re-evaluation, on the
+                                 * split-f16 and exact-fp32 tiers, of every Monte Carlo sample whose 16-bit top-2 logit margin is
+                                 * below the recheck bound, so that the vote counts of dmad_smooth_votes are the fp32 path's
+                                 * up to the measured bound documented at dmad_set_mode (an empirical guarantee) */
 };
 
 /* Operand format of the 16-bit MFMA WaveNet path (DMAD_BF16 / DMAD_EXACT engines), fp32 accumulation either way. */
@@ -48,15 +50,18 @@ enum dmad_half_type {
 
 /* Run-time mode of a DMAD_EXACT engine (the other two precisions have exactly one mode). */
 enum dmad_mode {
-    DMAD_MODE_FAST = 0,         /* bf16 WaveNet, no recheck (what a DMAD_BF16 engine does) */
-    DMAD_MODE_EXACT_VOTES = 1,  /* bf16 WaveNet + margin-triggered fp32 recheck inside dmad_smooth_votes; every other entry
-                                 * point runs the bf16 WaveNet */
+    DMAD_MODE_FAST = 0,         /* 16-bit WaveNet, no recheck (what a DMAD_BF16 engine does) */
+    DMAD_MODE_EXACT_VOTES = 1,  /* 16-bit WaveNet + margin-triggered recheck (split-f16 tier, then exact fp32) inside
+                                 * dmad_smooth_votes; every other entry point runs the 16-bit WaveNet */
     DMAD_MODE_FP32 = 2          /* every WaveNet evaluation on the exact-fp32 path (what a DMAD_FP32 engine does) */
 };
 
 /* configs/config.json (wavenet_config + diffusion_config) as read by
  * diffusion_models/diffwave_ddpm.py:395-411 create_diffwave_model(). */
 typedef struct dmad_config {
+    int32_t struct_size;        /* sizeof(dmad_config) of the header the caller was built with: dmad_create refuses any
+                                 * other value, so a caller of an older revision fails with a message instead of having
+                                 * fields read past the end of its struct */
     int32_t res_channels;       /* 256 (the only supported value)       */
     int32_t skip_channels;      /* 256                                   */
     int32_t num_res_layers;     /* <= 64; 36 in the reference            */
@@ -69,7 +74,8 @@ typedef struct dmad_config {
     int32_t num_classes;        /* 10  */
     int32_t precision;          /* enum dmad_precision                   */
     int32_t with_classifier;    /* 1: VGG19_bn + mel front-end buffers   */
-    int32_t recheck_batch;      /* DMAD_EXACT: clips per exact-fp32 pass (0 = default 32; <= max_batch) */
+    int32_t recheck_batch;      /* DMAD_EXACT: clips per pass of the recheck tiers (0 = 32; clamped to max_batch; the
+                                 * Python engine and bench.py pass 64) */
     int32_t half_type;          /* enum dmad_half_type                   */
 } dmad_config;
 
@@ -77,6 +83,9 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out);
 void dmad_destroy(dmad_engine* e);
 const char* dmad_last_error(void);
 const char* dmad_version(void);
+/* Non-fatal findings of the last dmad_finalize_weights() on this thread ("" if none): e.g. folded WaveNet weights that leave the
+ * f16 normal range on an f16 engine (subnormals below 6.1e-5 lose significant bits, values above 65504 become inf). */
+const char* dmad_last_warning(void);
 
 /* Weights arrive as FOLDED fp32 host arrays (weight-norm and eval BatchNorm already folded by the
  * Python loader, exactly as the reference's modules compute them on every forward:
@@ -168,9 +177,9 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
                       const float* delta, int64_t* counts, float* logits_out, float* x0_out, dmad_stream s);
 
 /* DMAD_EXACT engines.  dmad_set_mode selects the dmad_mode (default DMAD_MODE_EXACT_VOTES).  dmad_set_recheck_margin sets
- * the bound tau: a sample whose bf16 logits have (largest - second largest) < tau (or any NaN) does not vote from the bf16
+ * the bound tau: a sample whose 16-bit logits have (largest - second largest) < tau (or any NaN) does not vote from the 16-bit
  * logits; its global sample index is queued and the sample is re-evaluated from the SAME noise (Philox key (seed, index),
- * or its row of `delta`) on the exact-fp32 WaveNet, and that result votes (and replaces its row of logits_out / x0_out).
+ * or its row of `delta`) on the higher tiers, and that result votes (and replaces its row of logits_out / x0_out).
  * With tau >= the largest error the 16-bit path makes on a logit DIFFERENCE AGAINST THE EXACT LEADER (E = max_j |e_j - e_i|,
  * e = 16-bit minus exact logits, i = the exact arg-max: a 16-bit leader j != i with margin >= tau would need e_j - e_i >= tau)
  * the counts equal the fp32 path's exactly (robustness_eval/certified_robust.py:59-65 is an arg-max: it only depends on the
@@ -188,6 +197,23 @@ int dmad_set_recheck_margin(dmad_engine* e, float tau);
 int dmad_set_recheck_margin2(dmad_engine* e, float tau2);
 int dmad_recheck_stats(dmad_engine* e, int64_t* samples, int64_t* rechecked, int64_t* rechecked_fp32, int32_t reset);
 int dmad_wavenet_eps_path(dmad_engine* e, const float* x_t, int32_t t, int32_t B, int32_t path, float* eps, dmad_stream s);
+
+/* The forward of RobustCertificate.smooth_predict's loop body (certified_robust.py:46-56) for an explicit LIST of Monte Carlo
+ * samples on an explicit WaveNet path — the audit of the exact-vote mode (RobustCertificate.certify(audit=k): k samples that
+ * voted on the 16-bit tier are re-evaluated on a higher one) and the measurement tools' hook:  row i of logits_out [n][num_classes]
+ * / x0_out [n][clip_len] (either optional) is sample idx[i] (device int64, GLOBAL sample indices; noise = Philox key
+ * (seed, idx[i]) or row idx[i] - sample0 of `delta`), evaluated on path 0 (the mode's default), 1 (exact fp32) or 2 (split-f16).
+ * Nothing votes, no queue is touched. */
+int dmad_eval_samples(dmad_engine* e, const float* clip, float sigma, float sqrt_alpha_bar_star, int32_t t, float c_a, float c_b,
+                      uint64_t seed, uint64_t sample0, const float* delta, const int64_t* idx, int64_t n, int32_t path, float* logits_out,
+                      float* x0_out, dmad_stream s);
+
+/* Measurement hook (tools/gpu_error_attribution.py): switch single roundings of the 16-bit path on INSIDE the fp32-grade split-f16
+ * tier, to attribute the 16-bit tier's logit error to its sources.  masks[0..3] act on the tier's dilated-conv, res-conv, skip and
+ * final_conv.0 GEMM launches: bit 0 = weights rounded to f16, bit 1 = the MFMA eats f16(activation) while the stored value keeps
+ * its 22 bits, bit 2 = the launch's split-format output (gate / residual stream) is stored as f16; masks[4] != 0 = the init
+ * conv's output is stored as f16.  All zero (the default) = the product tier. */
+int dmad_debug_rounding(dmad_engine* e, const int32_t masks[5]);
 
 /* BASELINE configuration C5: the Monte Carlo vote loop with the SPEC-domain purifier (Improved-Diffusion UNet on 1x32x32 mel
  * spectrograms) in place of the waveform purifier.  The reference has no working composite for it

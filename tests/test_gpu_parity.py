@@ -789,7 +789,8 @@ def test_bench_contract():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--samples-per-step', '8',
-                        '--max-batch', '8', '--cpu-samples', '2', '--full-n', '64', '--c5-n', '16'], capture_output=True, text=True, timeout=600, cwd=root)
+                        '--max-batch', '8', '--cpu-samples', '2', '--full-n', '64', '--c5-n', '16', '--c2-iters', '1', '--c2-batch', '8', '--c3-clips', '1',
+                        '--check-steps', '1'], capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -815,6 +816,17 @@ def test_bench_contract():
     assert ff['bound'] == 'hbm' and ff['unit'] == 'GB/s' and ff['peak'] == 8000.0 and ff['launches_timed'] == 1 and 0 < ff['frac'] < 1.5
     c5 = j['c5_spec_mode']                 # BASELINE C5 beside the headline: the spec-domain vote loop on its own fp32 engine
     assert c5['n'] == 16 and sum(c5['votes']) == 16 and c5['samples_per_s'] > 0 and c5['dtype'] == 'f32' and 0 < c5['frac_of_fp32_matrix_peak'] < 1
+    # the line proves its own exactness claim: the first timed step's keys in the exact-vote mode and on the exact-fp32 path
+    ck = j['exact_vs_fp32_check']
+    assert j['exact_equals_fp32'] is True and ck['votes_exact'] == ck['votes_fp32'] and sum(ck['votes_fp32']) == ck['samples'] == 8
+    assert ck['sample_range'] == [8, 16]
+    # BASELINE.md's other single-GPU cells: C2 (DDPM t* = 5 on a bf16 engine) and C3 (certify n = 1000)
+    c2 = j['c2_ddpm_mode']
+    assert c2['dtype'] == 'bf16' and c2['t_star'] == 5 and c2['batch'] == 8 and c2['clips_per_s'] > 0
+    assert abs(c2['network_evals_per_s'] - 5 * c2['clips_per_s']) < 1e-6 * c2['network_evals_per_s'] and sum(c2['decisions_histogram']) == 8
+    assert c2['roofline']['launches_timed'] == 5 * 35 and 0 < c2['roofline']['frac'] < 1
+    c3 = j['c3_certify_n1000']
+    assert c3['clips_per_s'] > 0 and len(c3['y_pred']) == 1 and c3['y_pred'][0] in range(-1, 10)
     # a rank count the box cannot serve is refused loudly, never run as fewer ranks
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(torch.cuda.device_count() + 1), '--steps', '1'],
@@ -1150,9 +1162,12 @@ def test_exact_vote_queue_drains_mid_call(weights, sched, monkeypatch):
 
 
 def test_recheck_bounds_are_calibrated_for_the_resident_weights(exact_engine, sched):
-    """Engine.calibrate_recheck measures the two bounds of the exact-vote mode for the weights that are loaded (the defaults were
-    measured on the synthetic VGG19_bn; a checkpoint with another logit sensitivity needs its own): on the synthetic pair it lands
-    near the committed defaults, it restores mode and statistics, and RobustCertificate(calibrate=n) runs it once per sigma."""
+    """Engine.calibrate_recheck measures the two error statistics of the exact-vote mode for the weights that are loaded (the
+    defaults were measured on the synthetic VGG19_bn over 36 864 samples; a checkpoint with another logit sensitivity needs its
+    own).  A calibration may only WIDEN a bound: a maximum over a few hundred samples underestimates the tail, so on the
+    synthetic pair — whose errors sit below the committed defaults — the bounds stay exactly at the defaults; a small headroom
+    multiple is overridden by the floor, a huge one widens.  Mode and statistics are untouched; RobustCertificate(calibrate=n)
+    measures the first `calibrate_clips` clips of a sigma and keeps the widest bounds."""
     from audio_models.ConvNets_SpeechCommands.models.vgg import vgg19_bn  # noqa: F401
     from diffusion_models.diffwave_ddpm import DiffWave, WaveNetHIP
     from dmad_hip import engine as E
@@ -1160,18 +1175,129 @@ def test_recheck_bounds_are_calibrated_for_the_resident_weights(exact_engine, sc
     from robustness_eval.certified_robust import RobustCertificate
     eng = exact_engine
     hp, coef = sched
-    clip = torch.from_numpy(synth.synthetic_clip(1)).cuda()
+    clips = [torch.from_numpy(synth.synthetic_clip(i)).cuda() for i in (1, 2)]
     sc = float(torch.tensor((1 / 1.25) ** 0.5))
+    d1, d2 = E.DEFAULT_RECHECK_MARGIN[E.HALF_F16], E.DEFAULT_RECHECK_MARGIN2
     old = (eng.recheck_margin, eng.recheck_margin2)
-    t1, t2, e1, e2 = eng.calibrate_recheck(clip, 0.5, sc, 65, *coef(65), n=256, n_fp32=32)
-    assert 0.004 < e1 < 0.034 and 1e-5 < e2 < 1e-3, (e1, e2)             # the defaults' regime: 0.0244 / 2.5e-4 at N = 36 864
-    assert abs(t2 - 1.5 * e2) < 1e-7 and abs(t1 - (1.5 * e1 + t2)) < 1e-6 and eng.recheck_margin == pytest.approx(t1)
-    assert eng.mode == E.MODE_EXACT_VOTES and eng.recheck_stats() == (0, 0)
+    stats = eng.recheck_stats(detail=True)
+    t1, t2, e1, e2 = eng.calibrate_recheck(clips, 0.5, sc, 65, *coef(65), n=256, n_fp32=64)
+    assert 0.004 < e1 < d1 and 1e-5 < e2 < d2, (e1, e2)                  # the defaults' regime: 0.0244 / 2.5e-4 at N = 36 864
+    assert t1 == d1 and t2 == d2 and eng.recheck_margin == pytest.approx(d1)          # observed errors below the floor: defaults kept
+    assert eng.calibration['clips'] == 2 and eng.calibration['e1'] == e1 and eng.calibration['n_fp32'] == 64
+    assert eng.mode == E.MODE_EXACT_VOTES and eng.recheck_stats(detail=True) == stats  # nothing voted, nothing was reset
+    w1, w2, _, _ = eng.calibrate_recheck(clips[0], 0.5, sc, 65, *coef(65), n=128, n_fp32=32, headroom=50.0)
+    assert w2 == pytest.approx(max(d2, 50 * eng.calibration['e2'])) and w1 == pytest.approx(max(d1, 50 * eng.calibration['e1'] + w2)) and w1 > d1
     eng.set_recheck_margin(old[0]); eng.set_recheck_margin2(old[1])
     den = DiffWave(WaveNetHIP(eng), hp)
-    rc = RobustCertificate(classifier=synth_vgg().bind_engine(eng), transform=MelSpectrogramDB(eng), denoiser=den, seed=2, calibrate=64)
-    a = rc.smooth_predict(clip, num_sampling=32, sigma=0.5, batch_size=16)
-    assert int(a.sum()) == 32 and list(rc._calibrated) == [65] and eng.recheck_margin == pytest.approx(rc._calibrated[65][0])
-    rc.smooth_predict(clip, num_sampling=8, sigma=0.5, batch_size=8)
-    assert list(rc._calibrated) == [65]                                     # once per t*
+    lines = []
+    rc = RobustCertificate(classifier=synth_vgg().bind_engine(eng), transform=MelSpectrogramDB(eng), denoiser=den, seed=2, calibrate=64,
+                           calibrate_clips=2, log=lines.append)
+    a = rc.smooth_predict(clips[0], num_sampling=32, sigma=0.5, batch_size=16)
+    assert int(a.sum()) == 32 and list(rc._calibrated) == [65] and eng.recheck_margin == pytest.approx(rc._calibrated[65][0]) >= d1
+    rc.smooth_predict(clips[1], num_sampling=8, sigma=0.5, batch_size=8)
+    rc.smooth_predict(clips[1], num_sampling=8, sigma=0.5, batch_size=8)
+    assert rc._calibrated_clips == {65: 2} and len(lines) == 2 and 'tau1' in lines[0]     # two clips measured, then no more
     eng.set_recheck_margin(old[0]); eng.set_recheck_margin2(old[1])
+
+
+def test_eval_samples_and_audit(exact_engine, sched):
+    """dmad_eval_samples evaluates an explicit list of Monte Carlo samples on an explicit tier from their Philox keys: its rows
+    equal the rows the vote loop produced for the same global indices (bit for bit on the same tier).  RobustCertificate.audit
+    re-evaluates tier-1 voters of the last smooth_predict on the split-f16 tier: no disagreement at the committed bound, and a
+    bound of zero (every sample votes on tier 1) makes the audit see every flip the 16-bit tier commits."""
+    from diffusion_models.diffwave_ddpm import DiffWave, WaveNetHIP
+    from dmad_hip import engine as E
+    from dmad_hip.transforms import MelSpectrogramDB
+    from robustness_eval.certified_robust import RobustCertificate
+    eng = exact_engine
+    hp, coef = sched
+    clip = torch.from_numpy(synth.synthetic_clip(3)).cuda()
+    sc = float(torch.tensor((1 / 1.25) ** 0.5))
+    args = (clip, 0.5, sc, 65) + coef(65)
+    eng.set_mode(E.MODE_FAST)
+    _, lg_fast, _ = eng.smooth_votes(*args, 48, batch=16, seed=5, sample0=100, want_logits=True)
+    idx = torch.tensor([147, 100, 101, 131, 120], device='cuda')
+    got = eng.eval_samples(*args, idx, path=0, seed=5)
+    assert torch.equal(got, lg_fast[idx - 100])
+    eng.set_mode(E.MODE_FP32)
+    _, lg32, x32 = eng.smooth_votes(*args, 48, batch=16, seed=5, sample0=100, want_logits=True, want_x0=True)
+    eng.set_mode(E.MODE_EXACT_VOTES)
+    got32, x0 = eng.eval_samples(*args, idx, path=1, seed=5, want_x0=True)
+    assert torch.equal(got32, lg32[idx - 100]) and torch.equal(x0, x32[idx - 100])
+    mid = eng.eval_samples(*args, idx, path=2, seed=5)
+    assert float((mid - got32).abs().max()) < 1e-3 < float((got - got32).abs().max()) + 1.0
+    from dmad_hip._lib import DmadError
+    with pytest.raises(DmadError):
+        eng.eval_samples(*args, idx, path=5, seed=5)
+    # audit through the host mirror
+    den = DiffWave(WaveNetHIP(eng), hp)
+    rc = RobustCertificate(classifier=synth_vgg().bind_engine(eng), transform=MelSpectrogramDB(eng), denoiser=den, seed=9)
+    with pytest.raises(RuntimeError):
+        rc.audit(clip, 8)                                                   # nothing to audit yet
+    y, r = rc.certify(clip.reshape(1, 1, -1), torch.tensor([0], device='cuda'), sigma=0.5, n_0=16, n=192, batch_size=64, audit=96)
+    rec = rc.audit_log[-1]
+    assert rec['audited'] == 96 and 0 < rec['voted_on_tier1'] <= 96 and rec['disagreements'] == []
+    assert 0 < rec['max_leader_diff_error'] < rec['tau1'] == eng.recheck_margin
+    old = eng.recheck_margin
+    eng.set_recheck_margin(0.0)                                             # every finite sample votes on the 16-bit tier
+    try:
+        rc.smooth_predict(clip, num_sampling=192, sigma=0.5, batch_size=64)
+        rec0 = rc.audit(clip, 192)
+    finally:
+        eng.set_recheck_margin(old)
+    assert rec0['voted_on_tier1'] == 192
+    for i, a, b, m in rec0['disagreements']:                                # whatever flipped did so inside the committed bound
+        assert a != b and 0 <= m < old
+
+
+def test_rounding_attribution_hook(exact_engine, sched):
+    """dmad_debug_rounding switches single roundings of the 16-bit path on inside the split-f16 tier (tools/gpu_error_attribution.py).
+    All of them together reproduce the order of magnitude of the 16-bit tier's own logit error; each alone stays below that;
+    masks off = the product tier bit for bit."""
+    from dmad_hip import engine as E
+    eng = exact_engine
+    hp, coef = sched
+    clip = torch.from_numpy(synth.synthetic_clip(0)).cuda()
+    sc = float(torch.tensor((1 / 1.25) ** 0.5))
+    args = (clip, 0.5, sc, 65) + coef(65)
+    idx = torch.arange(32, device='cuda')
+    ref = eng.eval_samples(*args, idx, path=2, seed=3)
+    eng.set_mode(E.MODE_FAST)
+    fast = eng.eval_samples(*args, idx, path=0, seed=3)
+    eng.set_mode(E.MODE_EXACT_VOTES)
+
+    def err(**m):
+        eng.debug_rounding(**m)
+        try:
+            return float((eng.eval_samples(*args, idx, path=2, seed=3) - ref).abs().max())
+        finally:
+            eng.debug_rounding()
+    e_fast = float((fast - ref).abs().max())
+    e_all = err(dil=3, res=7, skip=3, f0=3, init=1)
+    e_w = err(dil=1, res=1, skip=1, f0=1)
+    e_h = err(res=4, init=1)
+    assert 0.25 * e_fast < e_all < 4 * e_fast, (e_all, e_fast)
+    assert 0 < e_w < e_all * 1.5 and 0 < e_h < e_all * 1.5, (e_w, e_h, e_all)
+    assert torch.equal(eng.eval_samples(*args, idx, path=2, seed=3), ref)
+    from dmad_hip._lib import DmadError
+    with pytest.raises(DmadError):
+        eng.debug_rounding(dil=9)
+
+
+def test_f16_engine_warns_about_weights_outside_the_half_range():
+    """Folded WaveNet weights below 2^-14 become f16 subnormals (fewer significant bits than the 16-bit tier's error bound was
+    measured with), values above 65504 overflow: dmad_finalize_weights reports both (dmad_last_warning) and the Python engine
+    raises a RuntimeWarning; the synthetic weights are inside the range and load silently."""
+    import warnings
+    from dmad_hip import engine as E
+    sd = synth.wavenet_state_dict(1234)
+    tiny = {k: (v * 1e-4 if 'res_conv.weight_g' in k else v) for k, v in sd.items()}     # weight-norm gain: scales the folded res weights
+    eng = E.Engine(max_batch=1, precision=E.BF16, half_type=E.HALF_F16, with_classifier=False)
+    with pytest.warns(RuntimeWarning, match='f16 subnormals'):
+        eng.load_wavenet(tiny)
+    eng.close()
+    eng = E.Engine(max_batch=1, precision=E.BF16, half_type=E.HALF_F16, with_classifier=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        eng.load_wavenet(sd)
+    eng.close()

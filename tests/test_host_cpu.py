@@ -50,6 +50,12 @@ def test_c_abi_fails_loudly_without_gpu(built_lib):
     bad = _lib.DmadConfig(128, 256, 36, 12, 128, 512, 512, 16000, 1, 10, 0, 1, 0, 0)
     assert lib.dmad_create(ctypes.byref(bad), ctypes.byref(h)) == -1
     assert b'256' in lib.dmad_last_error()
+    # a caller built against another revision of dmad.h (struct_size mismatch) is refused before any field is trusted
+    assert cfg.struct_size == ctypes.sizeof(_lib.DmadConfig) == 15 * 4
+    old = _lib.DmadConfig(256, 256, 36, 12, 128, 512, 512, 16000, 1, 10, 0, 1, 0, 0)
+    old.struct_size = 12 * 4                               # the round-1 layout: no struct_size, recheck_batch, half_type
+    assert lib.dmad_create(ctypes.byref(old), ctypes.byref(h)) == -1 and b'struct_size' in lib.dmad_last_error()
+    assert b'dmad-hip 0.3' in lib.dmad_version() and lib.dmad_last_warning() == b''
 
 
 def test_lds_layouts_are_bank_conflict_free():
@@ -288,6 +294,17 @@ def test_sc09_dataset_index(tmp_path):
     assert item['target'] == 2 and item['samples'].shape == (16000,)
     assert os.path.basename(os.path.dirname(item['path'])) == 'two'
     assert len(SC09Dataset(str(tmp_path), num_per_class=100)) == 30           # fewer files than num_per_class
+    # balanced-class sampler weights (reference datasets/sc_dataset.py:136-149): N / (items of the item's class)
+    w = ds.make_weights_for_balanced_classes()
+    assert w.dtype == np.float64 and w.shape == (20,) and np.all(w == 10.0)
+    os.remove(ds.data[-1][0])                                                  # an unbalanced index: 'nine' keeps one of its files
+    ub = SC09Dataset(str(tmp_path), num_per_class=2)
+    wu = ub.make_weights_for_balanced_classes()
+    assert len(ub) == 20 and np.all(wu == 10.0)                                # (three files per class: two are still listed)
+    os.remove(ub.data[-1][0])
+    ub = SC09Dataset(str(tmp_path), num_per_class=2)
+    wu = ub.make_weights_for_balanced_classes()
+    assert len(ub) == 19 and np.all(wu[:18] == 19 / 2) and wu[18] == 19.0
     assert ds[0].keys() >= {'path', 'target'} and SC09Dataset(str(tmp_path), num_per_class=1)[3] == {'path': ds.data[6][0], 'target': 3}
     with pytest.raises(AssertionError):                                        # a missing class folder
         os.rename(tmp_path / 'three', tmp_path / 'x3')
