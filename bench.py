@@ -384,35 +384,52 @@ def main():
     c5 = None
     if args.c5_n > 0 and args.classifier == 'vgg19_bn':
         # BASELINE configuration C5 beside the headline: the same vote loop with the spec-domain purifier (dmad_spec_smooth_votes:
-        # mel-dB -> standardise -> q_sample(t*) -> 26 UNet evaluations -> classifier), exact fp32 throughout, its own small engine
+        # mel-dB -> standardise -> q_sample(t*) -> 26 UNet evaluations -> classifier) on an engine of its own without WaveNet workspace,
+        # in the exact-vote mode (UNet chain on the 16-bit tier, low-margin samples re-run on the exact-fp32 UNet)
         from diffusion_models.improved_diffusion_ddpm import create_improved_diffusion
-        c5_b, c5_t = 512, 25                    # engine batch 512 like the headline (128: 208 samples/s, 512: 227, 2048: 234)
-        eng5 = E.Engine(max_batch=c5_b, precision=E.FP32, recheck_batch=0)
+        c5_b, c5_t = 512, 25                    # engine batch 512 like the headline
+        eng5 = E.Engine(max_batch=c5_b, precision=E.EXACT, recheck_batch=0, with_wavenet=False)
         eng5.load_vgg19_bn(csd)
         pur = create_improved_diffusion(None, reverse_timestep=c5_t, state_dict=synth.unet_state_dict(31), engine=eng5)
         c5_args = (clip, sigma) + tuple(pur.purify_coefficients()) + (-100.0, 38.22)
         eng5.spec_smooth_votes(*c5_args, c5_b, seed=1)                       # warm-up: one batch fills the per-step tables of all 26 steps
-        fence()
-        t0 = time.perf_counter()
-        # every rank takes c5_n samples of the global index range (weak scaling), one int64[10] all-reduce at the end
-        c5_counts, _, _ = eng5.spec_smooth_votes(*c5_args, args.c5_n, seed=2024, sample0=rank * args.c5_n)
-        if dist is not None:
-            if backend == 'gloo':
-                cc = c5_counts.cpu(); dist.all_reduce(cc); c5_counts = cc
-            else:
-                dist.all_reduce(c5_counts)
-        fence()
-        c5_dt = time.perf_counter() - t0
-        if dist is not None:
-            tmax = torch.tensor([c5_dt], dtype=torch.float64, device='cpu' if backend == 'gloo' else 'cuda')
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            c5_dt = float(tmax.item())
-        unet_tf = args.c5_n * (c5_t + 1) * UNET_FLOP_PER_SPEC / c5_dt / 1e12
+
+        def c5_run(mode, n_local):
+            eng5.set_mode(mode)
+            eng5.spec_recheck_stats(reset=True)
+            fence()
+            t0 = time.perf_counter()
+            # every rank takes n_local samples of the global index range (weak scaling), one int64[10] all-reduce at the end
+            cnt, _, _ = eng5.spec_smooth_votes(*c5_args, n_local, seed=2024, sample0=rank * n_local)
+            if dist is not None:
+                if backend == 'gloo':
+                    cc = cnt.cpu(); dist.all_reduce(cc); cnt = cc
+                else:
+                    dist.all_reduce(cnt)
+            fence()
+            dt5 = time.perf_counter() - t0
+            if dist is not None:
+                tmax = torch.tensor([dt5], dtype=torch.float64, device='cpu' if backend == 'gloo' else 'cuda')
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt5 = float(tmax.item())
+            return dt5, cnt.cpu().tolist(), eng5.spec_recheck_stats()
+        n32 = max(1, min(args.c5_n, 512))                                    # the exact-fp32 leg: the same first keys, fewer of them
+        c5_dt, c5_counts, (c5_voted, c5_re) = c5_run(E.MODE_EXACT_VOTES, args.c5_n)
+        f_dt, f_counts, _ = c5_run(E.MODE_FAST, args.c5_n)
+        x_dt, x_counts, _ = c5_run(E.MODE_EXACT_VOTES, n32)
+        p_dt, p_counts, _ = c5_run(E.MODE_FP32, n32)
+        evals = (c5_t + 1) * UNET_FLOP_PER_SPEC
         c5 = {"workload": "BASELINE C5: certified smoothing sigma=%.2f, spec-domain purifier (Improved-Diffusion UNet, t*=%d: %d network "
                           "evaluations per sample) + VGG19_bn" % (sigma, c5_t, c5_t + 1),
+              "mode": "exact-vote: UNet chain on the 16-bit tier (f16 operands, fp32 accumulate / GroupNorm / softmax), samples with top-2 "
+                      "margin < %.3g re-run on the exact-fp32 UNet" % eng5.spec_recheck_margin,
               "samples_per_s": args.c5_n * world / c5_dt, "n": args.c5_n * world, "n_gpus": world, "seconds": c5_dt, "engine_batch": c5_b,
-              "dtype": "f32", "votes": c5_counts.cpu().tolist(), "unet_tflops_per_gpu": unet_tf,
-              "frac_of_fp32_matrix_peak": unet_tf / PEAK_FP32_TFLOPS}
+              "dtype": "f16", "votes": c5_counts, "recheck_frac": c5_re / max(c5_voted, 1),
+              "unet_tflops_per_gpu": args.c5_n * evals / c5_dt / 1e12, "frac_of_mfma16_peak": args.c5_n * evals / c5_dt / 1e12 / PEAK_MFMA16_TFLOPS,
+              "fast_mode": {"samples_per_s": args.c5_n * world / f_dt, "votes": f_counts},
+              "fp32_mode": {"samples_per_s": n32 * world / p_dt, "n": n32 * world, "votes": p_counts, "unet_tflops_per_gpu": n32 * evals / p_dt / 1e12,
+                            "frac_of_fp32_matrix_peak": n32 * evals / p_dt / 1e12 / PEAK_FP32_TFLOPS},
+              "exact_equals_fp32": x_counts == p_counts, "votes_exact_same_keys": x_counts}
         eng5.close()
 
     if rank == 0:

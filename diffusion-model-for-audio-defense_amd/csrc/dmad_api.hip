@@ -15,6 +15,7 @@
 #include "unet_ops.h"
 #include "elementwise.h"
 #include "gemm_f32.h"
+#include "gemm_h16.h"
 #include "wn_bf16.h"
 
 using namespace dmad;
@@ -47,7 +48,7 @@ int fail(int code, const char* fmt, ...) {
 #define LASTCHK()                                                                                   \
     do {                                                                                            \
         HIPCHK(hipGetLastError());                                                                  \
-        if (int _b = gemm_take_bad_shapes()) return fail(DMAD_ERR_INVALID, "%d GEMM launch(es) refused: unsupported shape", _b); \
+        if (int _b = gemm_take_bad_shapes() + gemm_h16_take_bad_shapes()) return fail(DMAD_ERR_INVALID, "%d GEMM launch(es) refused: unsupported shape", _b); \
     } while (0)
 
 uint16_t f2bf(float f) {   // round-to-nearest-even, NaN stays NaN
@@ -73,15 +74,27 @@ uint16_t f2h(float f) {    // fp32 -> IEEE half, round-to-nearest-even (subnorma
     return (uint16_t)(sign | (uint32_t)(((e + 15) << 10) + (h - 0x400u)));   // a significand carry bumps the exponent
 }
 
-// f2h with a census of what leaves the f16 normal range (dmad_finalize_weights warns: a folded weight below 2^-14 keeps
-// fewer than 11 significant bits as an f16 subnormal, one above 65504 becomes inf and shows up as NaN logits)
-thread_local long g_h_sub = 0, g_h_ovf = 0, g_h_n = 0;
+// f2h with a census of what leaves the f16 normal range.  A Gaussian weight tensor always has a few values below 2^-14 (f16
+// subnormals): their absolute rounding error (<= 2^-25) is far below the 2^-12 relative error of the tensor's typical weights
+// and does not matter.  What does matter is a tensor (or a large part of one) that lives down there as a whole — a checkpoint
+// with tiny weight-norm gains — or a value beyond 65504 (inf, NaN logits).  So the census is per packed tensor: the share of its
+// squared norm carried by subnormal values; dmad_finalize_weights warns when that share exceeds 1e-6 in any tensor.
+thread_local double g_h_sq = 0.0, g_h_sq_sub = 0.0;
+thread_local long g_h_bad_tensors = 0, g_h_ovf = 0, g_h_tensors = 0;
+thread_local double g_h_worst = 0.0;
 uint16_t f2h_census(float f) {
     const float a = fabsf(f);
-    ++g_h_n;
-    if (a != 0.f && a < 6.103515625e-05f) ++g_h_sub;
+    g_h_sq += (double)a * a;
+    if (a < 6.103515625e-05f) g_h_sq_sub += (double)a * a;
     if (a >= 65520.f) ++g_h_ovf;
     return f2h(f);
+}
+void census_close_tensor() {
+    ++g_h_tensors;
+    const double share = g_h_sq > 0.0 ? g_h_sq_sub / g_h_sq : 0.0;
+    if (share > 1e-6) ++g_h_bad_tensors;
+    if (share > g_h_worst) g_h_worst = share;
+    g_h_sq = g_h_sq_sub = 0.0;
 }
 
 float h2f(uint16_t h) {    // IEEE half -> fp32 (exact)
@@ -197,6 +210,7 @@ struct dmad_engine {
         float *gn1w = nullptr, *gn1b = nullptr, *w1 = nullptr, *b1 = nullptr;       // res: in_layers; attn: norm, qkv; down/up/conv_in: conv
         float *embw = nullptr, *embb = nullptr, *gn2w = nullptr, *gn2b = nullptr, *w2 = nullptr, *b2 = nullptr;   // res: emb, out_layers; attn: proj_out
         float *skw = nullptr, *skb = nullptr;                                       // res: 1x1 skip_connection
+        h16_t *w1h = nullptr, *w2h = nullptr, *skwh = nullptr;                      // f16 images of w1 / w2 / skw (16-bit tier)
         size_t ss_off = 0;                 // res: offset of its (scale, shift) row [2 * cout] inside a step's row of un_ss_table
     };
     std::vector<std::vector<UnOp>> un_in, un_out;
@@ -217,6 +231,14 @@ struct dmad_engine {
     float *un_outw = nullptr, *un_outb = nullptr, *un_temb = nullptr, *un_emb1 = nullptr, *un_emb = nullptr, *un_semb = nullptr;
     float* un_buf[8] = {nullptr};          // work maps: 3 rotating block outputs, T1, T2, skip, qkv / cat, attention
     float* un_eps = nullptr;
+    // 16-bit tier of the UNet (gemm_h16: f16 operands, fp32 accumulate; GroupNorm / softmax / residual sums stay fp32): f16 twins of
+    // the block outputs (the maps a GEMM reads without a GroupNorm in between), f16-only GroupNorm / upsample / attention outputs
+    bool un_h16 = false;
+    h16_t* un_buf16[3] = {nullptr};
+    std::vector<h16_t*> un_hs16;
+    h16_t *un_t1h = nullptr, *un_uph = nullptr, *un_atth = nullptr;
+    float tau_spec = 0.f;                  // recheck bound of the spec-domain vote loop's 16-bit tier (dmad_set_spec_recheck_margin)
+    int64_t st_spec_samples = 0, st_spec_rechecked = 0;
 
     template <typename T>
     int alloc(T** p, size_t n, bool zero = false) {
@@ -308,7 +330,7 @@ int finalize_wavenet(dmad_engine* e) {
 
     if (e->bf16) {
         uint16_t (*cvt)(float) = e->f16 ? f2h_census : f2bf;
-        g_h_sub = g_h_ovf = g_h_n = 0;
+        g_h_sq = g_h_sq_sub = g_h_worst = 0.0; g_h_bad_tensors = g_h_ovf = g_h_tensors = 0;
         int rmap[512];
         // tile row R = wm*128 + half*64 + mt*16 + i  <->  gate row half*256 + (mt*64 + wm*16 + i): channel ownership is
         // interleaved over the M-waves so that GEMM2 can start on channels [64 mt, 64 mt + 64) as soon as tiles mt are gated
@@ -330,22 +352,27 @@ int finalize_wavenet(dmad_engine* e) {
                         tapw[(size_t)oc * 256 + ci] = dw[((size_t)oc * 256 + ci) * 3 + tap] * (oc < 256 ? -2.8853900817779268f : -1.4426950408889634f);
                 pack_rows(cvt, tapw.data(), 512, 256, 256, rmap, w1p, (size_t)n * 24 * 512 * 32, 3, tap);   // stage = 3 * kchunk + tap
             }
+            census_close_tensor();
             for (int R = 0; R < 512; ++R) b1p[(size_t)n * 512 + R] = db[rmap[R]];
             std::vector<float> rws(rw.size());                      // res conv pre-scaled by sqrt(1/2): h' = h*sqrt(1/2) + (W_res' g + c)
             for (size_t i = 0; i < rw.size(); ++i) rws[i] = rw[i] * 0.70710678118654752440f;
             pack_rows(cvt, rws.data(), 256, 256, 256, nullptr, w2p, (size_t)n * 8 * 256 * 32);
+            census_close_tensor();
             pack_rows(cvt, sw.data(), 256, 256, 256, nullptr, wsp, (size_t)n * 8 * 256 * 32);
+            census_close_tensor();
             for (int c = 0; c < 256; ++c) { b2[(size_t)n * 256 + c] = rb[c]; bsum[c] += sb[c]; }
         }
         pack_rows(cvt, f0w.data(), 256, 256, 256, nullptr, wf0p, 0);
+        census_close_tensor();
         CHK(e->upload_bf(&e->w1p, w1p)); CHK(e->upload_bf(&e->w2p, w2p)); CHK(e->upload_bf(&e->wsp, wsp));
         CHK(e->upload_bf(&e->wf0p, wf0p));
         CHK(e->upload(&e->b1p, b1p)); CHK(e->upload(&e->b2, b2)); CHK(e->upload(&e->bskip_sum, bsum));
-        if (e->f16 && (g_h_sub || g_h_ovf)) {
-            char buf[384];
-            snprintf(buf, sizeof buf, "WaveNet weights on the f16 MFMA path: %ld of %ld folded values are f16 subnormals (|w| < 6.1e-5: fewer "
-                     "than 11 significant bits) and %ld overflow to inf (|w| > 65504); the 16-bit tier's error bound was not measured for "
-                     "such weights: calibrate the recheck margins on these weights or use half_type = bf16", g_h_sub, g_h_n, g_h_ovf);
+        if (e->f16 && (g_h_bad_tensors || g_h_ovf)) {
+            char buf[448];
+            snprintf(buf, sizeof buf, "WaveNet weights on the f16 MFMA path: in %ld of %ld folded weight tensors f16 subnormals (|w| < 6.1e-5: fewer "
+                     "than 11 significant bits) carry more than 1e-6 of the squared norm (worst: %.3g), and %ld values overflow to inf "
+                     "(|w| > 65504); the 16-bit tier's error bound was not measured for such weights: calibrate the recheck margins on "
+                     "these weights or use half_type = bf16", g_h_bad_tensors, g_h_tensors, g_h_worst, g_h_ovf);
             e->warn = buf;
         }
     }
@@ -586,20 +613,28 @@ constexpr int kUnSsSteps = 1000;         // cached steps (create_improved_diffus
 const int kUnMult[4] = {1, 2, 2, 2};
 inline bool un_attn_at(int ds) { return ds == 2 || ds == 4; }
 
-int un_conv3(dmad_engine* e, const std::string& name, int cout, int cin, float** w, float** b) {
+int upload_h16(dmad_engine* e, const std::vector<float>& A, h16_t** wh) {
+    std::vector<uint16_t> H(A.size());
+    for (size_t i = 0; i < A.size(); ++i) H[i] = f2h(A[i]);
+    return e->upload_bf(wh, H);
+}
+
+int un_conv3(dmad_engine* e, const std::string& name, int cout, int cin, float** w, float** b, h16_t** wh = nullptr) {
     const HostW* h = e->get(name + ".weight", {cout, cin, 3, 3}); if (!h) return DMAD_ERR_STATE;
     std::vector<float> A((size_t)9 * cout * cin);
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci)
             for (int t = 0; t < 9; ++t) A[((size_t)t * cout + co) * cin + ci] = h->v[((size_t)co * cin + ci) * 9 + t];
     CHK(e->upload(w, A));
+    if (wh && e->un_h16) CHK(upload_h16(e, A, wh));
     h = e->get(name + ".bias", {cout}); if (!h) return DMAD_ERR_STATE;
     CHK(e->upload(b, h->v));
     return 0;
 }
-int un_dense(dmad_engine* e, const std::string& name, int out, int in, float** w, float** b) {
+int un_dense(dmad_engine* e, const std::string& name, int out, int in, float** w, float** b, h16_t** wh = nullptr) {
     const HostW* h = e->get(name + ".weight", {out, in}); if (!h) return DMAD_ERR_STATE;
     CHK(e->upload(w, h->v));
+    if (wh && e->un_h16) CHK(upload_h16(e, h->v, wh));
     h = e->get(name + ".bias", {out}); if (!h) return DMAD_ERR_STATE;
     CHK(e->upload(b, h->v));
     return 0;
@@ -612,21 +647,21 @@ int un_load_op(dmad_engine* e, const std::string& p, dmad_engine::UnOp& o) {
         CHK(e->upload(&o.b1, h->v));
     } else if (o.kind == 1) {
         CHK(un_dense(e, p + ".in_layers.0", o.cin, 1, &o.gn1w, &o.gn1b));
-        CHK(un_conv3(e, p + ".in_layers.2", o.cout, o.cin, &o.w1, &o.b1));
+        CHK(un_conv3(e, p + ".in_layers.2", o.cout, o.cin, &o.w1, &o.b1, &o.w1h));
         CHK(un_dense(e, p + ".emb_layers.1", 2 * o.cout, kUnTE, &o.embw, &o.embb));
         CHK(un_dense(e, p + ".out_layers.0", o.cout, 1, &o.gn2w, &o.gn2b));
-        CHK(un_conv3(e, p + ".out_layers.3", o.cout, o.cout, &o.w2, &o.b2));
-        if (o.cin != o.cout) CHK(un_dense(e, p + ".skip_connection", o.cout, o.cin, &o.skw, &o.skb));
+        CHK(un_conv3(e, p + ".out_layers.3", o.cout, o.cout, &o.w2, &o.b2, &o.w2h));
+        if (o.cin != o.cout) CHK(un_dense(e, p + ".skip_connection", o.cout, o.cin, &o.skw, &o.skb, &o.skwh));
         o.ss_off = e->un_ss_total;
         e->un_ss_total += (size_t)2 * o.cout;
     } else if (o.kind == 2) {
         CHK(un_dense(e, p + ".norm", o.cin, 1, &o.gn1w, &o.gn1b));
-        CHK(un_dense(e, p + ".qkv", 3 * o.cin, o.cin, &o.w1, &o.b1));
-        CHK(un_dense(e, p + ".proj_out", o.cin, o.cin, &o.w2, &o.b2));
+        CHK(un_dense(e, p + ".qkv", 3 * o.cin, o.cin, &o.w1, &o.b1, &o.w1h));
+        CHK(un_dense(e, p + ".proj_out", o.cin, o.cin, &o.w2, &o.b2, &o.w2h));
     } else if (o.kind == 3) {
-        CHK(un_conv3(e, p + ".op", o.cout, o.cin, &o.w1, &o.b1));
+        CHK(un_conv3(e, p + ".op", o.cout, o.cin, &o.w1, &o.b1, &o.w1h));
     } else {
-        CHK(un_conv3(e, p + ".conv", o.cout, o.cin, &o.w1, &o.b1));
+        CHK(un_conv3(e, p + ".conv", o.cout, o.cin, &o.w1, &o.b1, &o.w1h));
     }
     return 0;
 }
@@ -682,6 +717,18 @@ int finalize_unet(dmad_engine* e) {
     }
     for (int i = 0; i < 8; ++i) CHK(e->alloc(&e->un_buf[i], B * 1024 * 384));     // largest map: 32x32 x (256 + 128) concat
     CHK(e->alloc(&e->un_eps, B * 1024));
+    if (e->un_h16) {
+        for (size_t i = 0; i < e->un_hs_ch.size(); ++i) {
+            h16_t* p = nullptr;
+            CHK(e->alloc(&p, B * e->un_hs_hw[i] * e->un_hs_ch[i]));
+            e->un_hs16.push_back(p);
+        }
+        for (int i = 0; i < 3; ++i) CHK(e->alloc(&e->un_buf16[i], B * 1024 * 384));
+        CHK(e->alloc(&e->un_t1h, B * 1024 * 384));
+        CHK(e->alloc(&e->un_uph, B * 1024 * 256));
+        CHK(e->alloc(&e->un_atth, B * 256 * 256));
+        if (int r = gemm_h16_configure()) return fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS, f16 conv GEMM) failed: %d", r);
+    }
     CHK(e->alloc(&e->un_ss_table, (size_t)(kUnSsSteps + 1) * e->un_ss_total));
     e->un_ss_have.assign(kUnSsSteps, 0);
     e->un_t = -1;
@@ -772,17 +819,101 @@ const float* unet_apply(dmad_engine* e, const dmad_engine::UnOp& o, const float*
         H *= 2;
         launch_gemm_f32(un_conv_args(o.w1, o.b1, T1, out, o.cout, o.cin, 9, B, H, 1, nullptr), s, e->slab, e->slab_floats, nref * 4);
     } else {
-        launch_conv1ch_3x3(in, o.w1, o.b1, out, B, o.cout, s);
+        if (launch_conv1ch_3x3(in, o.w1, o.b1, out, B, o.cout, s)) { fail(DMAD_ERR_STATE, "input conv: %d output channels > 128", o.cout); return nullptr; }
     }
     return out;
 }
 
+// ---- the same network on the 16-bit tier: every conv / 1x1 through gemm_h16 (f16 operands, fp32 accumulate), GroupNorm, softmax,
+// bias / residual sums and the maps themselves in fp32; a block output also exists as an f16 twin for the GEMMs that read it raw
+struct UMap { const float* f; const h16_t* h; };
+
+GemmH16Args un_h16_args(const h16_t* A, const float* bias, const h16_t* X, float* C, h16_t* C16, int cout, int cin, int taps, int B, int H,
+                        int stride, const float* res) {
+    GemmH16Args g{};
+    const int Ho = (H - 1) / (stride > 1 ? stride : 1) + 1;
+    g.A = A; g.X = X; g.C = C; g.C16 = C16; g.shift = bias; g.res = res; g.M = cout; g.K = cin; g.taps = taps; g.ldc = cout;
+    g.N = (long)B * Ho * Ho; g.H = H; g.W = H; g.ldx = cin; g.stride = stride;
+    return g;
+}
+
+bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, int& H, float* dstf, h16_t* dsth, int& rot, hipStream_t s,
+                    UMap* result, UMap in2 = UMap{nullptr, nullptr}, int c1 = 0) {
+    float *T2 = e->un_buf[4], *SK = e->un_buf[5], *QKV = e->un_buf[6];
+    h16_t *T1h = e->un_t1h, *ATTh = e->un_atth;
+    float* outf = dstf;
+    h16_t* outh = dsth;
+    if (!outf) {
+        int r = rot; rot = (rot + 1) % 3;
+        if (e->un_buf[r] == in.f) { r = rot; rot = (rot + 1) % 3; }
+        outf = e->un_buf[r]; outh = e->un_buf16[r];
+    }
+    if (o.kind == 1) {                      // ResBlock._forward, unet.py:186-199
+        if (in2.f && o.cin == o.cout) { fail(DMAD_ERR_STATE, "a concatenated input needs the ResBlock's skip conv"); return false; }
+        if (launch_groupnorm_nhwc(in.f, o.gn1w, o.gn1b, nullptr, 1, nullptr, B, H * H, o.cin, s, in2.f, c1, T1h)) { gn_fail(H * H, o.cin); return false; }
+        launch_gemm_h16(un_h16_args(o.w1h, o.b1, T1h, T2, nullptr, o.cout, o.cin, 9, B, H, 1, nullptr), s);
+        if (launch_groupnorm_nhwc(T2, o.gn2w, o.gn2b, e->un_ss_cur + o.ss_off, 1, nullptr, B, H * H, o.cout, s, nullptr, 0, T1h)) { gn_fail(H * H, o.cout); return false; }
+        const float* skip = in.f;
+        if (o.cin != o.cout) {
+            GemmH16Args g = un_h16_args(o.skwh, o.skb, in.h, SK, nullptr, o.cout, o.cin, 1, B, H, 1, nullptr);
+            if (in2.f) { g.ldx = c1; g.X2 = in2.h; g.ksplit = c1; g.ldx2 = o.cin - c1; }
+            launch_gemm_h16(g, s);
+            skip = SK;
+        }
+        launch_gemm_h16(un_h16_args(o.w2h, o.b2, T1h, outf, outh, o.cout, o.cout, 9, B, H, 1, skip), s);
+    } else if (o.kind == 2) {               // AttentionBlock._forward + QKVAttention, unet.py:225-258
+        const int C = o.cin, T = H * H;
+        if (launch_groupnorm_nhwc(in.f, o.gn1w, o.gn1b, nullptr, 0, nullptr, B, T, C, s, nullptr, 0, T1h)) { gn_fail(T, C); return false; }
+        launch_gemm_h16(un_h16_args(o.w1h, o.b1, T1h, QKV, nullptr, 3 * C, C, 1, B, H, 1, nullptr), s);
+        if (int rc = launch_qkv_attention(QKV, nullptr, B, T, kUnHeads, s, ATTh)) { fail(rc > 0 ? DMAD_ERR_HIP : DMAD_ERR_STATE, "UNet attention (T = %d): %s", T, rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported map size"); return false; }
+        launch_gemm_h16(un_h16_args(o.w2h, o.b2, ATTh, outf, outh, C, C, 1, B, H, 1, in.f), s);
+    } else if (o.kind == 3) {               // Downsample: conv 3x3 stride 2, unet.py:82-111
+        launch_gemm_h16(un_h16_args(o.w1h, o.b1, in.h, outf, outh, o.cout, o.cin, 9, B, H, 2, nullptr), s);
+        H /= 2;
+    } else if (o.kind == 4) {               // Upsample: nearest x2 + conv 3x3, unet.py:49-79
+        launch_upsample2x_nhwc_h16(in.h, e->un_uph, B, H, H, o.cin, s);
+        H *= 2;
+        launch_gemm_h16(un_h16_args(o.w1h, o.b1, e->un_uph, outf, outh, o.cout, o.cin, 9, B, H, 1, nullptr), s);
+    } else {                                // input conv 1 -> 128 (direct kernel, fp32 arithmetic)
+        if (launch_conv1ch_3x3(in.f, o.w1, o.b1, outf, B, o.cout, s, outh)) { fail(DMAD_ERR_STATE, "input conv: %d output channels > 128", o.cout); return false; }
+    }
+    *result = UMap{outf, outh};
+    return true;
+}
+
 // eps = UNetModel.forward(x, t * ones)  (unet.py:453-477): x, eps [B][32][32]
-int unet_eps(dmad_engine* e, const float* x, int t, int B, float* eps, hipStream_t s) {
+// h16 < 0: the mode's default (the 16-bit tier where it is resident, unless the engine is in DMAD_MODE_FP32); 0 / 1: explicit
+int unet_eps(dmad_engine* e, const float* x, int t, int B, float* eps, hipStream_t s, int h16 = -1) {
     if (!e->un_final) return fail(DMAD_ERR_STATE, "UNet weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
     if (B < 1 || B > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d]", B, e->maxB);
     if (t < 0) return fail(DMAD_ERR_INVALID, "diffusion step %d < 0", t);
     CHK(unet_prepare_step(e, t, s));
+    if (h16 < 0) h16 = (e->un_h16 && e->mode != DMAD_MODE_FP32) ? 1 : 0;
+    if (h16 && !e->un_h16) return fail(DMAD_ERR_STATE, "this engine has no 16-bit UNet tier (DMAD_FP32 precision)");
+    if (h16) {
+        int H = 32, rot = 0;
+        UMap h{x, nullptr};
+        for (size_t i = 0; i < e->un_in.size(); ++i)
+            for (size_t j = 0; j < e->un_in[i].size(); ++j) {
+                const bool save = j + 1 == e->un_in[i].size();
+                if (!unet_apply_h16(e, e->un_in[i][j], h, B, H, save ? e->un_hs[i] : nullptr, save ? e->un_hs16[i] : nullptr, rot, s, &h)) return DMAD_ERR_STATE;
+            }
+        for (auto& o : e->un_mid) if (!unet_apply_h16(e, o, h, B, H, nullptr, nullptr, rot, s, &h)) return DMAD_ERR_STATE;
+        size_t top = e->un_hs.size();
+        for (auto& blk : e->un_out) {
+            --top;
+            const int c1 = blk[0].cin - e->un_hs_ch[top];
+            const UMap hs{e->un_hs[top], e->un_hs16[top]};
+            for (size_t j = 0; j < blk.size(); ++j) {
+                const bool ok = j == 0 ? unet_apply_h16(e, blk[0], h, B, H, nullptr, nullptr, rot, s, &h, hs, c1) : unet_apply_h16(e, blk[j], h, B, H, nullptr, nullptr, rot, s, &h);
+                if (!ok) return DMAD_ERR_STATE;
+            }
+        }
+        if (launch_groupnorm_nhwc(h.f, e->un_outgw, e->un_outgb, nullptr, 1, e->un_buf[3], B, 1024, kUnMC, s)) { gn_fail(1024, kUnMC); return DMAD_ERR_STATE; }
+        launch_conv3x3_c128_to1(e->un_buf[3], e->un_outw, e->un_outb, eps, B, s);
+        LASTCHK();
+        return 0;
+    }
     int H = 32, rot = 0;
     const float* h = x;
     for (size_t i = 0; i < e->un_in.size(); ++i)
@@ -1002,6 +1133,9 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     e->mode = cfg->precision == DMAD_EXACT ? DMAD_MODE_EXACT_VOTES : (cfg->precision == DMAD_FP32 ? DMAD_MODE_FP32 : DMAD_MODE_FAST);
     e->tau = cfg->half_type == DMAD_HALF_F16 ? 0.034f : 0.30f;  // measured logit-difference error (against the leader) of the 16-bit path x 1.4 (see dmad.h)
     e->tau2 = 1e-3f;                        // the same for the split-f16 tier (dmad_set_recheck_margin2)
+    e->un_h16 = cfg->precision != DMAD_FP32;    // engines with a 16-bit side also get the UNet's f16 tier (once UNet weights are loaded)
+    e->tau_spec = 0.4f;                     // spec-domain vote loop: measured logit-difference error of the f16 UNet chain x headroom (see dmad.h)
+    const bool wn = cfg->with_wavenet != 0;
     if (e->bf16 && !wn_final_p_supported(cfg->num_res_layers)) {
         delete e;
         return fail(DMAD_ERR_INVALID, "bf16 path does not support num_res_layers = %d", cfg->num_res_layers);
@@ -1013,13 +1147,13 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
         if ((r = e->alloc(&e->eps, B * L))) break;
         if ((r = e->alloc(&e->x0, B * L))) break;
         if ((r = e->alloc(&e->znoise, B * L))) break;
-        if (e->bf16) {
+        if (e->bf16 && wn) {
             if ((r = e->alloc(&e->hA, B * LP * kC, true))) break;
             if ((r = e->alloc(&e->hB, B * LP * kC, true))) break;
             if ((r = e->alloc(&e->gstore, NL * B * L * kC))) break;
             if ((r = wn_bf16_configure())) { r = fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %d", r); break; }
         }
-        if (e->f32) {
+        if (e->f32 && wn) {
             if ((r = e->alloc(&e->hA32, B32 * LP * kC, true))) break;
             if ((r = e->alloc(&e->hB32, B32 * LP * kC, true))) break;
             if ((r = e->alloc(&e->H32, B32 * L * 512))) break;
@@ -1136,6 +1270,7 @@ int dmad_finalize_weights(dmad_engine* e) {
     // finalises whichever part (WaveNet, classifier) has its weights loaded and is not packed yet
     bool did = false;
     if (!e->wn_final && e->hw.count("init.w")) {
+        if (!e->cfg.with_wavenet) return fail(DMAD_ERR_STATE, "engine was created with with_wavenet = 0: it has no WaveNet workspace");
         CHK(finalize_wavenet(e));
         e->wn_final = true; did = true;
     }
@@ -1457,6 +1592,40 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
     return 0;
 }
 
+}  // extern "C"
+
+namespace {
+
+struct SpecJob {
+    const float* clip; float sigma; int t_star; float q_a, q_b; const float *c_a, *c_b, *c_1, *c_2, *c_sig; float mel_lo, mel_hi;
+    uint64_t seed;
+};
+// One batch of the spec-domain chain (include/dmad.h, dmad_spec_smooth_votes): rows are samples s0 + b, or idx[b] when an index
+// list is given (the recheck pass).  h16: -1 the mode's UNet tier, 0 exact fp32, 1 the 16-bit tier.  The purified dB spectrograms
+// land in sp, the logits in lg.
+int spec_chain(dmad_engine* e, const SpecJob& j, uint64_t s0, const long long* idx, int B, int h16, float* sp, float* lg, hipStream_t st) {
+    const int L = e->L;
+    if (idx) launch_mc_noise_scale_idx(j.clip, nullptr, j.sigma, 1.f, j.seed, 0, idx, e->xt, B, L, st);
+    else launch_mc_noise_scale(j.clip, nullptr, j.sigma, 1.f, j.seed, s0, e->xt, B, L, st);      // no wave denoiser: no sqrt(alpha_bar*) scale
+    CHK(mel_db(e, e->xt, B, e->spec, st));
+    launch_philox_normal(j.seed, s0, 0x5BECu, e->znoise, B, 1024, st, idx);
+    float* x = e->x0;                                                                   // [B][32][32] chain state
+    launch_spec_diffuse(e->spec, e->znoise, j.mel_lo, j.mel_hi, j.q_a, j.q_b, x, (long)B * 1024, st);
+    for (int t = j.t_star; t >= 0; --t) {
+        CHK(unet_eps(e, x, t, B, e->un_eps, st, h16));
+        const float sig = t > 0 ? j.c_sig[t] : 0.f;
+        if (sig != 0.f) launch_philox_normal(j.seed, s0, 0x0E70u + (uint32_t)t, e->znoise, B, 1024, st, idx);
+        launch_unet_p_sample(x, e->un_eps, sig != 0.f ? e->znoise : nullptr, j.c_a[t], j.c_b[t], j.c_1[t], j.c_2[t], sig, x, nullptr, (long)B * 1024, st);
+    }
+    launch_spec_unstandardize(x, j.mel_lo, j.mel_hi, sp, (long)B * 1024, st);
+    CHK(classify(e, sp, B, lg, st));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
 int dmad_spec_smooth_votes(dmad_engine* e, const float* clip, float sigma, int32_t t_star, float q_a, float q_b, const float* c_a,
                            const float* c_b, const float* c_1, const float* c_2, const float* c_sig, float mel_lo, float mel_hi, int64_t n,
                            int32_t batch, uint64_t seed, uint64_t sample0, int64_t* counts, float* logits_out, float* spec_out, dmad_stream s) {
@@ -1467,24 +1636,59 @@ int dmad_spec_smooth_votes(dmad_engine* e, const float* clip, float sigma, int32
     if (t_star < 0) return fail(DMAD_ERR_INVALID, "t_star %d < 0", t_star);
     if (!(mel_hi > mel_lo)) return fail(DMAD_ERR_INVALID, "empty mel range");
     hipStream_t st = (hipStream_t)s;
-    const int L = e->L, C = e->cfg.num_classes;
+    const int C = e->cfg.num_classes;
+    const SpecJob job{clip, sigma, t_star, q_a, q_b, c_a, c_b, c_1, c_2, c_sig, mel_lo, mel_hi, seed};
+    // exact-vote mode of a DMAD_EXACT engine: the chain runs on the UNet's 16-bit tier, a sample whose top-2 margin is below
+    // tau_spec is queued and its WHOLE chain is re-run on the exact-fp32 UNet from the same Philox keys
+    const bool recheck = e->bf16 && e->f32 && e->un_h16 && e->mode == DMAD_MODE_EXACT_VOTES;
+    if (recheck) HIPCHK(hipMemsetAsync(e->rc_n, 0, sizeof(unsigned long long), st));
+    auto drain = [&]() -> int {
+        int rc = 0;
+        const long nq = read_queue_length(e, st, &rc);
+        if (rc) return rc;
+        e->st_spec_rechecked += nq;
+        for (long done = 0; done < nq; done += e->maxB) {
+            const int B = (int)(nq - done < e->maxB ? nq - done : e->maxB);
+            const long long* idx = e->rc_list + done;
+            CHK(spec_chain(e, job, 0, idx, B, 0, e->spec, e->logits, st));
+            if (spec_out) launch_scatter_rows(e->spec, idx, (long long)sample0, spec_out, B, 1024, st);
+            if (logits_out) launch_scatter_rows(e->logits, idx, (long long)sample0, logits_out, B, C, st);
+            launch_vote(e->logits, B, C, (unsigned long long*)counts, nullptr, st);
+        }
+        return 0;
+    };
+    int64_t queued_from = 0;
     for (int64_t done = 0; done < n; done += batch) {
         const int B = (int)((n - done < batch) ? (n - done) : batch);
         const uint64_t s0 = sample0 + (uint64_t)done;
-        launch_mc_noise_scale(clip, nullptr, sigma, 1.f, seed, s0, e->xt, B, L, st);      // no wave denoiser: no sqrt(alpha_bar*) scale
-        CHK(mel_db(e, e->xt, B, e->spec, st));
-        launch_philox_normal(seed, s0, 0x5BECu, e->znoise, B, 1024, st);
-        float* x = e->x0;                                                                   // [B][32][32] chain state
-        launch_spec_diffuse(e->spec, e->znoise, mel_lo, mel_hi, q_a, q_b, x, (long)B * 1024, st);
-        for (int t = t_star; t >= 0; --t)
-            CHK(dmad_unet_p_sample(e, x, t, c_a[t], c_b[t], c_1[t], c_2[t], t > 0 ? c_sig[t] : 0.f, nullptr, seed, s0, B, nullptr, s));
         float* sp = spec_out ? spec_out + done * 1024 : e->spec;
-        launch_spec_unstandardize(x, mel_lo, mel_hi, sp, (long)B * 1024, st);
         float* lg = logits_out ? logits_out + done * C : e->logits;
-        CHK(classify(e, sp, B, lg, st));
-        launch_vote(lg, B, C, (unsigned long long*)counts, nullptr, st);
+        CHK(spec_chain(e, job, s0, nullptr, B, -1, sp, lg, st));
+        if (recheck) {
+            launch_vote_margin(lg, B, C, (unsigned long long*)counts, e->tau_spec, (long long)s0, nullptr, e->rc_list, e->rc_n, e->rc_cap, nullptr, st);
+            if (done + B - queued_from + batch > e->rc_cap && done + B < n) { CHK(drain()); queued_from = done + B; }
+        } else {
+            launch_vote(lg, B, C, (unsigned long long*)counts, nullptr, st);
+        }
     }
+    if (recheck && n > 0) CHK(drain());
+    e->st_spec_samples += n;
     LASTCHK();
+    return 0;
+}
+
+int dmad_set_spec_recheck_margin(dmad_engine* e, float tau) {
+    if (!e) return fail(DMAD_ERR_INVALID, "null engine");
+    if (!(tau >= 0.f)) return fail(DMAD_ERR_INVALID, "recheck margin must be >= 0");
+    e->tau_spec = tau;
+    return 0;
+}
+
+int dmad_spec_recheck_stats(dmad_engine* e, int64_t* samples, int64_t* rechecked, int32_t reset) {
+    if (!e) return fail(DMAD_ERR_INVALID, "null engine");
+    if (samples) *samples = e->st_spec_samples;
+    if (rechecked) *rechecked = e->st_spec_rechecked;
+    if (reset) e->st_spec_samples = e->st_spec_rechecked = 0;
     return 0;
 }
 
@@ -1569,8 +1773,12 @@ int dmad_time_layer(dmad_engine* e, int32_t layer, int32_t B, int32_t iters, flo
         double sum[9] = {0};
         for (size_t i = 0; i < 256 && i < nblk; ++i)   // per-workgroup phase sums over all its tiles
             for (int k = 0; k < 8; ++k) sum[k + 1] += (double)h[i * 8 + k];
-        fprintf(stderr, "[dmad stamps] top-wait %.0f | gemm1 %.0f | gate0+barrier %.0f | gate||gemm2 %.0f | barrier %.0f | epi0 write %.0f | epi0 rows %.0f | epi1 %.0f  (mean cycles per tile, %zu tiles)\n",
-                sum[1] / nblk, sum[2] / nblk, sum[3] / nblk, sum[4] / nblk, sum[5] / nblk, sum[6] / nblk, sum[7] / nblk, sum[8] / nblk, nblk);
+        const size_t nwg = nblk < 256 ? nblk : 256;
+        fprintf(stderr, "[dmad stamps] top-wait %.0f | gemm1 %.0f | gate0+barrier %.0f | gate||gemm2 %.0f | barrier %.0f | epilogue %.0f  (mean cycles per tile, %zu tiles); "
+                "in-kernel clock %.3f GHz (shader cycles / 100 MHz ticks over the workgroups' lifetimes)\n",
+                sum[1] / nblk, sum[2] / nblk, sum[3] / nblk, sum[4] / nblk, sum[5] / nblk, sum[8] / nblk, nblk,
+                sum[7] > 0 ? sum[6] / sum[7] * 0.1 : 0.0);
+        (void)nwg;
         (void)hipFree(dbg);
     }
     return 0;

@@ -5,7 +5,8 @@
 namespace dmad {
 
 void launch_philox_raw(uint64_t seed, uint64_t sample, uint32_t stream, uint32_t nblocks, uint32_t* out, hipStream_t s);
-void launch_philox_normal(uint64_t seed, uint64_t sample0, uint32_t stream, float* z, int B, int L, hipStream_t s);
+void launch_philox_normal(uint64_t seed, uint64_t sample0, uint32_t stream, float* z, int B, int L, hipStream_t s,
+                          const long long* idx = nullptr);      // idx != nullptr: row b is sample idx[b] instead of sample0 + b
 void launch_mc_noise_scale(const float* clip, const float* delta, float sigma, float scale, uint64_t seed, uint64_t sample0,
                            float* xt, int B, int L, hipStream_t s);
 void launch_mc_noise_scale_idx(const float* clip, const float* delta, float sigma, float scale, uint64_t seed, uint64_t sample0,

@@ -46,14 +46,14 @@ __global__ void philox_raw_kernel(uint64_t seed, uint64_t sample, uint32_t strea
     out[4 * i + 0] = c[0]; out[4 * i + 1] = c[1]; out[4 * i + 2] = c[2]; out[4 * i + 3] = c[3];
 }
 
-// z[b][l] ~ N(0,1), sample index = sample0 + b
-__global__ void philox_normal_kernel(uint64_t seed, uint64_t sample0, uint32_t stream, float* z, int B, int L) {
+// z[b][l] ~ N(0,1), sample index = sample0 + b, or idx[b] when an index list is given (the recheck passes)
+__global__ void philox_normal_kernel(uint64_t seed, uint64_t sample0, uint32_t stream, float* z, int B, int L, const long long* __restrict__ idx) {
     const int per = L / 4;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * per) return;
     const int b = (int)(i / per), blk = (int)(i - (long)b * per);
     float v[4];
-    philox_normal4(seed, sample0 + b, stream, blk, v);
+    philox_normal4(seed, idx ? (uint64_t)idx[b] : sample0 + b, stream, blk, v);
     *(float4*)(z + (long)b * L + blk * 4) = float4{v[0], v[1], v[2], v[3]};
 }
 
@@ -384,8 +384,8 @@ static inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / b
 void launch_philox_raw(uint64_t seed, uint64_t sample, uint32_t stream, uint32_t nblocks, uint32_t* out, hipStream_t s) {
     hipLaunchKernelGGL(philox_raw_kernel, dim3(nblk(nblocks, 256)), dim3(256), 0, s, seed, sample, stream, nblocks, out);
 }
-void launch_philox_normal(uint64_t seed, uint64_t sample0, uint32_t stream, float* z, int B, int L, hipStream_t s) {
-    hipLaunchKernelGGL(philox_normal_kernel, dim3(nblk((long)B * (L / 4), 256)), dim3(256), 0, s, seed, sample0, stream, z, B, L);
+void launch_philox_normal(uint64_t seed, uint64_t sample0, uint32_t stream, float* z, int B, int L, hipStream_t s, const long long* idx) {
+    hipLaunchKernelGGL(philox_normal_kernel, dim3(nblk((long)B * (L / 4), 256)), dim3(256), 0, s, seed, sample0, stream, z, B, L, idx);
 }
 void launch_mc_noise_scale(const float* clip, const float* delta, float sigma, float scale, uint64_t seed, uint64_t sample0,
                            float* xt, int B, int L, hipStream_t s) {

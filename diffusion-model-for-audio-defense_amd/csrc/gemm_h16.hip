@@ -1,0 +1,178 @@
+// f16 implicit-GEMM for NHWC convolutions on v_mfma_f32_16x16x32_f16 (fp32 accumulate): the 16-bit tier of the Improved-Diffusion
+// UNet purifier (reference improved_diffusion/unet.py:278-491; every conv / 1x1 of ResBlock :107-197, AttentionBlock :200-252,
+// Downsample / Upsample :49-111).
+//
+//   C[n][m] = sum_tap sum_k A[tap][m][k] * X[pixel(n, tap)][k] + shift[m] (+ res[n][m])
+//
+// Same operand scheme as the fp32 gather-GEMM (gemm_f32.hip): both operands are row gathers of 64-byte k-chunks (here 32 halves)
+// staged by LDS-DMA, every lane fetching the 16 bytes that belong at its own LDS position (64-byte rows, chunks XOR-swizzled by
+// swz64(row)), so that an MFMA fragment — 8 consecutive k of one row — is ONE conflict-free ds_read_b128.  Rows outside the
+// problem (zero padding, N tail) come from a zero page.  One f16 MFMA per staged fragment pair is 16x less matrix time per staged
+// byte than the fp32 kernel's, so the tile is large and the pipeline deep (the split-f16 kernel's geometry): 384 staged rows per
+// k-step split as BM x BN = 256 x 128 or 128 x 256 (layers with 128 output channels per block row), 8 waves of 64 x 64, k-steps
+// of 64 halves (two 64-byte sub-stages), 3-slot LDS ring of 48 KiB (144 KiB, one workgroup per CU, two waves per SIMD), two
+// k-steps in flight while one is contracted, one barrier per k-step.
+#include "gemm_h16.h"
+
+namespace dmad {
+
+namespace {
+constexpr int HK = 32;                          // halves per 64-byte sub-stage row
+constexpr int SUB = 384 * 64;                   // bytes per sub-stage (384 rows of 64 B)
+constexpr int KSTEP = 2 * SUB, H16_LDS = 3 * KSTEP;
+__device__ __attribute__((aligned(64))) unsigned short g_zero_page_h[32];      // 64 B of zeros
+
+#define GH_WAIT_BARRIER(N)                                                          \
+    do {                                                                            \
+        asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");                       \
+        __builtin_amdgcn_s_waitcnt(0x0070 | ((N) & 15) | (((N) >> 4) << 14));       \
+        __builtin_amdgcn_s_barrier();                                               \
+        asm volatile("" ::: "memory");                                              \
+    } while (0)
+
+thread_local int g_bad = 0;
+}  // namespace
+
+template <int BM, bool TWO>
+__global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
+    constexpr int BN = 384 - BM, WN = BN / 64;          // waves along N (2 or 4); along M: BM / 64
+    constexpr int APIECES = BM / 128;                   // 128-row staging pieces that hold A rows (the rest hold X rows)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv / WN, wn = wv % WN, q = lane >> 4, r16 = lane & 15;
+    const long n0 = (long)blockIdx.x * BN;
+    const int m0 = blockIdx.y * BM;
+    const int subs_per_tap = a.K / HK, nsteps = (a.taps * subs_per_tap) >> 1;
+    // staging rows of this thread: piece p (p = 0..2) row p*128 + rloc; chunk slot = (lane & 3) ^ swz64(row)
+    const int rloc = wv * 16 + (lane >> 2), ch8 = ((lane & 3) ^ swz64(lane >> 2)) * 8;
+    const h16_t* zero = g_zero_page_h;
+    const h16_t* arow[APIECES];
+#pragma unroll
+    for (int p = 0; p < APIECES; ++p) arow[p] = a.A + (size_t)(m0 + p * 128 + rloc) * a.K + ch8;      // M % BM == 0 (launcher)
+    constexpr int XP = 3 - APIECES;
+    long xpix[XP];
+    int xy[XP], xx[XP];
+    bool xok[XP];
+    const int st = a.stride > 1 ? a.stride : 1;
+    const int Wo = (a.W - 1) / st + 1, Ho = (a.H - 1) / st + 1, hw = Ho * Wo;
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+        const long n = n0 + p * 128 + rloc;
+        xok[p] = n < a.N;
+        xpix[p] = 0; xy[p] = 0; xx[p] = 0;
+        if (xok[p]) {
+            const long b = n / hw;
+            const int pix = (int)(n - b * hw);
+            xy[p] = (pix / Wo) * st; xx[p] = (pix % Wo) * st;
+            xpix[p] = b * a.H * a.W;
+        }
+    }
+    auto stage = [&](int sub, char* base) {              // base: this sub-stage's 24 KiB (rows 0..383 of 64 B)
+        const int tap = sub / subs_per_tap, kc = (sub - tap * subs_per_tap) * HK;
+        char* la = base + wv * 1024;
+#pragma unroll
+        for (int p = 0; p < APIECES; ++p) glds16(arow[p] + (size_t)tap * a.M * a.K + kc, la + p * 8192);
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+            const h16_t* src = zero;
+            if (xok[p]) {
+                const int yy = xy[p] + (a.taps == 9 ? tap / 3 - 1 : 0), xq = xx[p] + (a.taps == 9 ? tap % 3 - 1 : 0);
+                if ((unsigned)yy < (unsigned)a.H && (unsigned)xq < (unsigned)a.W) {
+                    const long pix = xpix[p] + (long)yy * a.W + xq;
+                    src = (TWO && kc >= a.ksplit) ? a.X2 + pix * a.ldx2 + (kc - a.ksplit) + ch8 : a.X + pix * a.ldx + kc + ch8;
+                }
+            }
+            glds16(src, la + (APIECES + p) * 8192);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frag = r16 * 64 + ((q ^ swz64(r16)) * 16);
+    stage(0, smem); stage(1, smem + SUB);
+    if (nsteps > 1) { stage(2, smem + KSTEP); stage(3, smem + KSTEP + SUB); }
+    int slot = 0;
+    for (int p = 0; p < nsteps; ++p) {
+        // k-step p landed (the 6 pieces of k-step p+1 may still fly); every wave is done reading k-step p-1
+        if (p + 1 < nsteps) { GH_WAIT_BARRIER(6); } else { GH_WAIT_BARRIER(0); }
+        if (p + 2 < nsteps) {
+            char* nb = smem + (slot == 0 ? 2 : slot - 1) * KSTEP;        // the slot k-step p-1 occupied
+            stage(2 * p + 4, nb); stage(2 * p + 5, nb + SUB);
+        }
+        const char* A0 = smem + slot * KSTEP + wm * 4096 + frag;
+        const char* B0 = smem + slot * KSTEP + BM * 64 + wn * 4096 + frag;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(A0 + h * SUB + i * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *(const f16x8*)(B0 + h * SUB + j * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    // epilogue: bias, optional residual; fp32 map and / or its f16 twin
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + q * 4;
+        const float4 b4 = a.shift ? *(const float4*)(a.shift + m) : float4{0.f, 0.f, 0.f, 0.f};
+        const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long n = n0 + wn * 64 + j * 16 + r16;
+            if (n >= a.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + ba[r];
+            if (a.res) {
+                const float4 rr = *(const float4*)(a.res + n * a.ldc + m);
+                v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+            }
+            if (a.C) *(float4*)(a.C + n * a.ldc + m) = float4{v[0], v[1], v[2], v[3]};
+            if (a.C16) *(f16x4*)(a.C16 + n * a.ldc + m) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        }
+    }
+}
+
+int gemm_h16_configure() {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_h16_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_h16_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_h16_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipFuncSetAttribute((const void*)gemm_h16_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS);
+}
+
+int gemm_h16_take_bad_shapes() { const int n = g_bad; g_bad = 0; return n; }
+
+int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
+    const int subs = a.taps * (a.K / HK);
+    const bool two = a.X2 != nullptr;
+    if ((a.taps != 9 && a.taps != 1) || (a.K % HK) || (subs & 1) || (a.M % 128) || (a.ldc & 3) || a.N < 1 || (!a.C && !a.C16) ||
+        (a.ldx & 7) || (two && ((a.ksplit % HK) || a.ksplit <= 0 || a.ksplit >= a.K || (a.ldx2 & 7)))) {
+        ++g_bad;
+        return -1;
+    }
+    // 256-row tiles where the output channels fill them; 128 x 256 otherwise (128-channel layers, 384 / 768-row qkv convs use
+    // whichever divides M)
+    if (a.M % 256 == 0) {
+        const dim3 grid((unsigned)((a.N + 127) / 128), (unsigned)(a.M / 256));
+        if (two) hipLaunchKernelGGL((gemm_h16_kernel<256, true>), grid, dim3(512), H16_LDS, s, a);
+        else hipLaunchKernelGGL((gemm_h16_kernel<256, false>), grid, dim3(512), H16_LDS, s, a);
+    } else {
+        const dim3 grid((unsigned)((a.N + 255) / 256), (unsigned)(a.M / 128));
+        if (two) hipLaunchKernelGGL((gemm_h16_kernel<128, true>), grid, dim3(512), H16_LDS, s, a);
+        else hipLaunchKernelGGL((gemm_h16_kernel<128, false>), grid, dim3(512), H16_LDS, s, a);
+    }
+    return 0;
+}
+
+}  // namespace dmad

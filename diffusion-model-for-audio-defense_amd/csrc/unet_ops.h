@@ -7,7 +7,8 @@
 namespace dmad {
 
 // conv 3x3, one input channel, padding 1, bias: in [B][32][32] -> out [B][1024][Cout]   (input_blocks.0.0)
-void launch_conv1ch_3x3(const float* in, const float* w, const float* bias, float* out, int B, int Cout, hipStream_t s);
+// out16: optional f16 twin of the output (the 16-bit tier's GEMMs read f16 maps).  Returns -1 for Cout > 128.
+int launch_conv1ch_3x3(const float* in, const float* w, const float* bias, float* out, int B, int Cout, hipStream_t s, h16_t* out16 = nullptr);
 // conv 3x3, 128 -> 1 channel, padding 1, bias: in [B][1024][128] (NHWC), w [9][128] (tap-major), out [B][1024]   (out.2)
 void launch_conv3x3_c128_to1(const float* in, const float* w, const float* bias, float* out, int B, hipStream_t s);
 // GroupNorm32(32, C) in fp32 (nn.py:15-17,92-100) over [B][HW][C], then optionally y * (1 + ss[c]) + ss[C + c]
@@ -16,15 +17,16 @@ void launch_conv3x3_c128_to1(const float* in, const float* w, const float* bias,
 // x2 != nullptr: the input is the channel concatenation [x : c1 channels | x2 : C - c1 channels] (th.cat(dim=1), unet.py:473)
 // read from its two parts; y is always one map of C channels.
 int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* ss, int silu, float* y, int B, int HW,
-                          int C, hipStream_t s, const float* x2 = nullptr, int c1 = 0);
+                          int C, hipStream_t s, const float* x2 = nullptr, int c1 = 0, h16_t* y16 = nullptr);      // y16 != nullptr: the result is written as f16 there (y unused)
 void launch_silu(const float* x, float* y, long n, hipStream_t s);
 // nearest-neighbour x2 (F.interpolate(scale_factor=2, mode="nearest"), unet.py:72)
 void launch_upsample2x_nhwc(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
+void launch_upsample2x_nhwc_h16(const h16_t* in, h16_t* out, int B, int H, int W, int C, hipStream_t s);       // the same on an f16 map, C % 8 == 0
 // QKVAttention (unet.py:241-258) with the reference's head-major channel split: qkv [B*T][3C] (token-major),
 // head h: q = channels h*3*64 + [0,64), k = + 64, v = + 128;  out [B*T][C], channel h*64 + c.  Head width 64.
 // T = 256, 64 or 16 (the 16x16, 8x8 and 4x4 maps this network attends at); returns -1 for any other T, a hipError_t > 0
 // if the kernel could not be configured.
-int launch_qkv_attention(const float* qkv, float* out, int B, int T, int heads, hipStream_t s);
+int launch_qkv_attention(const float* qkv, float* out, int B, int T, int heads, hipStream_t s, h16_t* out16 = nullptr);   // out16: write f16 there instead of out
 // GaussianDiffusion.p_sample (gaussian_diffusion.py:232-257,331-387: epsilon prediction, clip_denoised, fixed variance):
 //   x0 = clamp(ca * x - cb * eps, -1, 1);  out = c1 * x0 + c2 * x + sig * z      (z may be null when sig == 0)
 void launch_unet_p_sample(const float* x, const float* eps, const float* z, float ca, float cb, float c1, float c2, float sig,

@@ -9,7 +9,7 @@ inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1) / b); }
 // one workgroup per image row, one thread per output channel: its 9 weights live in registers, the 3 x 34 input values the
 // row needs are wave-uniform (scalar loads), every store instruction writes whole 256-byte channel rows
 __global__ void __launch_bounds__(128) conv1ch_3x3_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
-                                                          float* __restrict__ out, int Cout) {
+                                                          float* __restrict__ out, int Cout, h16_t* __restrict__ out16) {
     const int co = threadIdx.x, y = blockIdx.x & 31;
     const long b = blockIdx.x >> 5;
     if (co >= Cout) return;
@@ -29,6 +29,7 @@ __global__ void __launch_bounds__(128) conv1ch_3x3_kernel(const float* __restric
                 if ((unsigned)yy < 32u && (unsigned)xx < 32u) s = fmaf(k[ky * 3 + kx], img[yy * 32 + xx], s);
             }
         o[(long)x * Cout] = s + bv;
+        if (out16) out16[((b << 10) + y * 32 + x) * Cout + co] = __builtin_bit_cast(h16_t, (_Float16)(s + bv));
     }
 }
 
@@ -67,7 +68,7 @@ template <int PER>
 __global__ void __launch_bounds__(1024) groupnorm_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ ss, int silu,
                                                               float* __restrict__ y, int HW, int C, int G,
-                                                              const float* __restrict__ x2, int c1) {
+                                                              const float* __restrict__ x2, int c1, h16_t* __restrict__ y16) {
     __shared__ float part[1024];
     __shared__ float gsum[8];
     const int NT = blockDim.x, t = threadIdx.x, lane = t & 63, wv = t >> 6, nwaves = NT >> 6;
@@ -129,7 +130,8 @@ __global__ void __launch_bounds__(1024) groupnorm_nhwc_kernel(const float* __res
             if (silu) u = u / (1.f + expf(-u));
             o[r] = u;
         }
-        *(float4*)(y + base + (long)pix * C) = float4{o[0], o[1], o[2], o[3]};
+        if (y16) *(f16x4*)(y16 + base + (long)pix * C) = f16x4{(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+        else *(float4*)(y + base + (long)pix * C) = float4{o[0], o[1], o[2], o[3]};
     }
 }
 
@@ -149,6 +151,17 @@ __global__ void upsample2x_nhwc_kernel(const float* __restrict__ in, float* __re
     ((float4*)out)[i] = ((const float4*)in)[((b * H + (yo >> 1)) * W + (xo >> 1)) * C4 + c];
 }
 
+__global__ void upsample2x_nhwc_h16_kernel(const h16_t* __restrict__ in, h16_t* __restrict__ out, int H, int W, int C8, long total8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // 8 halves (16 bytes) of output
+    if (i >= total8) return;
+    const int c = (int)(i % C8);
+    long p = i / C8;
+    const int xo = (int)(p % (2 * W)); p /= 2 * W;
+    const int yo = (int)(p % (2 * H));
+    const long b = p / (2 * H);
+    ((u32x4_t*)out)[i] = ((const u32x4_t*)in)[((b * H + (yo >> 1)) * W + (xo >> 1)) * C8 + c];
+}
+
 // QKVAttention on the fp32 matrix cores, transposed so that no fragment ever changes layout:
 //   S^T = K Q^T   (A = key rows, B = query rows, contraction over the 64 head channels)
 //   O^T = V^T P^T (A = V read column-wise from LDS, B = the softmax weights exactly where the first product left them)
@@ -160,7 +173,7 @@ __global__ void upsample2x_nhwc_kernel(const float* __restrict__ in, float* __re
 // holds the whole S^T column block (T / 16 tiles) in registers and does the exact two-pass softmax torch does.
 constexpr int HD = 64, AROW = 68;
 template <int KT>                                       // T = 16 * KT keys / queries
-__global__ void __launch_bounds__(KT >= 8 ? 512 : 64 * KT) qkv_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int heads) {
+__global__ void __launch_bounds__(KT >= 8 ? 512 : 64 * KT) qkv_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int heads, h16_t* __restrict__ out16) {
     extern __shared__ __attribute__((aligned(16))) float att_lds[];
     constexpr int T = 16 * KT, NW = KT >= 8 ? 8 : KT;
     float* Ks = att_lds;
@@ -219,9 +232,12 @@ __global__ void __launch_bounds__(KT >= 8 ? 512 : 64 * KT) qkv_attention_kernel(
                 if (j & 1) __builtin_amdgcn_sched_barrier(0);
             }
         const float inv = 1.f / l;
-        float* o = out + ((long)b * T + qt * 16 + c) * (HD * heads) + h * HD + g * 4;       // O^T tile dt: channels dt * 16 + 4 g + r of query c
+        const long ooff = ((long)b * T + qt * 16 + c) * (HD * heads) + h * HD + g * 4;       // O^T tile dt: channels dt * 16 + 4 g + r of query c
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) *(float4*)(o + dt * 16) = float4{oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv};
+        for (int dt = 0; dt < 4; ++dt) {
+            if (out16) *(f16x4*)(out16 + ooff + dt * 16) = f16x4{(_Float16)(oacc[dt][0] * inv), (_Float16)(oacc[dt][1] * inv), (_Float16)(oacc[dt][2] * inv), (_Float16)(oacc[dt][3] * inv)};
+            else *(float4*)(out + ooff + dt * 16) = float4{oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv};
+        }
     }
 }
 
@@ -261,16 +277,17 @@ void launch_spec_unstandardize(const float* x, float lo, float hi, float* spec, 
     hipLaunchKernelGGL(spec_unstandardize_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, x, lo, hi - lo, spec, n);
 }
 
-void launch_conv1ch_3x3(const float* in, const float* w, const float* bias, float* out, int B, int Cout, hipStream_t s) {
-    if (Cout > 128) abort();                       // one thread per output channel (this network: 128)
-    hipLaunchKernelGGL(conv1ch_3x3_kernel, dim3((unsigned)B * 32u), dim3(128), 0, s, in, w, bias, out, Cout);
+int launch_conv1ch_3x3(const float* in, const float* w, const float* bias, float* out, int B, int Cout, hipStream_t s, h16_t* out16) {
+    if (Cout > 128) return -1;                     // one thread per output channel (this network: 128)
+    hipLaunchKernelGGL(conv1ch_3x3_kernel, dim3((unsigned)B * 32u), dim3(128), 0, s, in, w, bias, out, Cout, out16);
+    return 0;
 }
 void launch_conv3x3_c128_to1(const float* in, const float* w, const float* bias, float* out, int B, hipStream_t s) {
     const long total = (long)B * 1024;
     hipLaunchKernelGGL(conv3x3_c128_to1_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, in, w, bias, out, total);
 }
 int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* ss, int silu, float* y, int B, int HW,
-                          int C, hipStream_t s, const float* x2, int c1) {
+                          int C, hipStream_t s, const float* x2, int c1, h16_t* y16) {
     const int c4 = C >> 7;
     if (C % 128 || c4 < 1 || c4 > 4 || B < 1 || HW < 1) return -1;
     if (x2 && (c1 < 4 || c1 >= C || (c1 & 3))) return -1;       // 32 groups of 4, 8, 12 or 16 channels
@@ -285,7 +302,7 @@ int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta,
     const int want = HW >= 1024 ? 8 : HW >= 256 ? 4 : 2;          // float4s per thread: small maps are latency bound and want more threads
     while (per < want && NT > 64 && (NT / 2) % R == 0 && (NT / 2) % 64 == 0) { NT /= 2; per = (int)((n4 + NT - 1) / NT); }
     const dim3 grid((unsigned)(B * (32 / G)));
-#define GN_LAUNCH(PER) hipLaunchKernelGGL(groupnorm_nhwc_kernel<PER>, grid, dim3(NT), 0, s, x, gamma, beta, ss, silu, y, HW, C, G, x2, c1)
+#define GN_LAUNCH(PER) hipLaunchKernelGGL(groupnorm_nhwc_kernel<PER>, grid, dim3(NT), 0, s, x, gamma, beta, ss, silu, y, HW, C, G, x2, c1, y16)
     if (per <= 1) GN_LAUNCH(1);
     else if (per <= 2) GN_LAUNCH(2);
     else if (per <= 4) GN_LAUNCH(4);
@@ -298,20 +315,24 @@ int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta,
 void launch_silu(const float* x, float* y, long n, hipStream_t s) {
     hipLaunchKernelGGL(silu_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, x, y, n);
 }
+void launch_upsample2x_nhwc_h16(const h16_t* in, h16_t* out, int B, int H, int W, int C, hipStream_t s) {
+    const long total8 = (long)B * 4 * H * W * (C / 8);
+    hipLaunchKernelGGL(upsample2x_nhwc_h16_kernel, dim3(nblk(total8, 256)), dim3(256), 0, s, in, out, H, W, C / 8, total8);
+}
 void launch_upsample2x_nhwc(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
     const long total4 = (long)B * 4 * H * W * (C / 4);
     hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3(nblk(total4, 256)), dim3(256), 0, s, in, out, H, W, C / 4, total4);
 }
-int launch_qkv_attention(const float* qkv, float* out, int B, int T, int heads, hipStream_t s) {
+int launch_qkv_attention(const float* qkv, float* out, int B, int T, int heads, hipStream_t s, h16_t* out16) {
     const size_t lds = (size_t)2 * T * AROW * sizeof(float);
     if (T == 256) {
         static const hipError_t once = hipFuncSetAttribute((const void*)qkv_attention_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (once != hipSuccess) return (int)once;
-        hipLaunchKernelGGL(qkv_attention_kernel<16>, dim3((unsigned)heads, (unsigned)B), dim3(512), lds, s, qkv, out, heads);
+        hipLaunchKernelGGL(qkv_attention_kernel<16>, dim3((unsigned)heads, (unsigned)B), dim3(512), lds, s, qkv, out, heads, out16);
     } else if (T == 64) {
-        hipLaunchKernelGGL(qkv_attention_kernel<4>, dim3((unsigned)heads, (unsigned)B), dim3(256), lds, s, qkv, out, heads);
+        hipLaunchKernelGGL(qkv_attention_kernel<4>, dim3((unsigned)heads, (unsigned)B), dim3(256), lds, s, qkv, out, heads, out16);
     } else if (T == 16) {
-        hipLaunchKernelGGL(qkv_attention_kernel<1>, dim3((unsigned)heads, (unsigned)B), dim3(64), lds, s, qkv, out, heads);
+        hipLaunchKernelGGL(qkv_attention_kernel<1>, dim3((unsigned)heads, (unsigned)B), dim3(64), lds, s, qkv, out, heads, out16);
     } else {
         return -1;                  // this network attends at 16x16, 8x8 (script_util.py attention_resolutions "16,8") and 4x4 (middle block)
     }

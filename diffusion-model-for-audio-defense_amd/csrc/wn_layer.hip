@@ -107,8 +107,14 @@ __global__ void __launch_bounds__(512, 2) wn_layer_p(WnLayerArgs a, int ntiles) 
             tprev = now;
         }
     };
+    // slots 5 / 6 of the diagnostic build: shader cycles and 100 MHz ticks of the whole workgroup lifetime -> the clock the
+    // chip held inside this kernel (MI355X_MICROARCH.md, DVFS give-back item 6)
+    unsigned long long t_begin = 0, r_begin = 0;
+    if constexpr (STAMP) { t_begin = __builtin_amdgcn_s_memtime(); r_begin = __builtin_amdgcn_s_memrealtime(); }
     auto flush = [&]() {
         if constexpr (STAMP) {
+            tacc[5] = __builtin_amdgcn_s_memtime() - t_begin;
+            tacc[6] = __builtin_amdgcn_s_memrealtime() - r_begin;
             if (threadIdx.x == 0)
                 for (int k = 0; k < 8; ++k) a.dbg[(size_t)blockIdx.x * 8 + k] = tacc[k];
         }

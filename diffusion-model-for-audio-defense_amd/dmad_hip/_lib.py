@@ -19,9 +19,12 @@ class DmadConfig(C.Structure):
     """dmad_config of include/dmad.h; positional arguments are the fields AFTER struct_size, which is filled in here."""
     _fields_ = [(n, C.c_int32) for n in (
         'struct_size', 'res_channels', 'skip_channels', 'num_res_layers', 'dilation_cycle', 'embed_dim_in', 'embed_dim_mid',
-        'embed_dim_out', 'clip_len', 'max_batch', 'num_classes', 'precision', 'with_classifier', 'recheck_batch', 'half_type')]
+        'embed_dim_out', 'clip_len', 'max_batch', 'num_classes', 'precision', 'with_classifier', 'recheck_batch', 'half_type',
+        'with_wavenet')]
 
     def __init__(self, *fields, **named):
+        if len(fields) < 15:
+            named.setdefault('with_wavenet', 1)
         super().__init__(C.sizeof(type(self)), *fields, **named)
 
 
@@ -60,6 +63,8 @@ _SIGNATURES = {
                                     C.c_uint64, C.c_uint64, _P, _P, _P]),
     'dmad_spec_smooth_votes': (C.c_int, [_P, _P, C.c_float, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, _P, C.c_float, C.c_float,
                                          C.c_int64, C.c_int32, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
+    'dmad_set_spec_recheck_margin': (C.c_int, [_P, C.c_float]),
+    'dmad_spec_recheck_stats': (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
     'dmad_vote': (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     'dmad_philox_raw': (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _P, _P]),
     'dmad_philox_normal': (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int32, _P, _P]),

@@ -30,6 +30,10 @@ DEFAULT_RECHECK_MARGIN = {1: 0.034, 0: 0.30}          # by dmad_half_type: HALF_
 # The queued samples first go through the split-f16 tier (fp32 pipeline, three f16 MFMAs per product, ~22 significant bits);
 # only those whose margin is inside ITS error bound reach the exact-fp32 path.
 DEFAULT_RECHECK_MARGIN2 = 1e-3
+# Spec-domain vote loop (BASELINE C5): the UNet's 16-bit tier runs the whole 26-evaluation chain on f16 operands; a sample whose
+# top-2 logit margin is below this bound re-runs its chain on the exact-fp32 UNet.  Measured with tools/gpu_c5_flip_study.py
+# (profiles/r03_c5_flip_study.md): the same leader-difference statistic as DEFAULT_RECHECK_MARGIN, x headroom.
+DEFAULT_SPEC_RECHECK_MARGIN = 0.4
 # Tail rule shared by the committed default and calibrate_recheck (tools/fit_recheck_tail.py): with s the
 # Gaussian scale of the per-sample leader-difference error, a bound of TAIL_Z * s keeps the modelled miss probability per
 # sample (error beyond the bound AND an exact margin small enough to be overturned) at or below 1e-9.
@@ -158,7 +162,7 @@ class Engine:
 
     def __init__(self, wavenet_config: Optional[dict] = None, clip_len: int = 16000, max_batch: int = 64,
                  num_classes: int = 10, precision: int = BF16, with_classifier: bool = True, recheck_batch: int = 0,
-                 recheck_margin: Optional[float] = None, half_type: Optional[int] = None):
+                 recheck_margin: Optional[float] = None, half_type: Optional[int] = None, with_wavenet: bool = True):
         if not torch.cuda.is_available():
             raise DmadError('no MI355X/HIP device visible: the dmad engine has no CPU path')
         self.lib = _lib.load()
@@ -172,8 +176,9 @@ class Engine:
         self.cfg = DmadConfig(wc['res_channels'], wc['skip_channels'], wc['num_res_layers'], wc['dilation_cycle'],
                               wc['diffusion_step_embed_dim_in'], wc['diffusion_step_embed_dim_mid'],
                               wc['diffusion_step_embed_dim_out'], clip_len, max_batch, num_classes, precision,
-                              1 if with_classifier else 0, recheck_batch, half_type)
+                              1 if with_classifier else 0, recheck_batch, half_type, 1 if with_wavenet else 0)
         self.half_type = half_type
+        self.with_wavenet = bool(with_wavenet)
         self.L, self.max_batch, self.num_classes, self.precision = clip_len, max_batch, num_classes, precision
         self.num_res_layers = wc['num_res_layers']
         self.wavenet_geometry = Engine.geometry(wc)
@@ -195,6 +200,7 @@ class Engine:
                 recheck_margin = float(os.environ.get('DMAD_RECHECK_MARGIN', DEFAULT_RECHECK_MARGIN[half_type]))
             self.set_recheck_margin(recheck_margin)
             self.set_recheck_margin2(float(os.environ.get('DMAD_RECHECK_MARGIN2', DEFAULT_RECHECK_MARGIN2)))
+            self.set_spec_recheck_margin(float(os.environ.get('DMAD_SPEC_RECHECK_MARGIN', DEFAULT_SPEC_RECHECK_MARGIN)))
 
     def close(self):
         if getattr(self, '_h', None):
@@ -260,6 +266,17 @@ class Engine:
         check(self.lib.dmad_set_recheck_margin2(self._h, float(tau2)))
         self.recheck_margin2 = float(tau2)
 
+    def set_spec_recheck_margin(self, tau: float):
+        """bound of the spec-domain vote loop's 16-bit UNet tier (dmad_set_spec_recheck_margin)."""
+        check(self.lib.dmad_set_spec_recheck_margin(self._h, float(tau)))
+        self.spec_recheck_margin = float(tau)
+
+    def spec_recheck_stats(self, reset: bool = False):
+        """-> (samples voted by spec_smooth_votes, samples whose chain was re-run on the exact-fp32 UNet) since the last reset."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(self.lib.dmad_spec_recheck_stats(self._h, C.byref(a), C.byref(b), 1 if reset else 0))
+        return int(a.value), int(b.value)
+
     def recheck_stats(self, reset: bool = False, detail: bool = False):
         """-> (samples voted, samples that left the 16-bit pass) since the last reset; detail: + samples that reached fp32."""
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
@@ -296,7 +313,7 @@ class Engine:
             return float(lead_err(a, b).max())
 
         def gauss_scale(le):                 # P(max of 9 |normal differences| > x) ~= 18 Q(x / s): s from the q90 and q99 points
-            zs = {0.9: 2.5392, 0.99: 3.2579}            # 18 Q(z) = 1 - q
+            zs = {0.9: 2.5392, 0.99: 3.2608}            # 18 Q(z) = 1 - q
             return max(float(torch.quantile(le, q)) / z for q, z in zs.items())
         e1 = e2 = s1 = 0.0
         try:

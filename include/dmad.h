@@ -77,6 +77,9 @@ typedef struct dmad_config {
     int32_t recheck_batch;      /* DMAD_EXACT: clips per pass of the recheck tiers (0 = 32; clamped to max_batch; the
                                  * Python engine and bench.py pass 64) */
     int32_t half_type;          /* enum dmad_half_type                   */
+    int32_t with_wavenet;       /* 1: WaveNet workspace (residual streams, gate store: 330 MB per clip of max_batch on the
+                                 * 16-bit path).  0: an engine for the spec-domain purifier / classifier only (BASELINE C5): no
+                                 * WaveNet weights can be loaded, none of that memory is held */
 } dmad_config;
 
 int dmad_create(const dmad_config* cfg, dmad_engine** out);
@@ -230,6 +233,17 @@ int dmad_debug_rounding(dmad_engine* e, const int32_t masks[5]);
 int dmad_spec_smooth_votes(dmad_engine* e, const float* clip, float sigma, int32_t t_star, float q_a, float q_b, const float* c_a,
                            const float* c_b, const float* c_1, const float* c_2, const float* c_sig, float mel_lo, float mel_hi, int64_t n,
                            int32_t batch, uint64_t seed, uint64_t sample0, int64_t* counts, float* logits_out, float* spec_out, dmad_stream s);
+
+/* The UNet's tiers.  Engines of precision DMAD_BF16 / DMAD_EXACT hold, beside the exact-fp32 UNet, a 16-BIT TIER of it: every
+ * conv / 1x1 (unet.py:107-252) on f16 operands with fp32 accumulation (v_mfma_f32_16x16x32_f16), GroupNorm, softmax, bias and
+ * residual sums and the maps themselves in fp32.  dmad_unet_eps / dmad_unet_p_sample evaluate the tier the mode selects
+ * (DMAD_MODE_FP32: exact fp32, otherwise the 16-bit tier; DMAD_FP32 engines have only the fp32 one).  In DMAD_MODE_EXACT_VOTES
+ * dmad_spec_smooth_votes runs every sample's chain on the 16-bit tier, queues the samples whose top-2 logit margin is below
+ * tau_spec (dmad_set_spec_recheck_margin; default 0.4 = 1.6 x the largest leader-difference error of the 16-bit chain measured on 6 144 samples) and re-runs their WHOLE chain on the exact-fp32
+ * UNet from the same Philox keys — the same empirical guarantee as the waveform loop's (dmad_set_mode).
+ * dmad_spec_recheck_stats: samples voted by dmad_spec_smooth_votes, samples whose chain was re-run in fp32. */
+int dmad_set_spec_recheck_margin(dmad_engine* e, float tau);
+int dmad_spec_recheck_stats(dmad_engine* e, int64_t* samples, int64_t* rechecked, int32_t reset);
 
 /* Batched query of the whole system for the gradient-free attack drivers: EOT.forward evaluates
  * model(x_batch.repeat(EOT_batch_size, 1, 1)) EOT_num_batches times (robustness_eval/_EOT.py:30-64; callers

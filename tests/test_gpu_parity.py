@@ -590,7 +590,8 @@ def test_unet_purifier_vs_reference_fixture(golden_dir):
     from dmad_hip import engine as E
     from diffusion_models.improved_diffusion_ddpm import create_improved_diffusion, melspec_standardize, melspec_inv_standardize
     z = G(golden_dir, 'unet.npz')
-    eng = E.Engine(max_batch=4, precision=E.BF16, with_classifier=False)
+    eng = E.Engine(max_batch=4, precision=E.EXACT, with_classifier=False, with_wavenet=False)      # both UNet tiers, no WaveNet workspace
+    eng.set_mode(E.MODE_FP32)                                  # the exact-fp32 UNet: the tier pinned to the reference fixtures
     pur = create_improved_diffusion(None, reverse_timestep=3, state_dict=synth.unet_state_dict(int(z['seed'])), engine=eng)
     model, gd = pur.model, pur.diffusion
     spec = torch.from_numpy(z['spec']).cuda()
@@ -620,6 +621,20 @@ def test_unet_purifier_vs_reference_fixture(golden_dir):
     assert out.shape == again.shape
     with pytest.raises(NotImplementedError):
         model(x0, torch.tensor([3, 4]).cuda())
+    # the 16-bit tier (f16 operands in every conv / 1x1, fp32 accumulate, fp32 GroupNorm / softmax / sums): same fixtures, f16 tolerance
+    eng.set_mode(E.MODE_FAST)
+    for t in (3, 40):
+        e16 = model(torch.from_numpy(z['x_t%d' % t]).cuda(), torch.full((2,), t, dtype=torch.long).cuda())
+        assert 1e-5 < relmax(e16.cpu().numpy(), z['eps_t%d' % t]) < F16_MAX_TOL, (t, relmax(e16.cpu().numpy(), z['eps_t%d' % t]))
+    solo16 = model(torch.from_numpy(z['x_t3'][1:]).cuda(), torch.tensor([3]))
+    assert torch.equal(solo16, model(torch.from_numpy(z['x_t3']).cuda(), torch.tensor([3, 3]))[1:])    # batch invariance holds on this tier too
+    with pytest.raises(E.DmadError):
+        eng.load_wavenet(synth.wavenet_state_dict(1234))       # created with with_wavenet = 0
+    eng.close()
+    f32 = E.Engine(max_batch=2, precision=E.FP32, with_classifier=False, with_wavenet=False)
+    create_improved_diffusion(None, reverse_timestep=3, state_dict=synth.unet_state_dict(int(z['seed'])), engine=f32)
+    assert relmax(f32.unet_eps(torch.from_numpy(z['x_t3']).cuda(), 3).cpu().numpy(), z['eps_t3'][:, 0]) < 5e-4      # FP32 engines: the fp32 tier only
+    f32.close()
 
 
 # ------------------------------------------------------------------------------------------ BASELINE.json configs at full size
@@ -815,7 +830,9 @@ def test_bench_contract():
     ff = j['roofline_final']
     assert ff['bound'] == 'hbm' and ff['unit'] == 'GB/s' and ff['peak'] == 8000.0 and ff['launches_timed'] == 1 and 0 < ff['frac'] < 1.5
     c5 = j['c5_spec_mode']                 # BASELINE C5 beside the headline: the spec-domain vote loop on its own fp32 engine
-    assert c5['n'] == 16 and sum(c5['votes']) == 16 and c5['samples_per_s'] > 0 and c5['dtype'] == 'f32' and 0 < c5['frac_of_fp32_matrix_peak'] < 1
+    assert c5['n'] == 16 and sum(c5['votes']) == 16 and c5['samples_per_s'] > 0 and c5['dtype'] == 'f16' and 0 <= c5['recheck_frac'] <= 1
+    assert c5['exact_equals_fp32'] is True and sum(c5['fp32_mode']['votes']) == c5['fp32_mode']['n'] == 16 and 0 < c5['fp32_mode']['frac_of_fp32_matrix_peak'] < 1
+    assert c5['fast_mode']['samples_per_s'] > 0 and sum(c5['fast_mode']['votes']) == 16
     # the line proves its own exactness claim: the first timed step's keys in the exact-vote mode and on the exact-fp32 path
     ck = j['exact_vs_fp32_check']
     assert j['exact_equals_fp32'] is True and ck['votes_exact'] == ck['votes_fp32'] and sum(ck['votes_fp32']) == ck['samples'] == 8
@@ -1125,6 +1142,47 @@ def test_config5_spec_domain_vote_loop(golden_dir):
     eng.close()
 
 
+def test_config5_exact_votes_on_the_16bit_unet_tier():
+    """BASELINE C5 in the exact-vote mode: the whole chain on the UNet's 16-bit tier, every sample whose top-2 margin is below
+    tau_spec re-run on the exact-fp32 UNet from the same Philox keys.  Counts equal the fp32 engine mode's on the same keys (also
+    with every sample forced through the recheck, and across shards), the rechecked rows of logits_out are the fp32 tier's bit
+    for bit, the 16-bit tier alone stays within its error statistic, and the statistics count what was re-run."""
+    from diffusion_models.improved_diffusion_ddpm import create_improved_diffusion
+    from dmad_hip import engine as E
+    eng = E.Engine(max_batch=64, precision=E.EXACT, with_wavenet=False)
+    eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321))
+    pur = create_improved_diffusion(None, reverse_timestep=5, state_dict=synth.unet_state_dict(31), engine=eng)
+    coef = tuple(pur.purify_coefficients())
+    N = 384
+    for ci, sigma in ((4, 0.5), (5, 1.0)):
+        clip = torch.from_numpy(synth.synthetic_clip(ci)).cuda()
+        args = (clip, sigma) + coef + (-100.0, 38.22)
+        eng.set_mode(E.MODE_FP32)
+        c32, l32, _ = eng.spec_smooth_votes(*args, N, seed=11, want_logits=True)
+        eng.set_mode(E.MODE_FAST)
+        c16, l16, _ = eng.spec_smooth_votes(*args, N, seed=11, want_logits=True)
+        e = (l16 - l32).double()
+        lead = float((e - e.gather(1, l32.argmax(1, keepdim=True))).abs().max())
+        assert 1e-5 < lead < eng.spec_recheck_margin, lead                       # the statistic the bound covers, with room
+        eng.set_mode(E.MODE_EXACT_VOTES)
+        eng.spec_recheck_stats(reset=True)
+        cx, lx, _ = eng.spec_smooth_votes(*args, N, seed=11, want_logits=True)
+        voted, re = eng.spec_recheck_stats()
+        assert cx.tolist() == c32.tolist() and voted == N and 0 <= re < N
+        top2 = l16.topk(2, dim=1).values
+        low = (top2[:, 0] - top2[:, 1]) < eng.spec_recheck_margin
+        assert int(low.sum()) == re and torch.equal(lx[low], l32[low]) and torch.equal(lx[~low], l16[~low])
+        a, _, _ = eng.spec_smooth_votes(*args, 150, batch=40, seed=11)           # shards of the same index range
+        b, _, _ = eng.spec_smooth_votes(*args, N - 150, batch=64, seed=11, sample0=150)
+        assert (a + b).tolist() == c32.tolist()
+    old = eng.spec_recheck_margin
+    eng.set_spec_recheck_margin(1e30)                                            # everything through the fp32 re-run
+    cz, lz, _ = eng.spec_smooth_votes(*args, 100, batch=32, seed=11, want_logits=True)
+    eng.set_spec_recheck_margin(old)
+    assert torch.equal(lz, l32[:100]) and int(cz.sum()) == 100
+    eng.close()
+
+
 def test_exact_vote_queue_drains_mid_call(weights, sched, monkeypatch):
     """The recheck queue holds a bounded number of sample indices; a call that votes more samples than fit drains it between
     batches.  With an 8-entry queue (DMAD_RECHECK_QUEUE, a test knob) and every sample forced through the recheck tiers the
@@ -1182,18 +1240,21 @@ def test_recheck_bounds_are_calibrated_for_the_resident_weights(exact_engine, sc
     stats = eng.recheck_stats(detail=True)
     t1, t2, e1, e2 = eng.calibrate_recheck(clips, 0.5, sc, 65, *coef(65), n=256, n_fp32=64)
     assert 0.004 < e1 < d1 and 1e-5 < e2 < d2, (e1, e2)                  # the defaults' regime: 0.0244 / 2.5e-4 at N = 36 864
-    assert t1 == d1 and t2 == d2 and eng.recheck_margin == pytest.approx(d1)          # observed errors below the floor: defaults kept
-    assert eng.calibration['clips'] == 2 and eng.calibration['e1'] == e1 and eng.calibration['n_fp32'] == 64
+    cal = eng.calibration
+    assert cal['clips'] == 2 and cal['e1'] == e1 and cal['n_fp32'] == 64 and 0.002 < cal['s1'] < 0.01
+    # the bounds never go below the committed defaults: max(default, headroom x observed maximum, tail rule on the observed scale)
+    assert t2 == d2 and t1 == pytest.approx(max(d1, 1.5 * e1 + t2, E.TAIL_Z * cal['s1'] + t2)) and d1 <= t1 < 1.25 * d1
+    assert eng.recheck_margin == pytest.approx(t1)
     assert eng.mode == E.MODE_EXACT_VOTES and eng.recheck_stats(detail=True) == stats  # nothing voted, nothing was reset
     w1, w2, _, _ = eng.calibrate_recheck(clips[0], 0.5, sc, 65, *coef(65), n=128, n_fp32=32, headroom=50.0)
-    assert w2 == pytest.approx(max(d2, 50 * eng.calibration['e2'])) and w1 == pytest.approx(max(d1, 50 * eng.calibration['e1'] + w2)) and w1 > d1
+    assert w2 == pytest.approx(max(d2, 50 * eng.calibration['e2'])) and w1 == pytest.approx(50 * eng.calibration['e1'] + w2) and w1 > 5 * d1
     eng.set_recheck_margin(old[0]); eng.set_recheck_margin2(old[1])
     den = DiffWave(WaveNetHIP(eng), hp)
     lines = []
     rc = RobustCertificate(classifier=synth_vgg().bind_engine(eng), transform=MelSpectrogramDB(eng), denoiser=den, seed=2, calibrate=64,
                            calibrate_clips=2, log=lines.append)
     a = rc.smooth_predict(clips[0], num_sampling=32, sigma=0.5, batch_size=16)
-    assert int(a.sum()) == 32 and list(rc._calibrated) == [65] and eng.recheck_margin == pytest.approx(rc._calibrated[65][0]) >= d1
+    assert int(a.sum()) == 32 and list(rc._calibrated) == [65] and eng.recheck_margin == pytest.approx(rc._calibrated[65][0]) and rc._calibrated[65][0] >= d1
     rc.smooth_predict(clips[1], num_sampling=8, sigma=0.5, batch_size=8)
     rc.smooth_predict(clips[1], num_sampling=8, sigma=0.5, batch_size=8)
     assert rc._calibrated_clips == {65: 2} and len(lines) == 2 and 'tau1' in lines[0]     # two clips measured, then no more
@@ -1293,7 +1354,7 @@ def test_f16_engine_warns_about_weights_outside_the_half_range():
     sd = synth.wavenet_state_dict(1234)
     tiny = {k: (v * 1e-4 if 'res_conv.weight_g' in k else v) for k, v in sd.items()}     # weight-norm gain: scales the folded res weights
     eng = E.Engine(max_batch=1, precision=E.BF16, half_type=E.HALF_F16, with_classifier=False)
-    with pytest.warns(RuntimeWarning, match='f16 subnormals'):
+    with pytest.warns(RuntimeWarning, match='in 36 of 109 folded weight tensors f16 subnormals'):
         eng.load_wavenet(tiny)
     eng.close()
     eng = E.Engine(max_batch=1, precision=E.BF16, half_type=E.HALF_F16, with_classifier=False)

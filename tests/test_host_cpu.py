@@ -51,7 +51,7 @@ def test_c_abi_fails_loudly_without_gpu(built_lib):
     assert lib.dmad_create(ctypes.byref(bad), ctypes.byref(h)) == -1
     assert b'256' in lib.dmad_last_error()
     # a caller built against another revision of dmad.h (struct_size mismatch) is refused before any field is trusted
-    assert cfg.struct_size == ctypes.sizeof(_lib.DmadConfig) == 15 * 4
+    assert cfg.struct_size == ctypes.sizeof(_lib.DmadConfig) == 16 * 4 and cfg.with_wavenet == 1
     old = _lib.DmadConfig(256, 256, 36, 12, 128, 512, 512, 16000, 1, 10, 0, 1, 0, 0)
     old.struct_size = 12 * 4                               # the round-1 layout: no struct_size, recheck_batch, half_type
     assert lib.dmad_create(ctypes.byref(old), ctypes.byref(h)) == -1 and b'struct_size' in lib.dmad_last_error()
