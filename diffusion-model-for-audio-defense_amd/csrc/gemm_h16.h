@@ -5,7 +5,7 @@
 namespace dmad {
 
 struct GemmH16Args {
-    const h16_t* A;       // f16 weights [taps][M][K], K contiguous, K % 32 == 0, M % 128 == 0
+    const h16_t* A;       // f16 weights [taps][M][K], K contiguous, K % 64 == 0, M % 128 == 0
     const h16_t* X;       // f16 NHWC activations [B][H][W][ldx]
     float* C;             // fp32 output [N][ldc] or nullptr
     h16_t* C16;           // f16 twin of the output [N][ldc] or nullptr (for consumers that are GEMMs)
@@ -17,7 +17,7 @@ struct GemmH16Args {
     int ldx;              // halves between two pixels of X
     int stride;           // 0/1 = 1, 2 = output (H-1)/2+1 x (W-1)/2+1
     const h16_t* X2;      // optional: channels [ksplit, K) of every pixel come from X2 (pixel pitch ldx2) — th.cat([h, skip], dim=1)
-    int ksplit, ldx2;     //   of the UNet (unet.py:473) read in place; ksplit % 32 == 0
+    int ksplit, ldx2;     //   of the UNet (unet.py:473) read in place; ksplit % 64 == 0
 };
 
 // 0, or -1 for an argument block the kernel does not serve (nothing is launched; counted for gemm_h16_take_bad_shapes)

@@ -4,23 +4,23 @@
 //
 //   C[n][m] = sum_tap sum_k A[tap][m][k] * X[pixel(n, tap)][k] + shift[m] (+ res[n][m])
 //
-// Same operand scheme as the fp32 gather-GEMM (gemm_f32.hip): both operands are row gathers of 64-byte k-chunks (here 32 halves)
-// staged by LDS-DMA, every lane fetching the 16 bytes that belong at its own LDS position (64-byte rows, chunks XOR-swizzled by
-// swz64(row)), so that an MFMA fragment — 8 consecutive k of one row — is ONE conflict-free ds_read_b128.  Rows outside the
-// problem (zero padding, N tail) come from a zero page.  One f16 MFMA per staged fragment pair is 16x less matrix time per staged
-// byte than the fp32 kernel's, so the tile is large and the pipeline deep (the split-f16 kernel's geometry): 384 staged rows per
-// k-step split as BM x BN = 256 x 128 or 128 x 256 (layers with 128 output channels per block row), 8 waves of 64 x 64, k-steps
-// of 64 halves (two 64-byte sub-stages), 3-slot LDS ring of 48 KiB (144 KiB, one workgroup per CU, two waves per SIMD), two
-// k-steps in flight while one is contracted, one barrier per k-step.
+// Operand scheme: both operands are row gathers staged by LDS-DMA, every lane fetching the 16 bytes that belong at its own LDS
+// position.  A k-step is 64 halves = ONE 128-byte row per operand row: eight consecutive lanes fetch one whole cache line (the
+// fp32 gather-GEMM's 64-byte rows would ask L2 for every line twice at this kernel's 16x smaller matrix time per staged byte).
+// LDS image: 128-byte rows, the eight 16-byte chunks XOR-swizzled by (row >> 1) & 7, so that the 16 rows x one chunk of an MFMA
+// fragment read (ds_read_b128) cover all 64 banks exactly once.  Rows outside the problem (zero padding, N tail) come from a
+// zero page.  One f16 MFMA per staged fragment pair is 16x less matrix time per staged byte than the fp32 kernel's, so the tile is
+// large and the pipeline deep: 384 staged rows per k-step split as BM x BN = 256 x 128 or 128 x 256 (layers whose output
+// channels are a multiple of 128 only), 8 waves of 64 x 64, 3-slot LDS ring of 48 KiB (144 KiB, one workgroup per CU, two waves
+// per SIMD), two k-steps in flight while one is contracted, one barrier per k-step.
 #include "gemm_h16.h"
 
 namespace dmad {
 
 namespace {
-constexpr int HK = 32;                          // halves per 64-byte sub-stage row
-constexpr int SUB = 384 * 64;                   // bytes per sub-stage (384 rows of 64 B)
-constexpr int KSTEP = 2 * SUB, H16_LDS = 3 * KSTEP;
-__device__ __attribute__((aligned(64))) unsigned short g_zero_page_h[32];      // 64 B of zeros
+constexpr int HK = 64;                          // halves per k-step row (128 bytes)
+constexpr int KSTEP = 384 * 128, H16_LDS = 3 * KSTEP;
+__device__ __attribute__((aligned(128))) unsigned short g_zero_page_h[64];     // 128 B of zeros
 
 #define GH_WAIT_BARRIER(N)                                                          \
     do {                                                                            \
@@ -36,21 +36,21 @@ thread_local int g_bad = 0;
 template <int BM, bool TWO>
 __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
     constexpr int BN = 384 - BM, WN = BN / 64;          // waves along N (2 or 4); along M: BM / 64
-    constexpr int APIECES = BM / 128;                   // 128-row staging pieces that hold A rows (the rest hold X rows)
+    constexpr int AP = BM / 64, XP = 6 - AP;            // 64-row staging pieces (8 KiB each) holding A rows / X rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv / WN, wn = wv % WN, q = lane >> 4, r16 = lane & 15;
     const long n0 = (long)blockIdx.x * BN;
     const int m0 = blockIdx.y * BM;
-    const int subs_per_tap = a.K / HK, nsteps = (a.taps * subs_per_tap) >> 1;
-    // staging rows of this thread: piece p (p = 0..2) row p*128 + rloc; chunk slot = (lane & 3) ^ swz64(row)
-    const int rloc = wv * 16 + (lane >> 2), ch8 = ((lane & 3) ^ swz64(lane >> 2)) * 8;
+    const int steps_per_tap = a.K / HK, nsteps = a.taps * steps_per_tap;
+    // staging: piece p row p*64 + rloc (rloc = wave*8 + lane/8); LDS slot lane & 7 holds chunk (lane & 7) ^ ((row >> 1) & 7),
+    // and (row >> 1) & 7 = (rloc >> 1) & 7 for every piece (64 | piece base)
+    const int rloc = wv * 8 + (lane >> 3), ch8 = ((lane & 7) ^ ((rloc >> 1) & 7)) * 8;
     const h16_t* zero = g_zero_page_h;
-    const h16_t* arow[APIECES];
+    const h16_t* arow[AP];
 #pragma unroll
-    for (int p = 0; p < APIECES; ++p) arow[p] = a.A + (size_t)(m0 + p * 128 + rloc) * a.K + ch8;      // M % BM == 0 (launcher)
-    constexpr int XP = 3 - APIECES;
+    for (int p = 0; p < AP; ++p) arow[p] = a.A + (size_t)(m0 + p * 64 + rloc) * a.K + ch8;      // M % BM == 0 (launcher)
     long xpix[XP];
     int xy[XP], xx[XP];
     bool xok[XP];
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
     const int Wo = (a.W - 1) / st + 1, Ho = (a.H - 1) / st + 1, hw = Ho * Wo;
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
-        const long n = n0 + p * 128 + rloc;
+        const long n = n0 + p * 64 + rloc;
         xok[p] = n < a.N;
         xpix[p] = 0; xy[p] = 0; xx[p] = 0;
         if (xok[p]) {
@@ -68,22 +68,21 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
             xpix[p] = b * a.H * a.W;
         }
     }
-    auto stage = [&](int sub, char* base) {              // base: this sub-stage's 24 KiB (rows 0..383 of 64 B)
-        const int tap = sub / subs_per_tap, kc = (sub - tap * subs_per_tap) * HK;
+    auto stage = [&](int ks, char* base) {               // base: this k-step's 48 KiB (rows 0..383 of 128 B)
+        const int tap = ks / steps_per_tap, kc = (ks - tap * steps_per_tap) * HK;
         char* la = base + wv * 1024;
 #pragma unroll
-        for (int p = 0; p < APIECES; ++p) glds16(arow[p] + (size_t)tap * a.M * a.K + kc, la + p * 8192);
+        for (int p = 0; p < AP; ++p) glds16(arow[p] + (size_t)tap * a.M * a.K + kc, la + p * 8192);
+        const int dy = a.taps == 9 ? tap / 3 - 1 : 0, dx = a.taps == 9 ? tap % 3 - 1 : 0;
 #pragma unroll
         for (int p = 0; p < XP; ++p) {
-            const h16_t* src = zero;
-            if (xok[p]) {
-                const int yy = xy[p] + (a.taps == 9 ? tap / 3 - 1 : 0), xq = xx[p] + (a.taps == 9 ? tap % 3 - 1 : 0);
-                if ((unsigned)yy < (unsigned)a.H && (unsigned)xq < (unsigned)a.W) {
-                    const long pix = xpix[p] + (long)yy * a.W + xq;
-                    src = (TWO && kc >= a.ksplit) ? a.X2 + pix * a.ldx2 + (kc - a.ksplit) + ch8 : a.X + pix * a.ldx + kc + ch8;
-                }
+            const h16_t* src = zero + (lane & 7) * 8;
+            const int yy = xy[p] + dy, xq = xx[p] + dx;
+            if (xok[p] && (unsigned)yy < (unsigned)a.H && (unsigned)xq < (unsigned)a.W) {
+                const long pix = xpix[p] + (long)yy * a.W + xq;
+                src = (TWO && kc >= a.ksplit) ? a.X2 + pix * a.ldx2 + (kc - a.ksplit) + ch8 : a.X + pix * a.ldx + kc + ch8;
             }
-            glds16(src, la + (APIECES + p) * 8192);
+            glds16(src, la + (AP + p) * 8192);
         }
     };
     f32x4 acc[4][4];
@@ -91,26 +90,26 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frag = r16 * 64 + ((q ^ swz64(r16)) * 16);
-    stage(0, smem); stage(1, smem + SUB);
-    if (nsteps > 1) { stage(2, smem + KSTEP); stage(3, smem + KSTEP + SUB); }
+    // fragment of k-half h (k = 32 h .. 32 h + 31): chunk 4 h + q of row r16 of a 16-row tile, at slot chunk ^ ((r16 >> 1) & 7)
+    const int sw = (r16 >> 1) & 7;
+    const int frag0 = r16 * 128 + ((q ^ sw) * 16), frag1 = r16 * 128 + (((4 + q) ^ sw) * 16);
+    stage(0, smem);
+    if (nsteps > 1) stage(1, smem + KSTEP);
     int slot = 0;
     for (int p = 0; p < nsteps; ++p) {
         // k-step p landed (the 6 pieces of k-step p+1 may still fly); every wave is done reading k-step p-1
         if (p + 1 < nsteps) { GH_WAIT_BARRIER(6); } else { GH_WAIT_BARRIER(0); }
-        if (p + 2 < nsteps) {
-            char* nb = smem + (slot == 0 ? 2 : slot - 1) * KSTEP;        // the slot k-step p-1 occupied
-            stage(2 * p + 4, nb); stage(2 * p + 5, nb + SUB);
-        }
-        const char* A0 = smem + slot * KSTEP + wm * 4096 + frag;
-        const char* B0 = smem + slot * KSTEP + BM * 64 + wn * 4096 + frag;
+        if (p + 2 < nsteps) stage(p + 2, smem + (slot == 0 ? 2 : slot - 1) * KSTEP);        // into the slot k-step p-1 occupied
+        const char* A0 = smem + slot * KSTEP + wm * 8192;
+        const char* B0 = smem + slot * KSTEP + BM * 128 + wn * 8192;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            const int fo = h ? frag1 : frag0;
             f16x8 af[4], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(A0 + h * SUB + i * 1024);
+            for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(A0 + i * 2048 + fo);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = *(const f16x8*)(B0 + h * SUB + j * 1024);
+            for (int j = 0; j < 4; ++j) bf[j] = *(const f16x8*)(B0 + j * 2048 + fo);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -154,9 +153,8 @@ int gemm_h16_configure() {
 int gemm_h16_take_bad_shapes() { const int n = g_bad; g_bad = 0; return n; }
 
 int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
-    const int subs = a.taps * (a.K / HK);
     const bool two = a.X2 != nullptr;
-    if ((a.taps != 9 && a.taps != 1) || (a.K % HK) || (subs & 1) || (a.M % 128) || (a.ldc & 3) || a.N < 1 || (!a.C && !a.C16) ||
+    if ((a.taps != 9 && a.taps != 1) || (a.K % HK) || a.K < HK || (a.M % 128) || (a.ldc & 3) || a.N < 1 || (!a.C && !a.C16) ||
         (a.ldx & 7) || (two && ((a.ksplit % HK) || a.ksplit <= 0 || a.ksplit >= a.K || (a.ldx2 & 7)))) {
         ++g_bad;
         return -1;

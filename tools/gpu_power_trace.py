@@ -9,6 +9,9 @@ clock the chip holds INSIDE the kernel, sampled while wn_layer_p runs back to ba
      and on ZERO data (same binary, same cycles: MI355X_MICROARCH.md, DVFS give-back item 1) and reports ms per launch;
   3. the diagnostic (stamped) build of the same kernel then reports the in-kernel clock = shader cycles / 100 MHz ticks
      (give-back item 6) after the chip has been under that load for SECONDS.
+  4. MIX=1: the energy of a tile split by operand — the same launches with ONLY the weights of the timed layer zeroed (random
+     activations: what the activation path + gate + stores cost) and with everything BUT that layer's weights zeroed (zero
+     activations, random weights: what the weight fill + A-fragment path costs); energy per launch = board power x time.
 Writes gpurun_out/power_trace.json.       B=256 SECONDS=6 HALF=f16 python tools/gpu_power_trace.py
 """
 import glob
@@ -149,14 +152,26 @@ eng.load_wavenet(sd)
 eng0 = E.Engine(max_batch=B, precision=E.BF16, half_type=ht, with_classifier=False)
 eng0.load_wavenet({k: (v if k.endswith('weight_v') else v * 0) for k, v in sd.items()})
 x = torch.randn(B, 16000, device='cuda') * 0.3
-for name, xin in (('idle', None), ('random', x), ('zeros', torch.zeros_like(x))):
+engs = {'random': eng, 'zeros': eng0}
+phases = [('idle', None), ('random', x), ('zeros', torch.zeros_like(x))]
+if os.environ.get('MIX', '0') == '1':
+    LAYER = 'residual_layer.residual_blocks.5.'
+    is_l5w = lambda k: k.startswith(LAYER) and ('dilated_conv_layer' in k or 'res_conv' in k) and k.endswith('weight_g')      # noqa: E731
+    # layer 5's folded dilated / res weights zero, everything else as trained: random activations into zero weights
+    engs['zero_weights'] = E.Engine(max_batch=B, precision=E.BF16, half_type=ht, with_classifier=False)
+    engs['zero_weights'].load_wavenet({k: (v * 0 if is_l5w(k) else v) for k, v in sd.items()})
+    # only layer 5's weights (and its biases) kept: the stream the timed layer reads is exactly zero, its weights random
+    engs['zero_activations'] = E.Engine(max_batch=B, precision=E.BF16, half_type=ht, with_classifier=False)
+    engs['zero_activations'].load_wavenet({k: (v if (k.endswith('weight_v') or (k.startswith(LAYER) and 'fc_t' not in k)) else v * 0) for k, v in sd.items()})
+    phases += [('zero_weights', x), ('zero_activations', torch.zeros_like(x))]
+for name, xin in phases:
     smp = Sampler(src)
     if xin is None:
         smp.start(); time.sleep(2.0); smp.stop = True; smp.join()
         report[name] = {'power_w': summarise(smp.rows, 'power_w'), 'sclk_mhz_hwmon': summarise(smp.rows, 'sclk_mhz_hwmon'),
                         'sclk_mhz_dpm': summarise(smp.rows, 'sclk_mhz_dpm')}
         continue
-    en = eng0 if name == 'zeros' else eng
+    en = engs[name]
     eps = en.wavenet_eps(xin, 65)                 # fills the residual stream the timed layer reads
     torch.cuda.synchronize()
     if name == 'zeros':
@@ -172,6 +187,10 @@ for name, xin in (('idle', None), ('random', x), ('zeros', torch.zeros_like(x)))
     report[name] = {'ms_per_launch': ms, 'launches': iters, 'wall_s': wall, 'tflops': 2.0 * 16000 * (512 * 768 + 256 * 256) * B / (ms * 1e-3) / 1e12,
                     'power_w': summarise(steady, 'power_w'), 'sclk_mhz_hwmon': summarise(steady, 'sclk_mhz_hwmon'),
                     'sclk_mhz_dpm': summarise(steady, 'sclk_mhz_dpm'), 'trace': smp.rows[::4]}
+    pw = report[name]['power_w']
+    if pw:
+        report[name]['joules_per_launch'] = pw['median'] * ms * 1e-3
+        report[name]['joules_per_launch_above_idle'] = (pw['median'] - (report['idle']['power_w'] or {}).get('median', 0.0)) * ms * 1e-3
     print(name, json.dumps({k: v for k, v in report[name].items() if k != 'trace'}), flush=True)
 
 # in-kernel clock of the stamped build right after the load phase (stderr line "[dmad stamps] ... in-kernel clock")
@@ -185,6 +204,6 @@ eng0.time_layer(5, B, max(20, int(2.0 * 1e3 / report['zeros']['ms_per_launch']))
 report['stamped_build_ms_per_launch_zeros'] = eng0.time_layer(5, B, 10)      # second "[dmad stamps]" line: the clock on zero operands
 with open(os.path.join(OUT, 'power_trace.json'), 'w') as fh:
     json.dump(report, fh, indent=1)
-print(json.dumps({k: v for k, v in report.items() if k not in ('random', 'zeros')}), flush=True)
-eng.close()
-eng0.close()
+print(json.dumps({k: v for k, v in report.items() if k not in engs}), flush=True)
+for en in engs.values():
+    en.close()
