@@ -31,6 +31,13 @@ class ResNeXtBottleneck(nn.Module):
                                                                 padding=0, bias=False))
             self.shortcut.add_module('shortcut_bn', nn.BatchNorm2d(out_channels))
 
+    def forward(self, x):
+        """reference l.47-62 — used on the gradient branch of CifarResNeXt.forward only (inference runs in the HIP engine)."""
+        b = torch.relu(self.bn_reduce(self.conv_reduce(x)))
+        b = torch.relu(self.bn(self.conv_conv(b)))
+        b = self.bn_expand(self.conv_expand(b))
+        return torch.relu(self.shortcut(x) + b)
+
 
 class CifarResNeXt(nn.Module):
 
@@ -87,7 +94,13 @@ class CifarResNeXt(nn.Module):
         if self.training:
             raise NotImplementedError('the HIP ResNeXt29 is inference-only: call .eval() first')
         if torch.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError('the HIP ResNeXt29 is inference-only (no autograd)')
+            # callers that differentiate through the system: the module's own layers, reference l.133-142; CUDA only
+            if not x.is_cuda:
+                raise NotImplementedError('the ResNeXt29 mirror has no CPU path (gradient branch included)')
+            h = torch.relu(self.bn_1(self.conv_1_3x3(x)))
+            h = self.stage_3(self.stage_2(self.stage_1(h)))
+            h = torch.nn.functional.avg_pool2d(h, 8, 1).view(-1, self.stages[3])
+            return self.classifier(h)
         if 'engine' not in self.__dict__:
             self.bind_engine()
         return self.__dict__['engine'].classify(x)

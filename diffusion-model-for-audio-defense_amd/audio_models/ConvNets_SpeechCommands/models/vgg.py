@@ -55,7 +55,11 @@ class VGG(nn.Module):
         if self.training:
             raise NotImplementedError('the HIP VGG19_bn is inference-only: call .eval() first')
         if torch.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError('the HIP VGG19_bn is inference-only (no autograd)')
+            # callers that differentiate through the system: the module's own layers are the torch restatement of
+            # reference models/vgg.py:48-52 (eval mode: BatchNorm on its running statistics, Dropout inactive); CUDA tensors only
+            if not x.is_cuda:
+                raise NotImplementedError('the VGG19_bn mirror has no CPU path (gradient branch included)')
+            return self.classifier(self.features(x).view(x.size(0), -1))
         if 'engine' not in self.__dict__:
             self.bind_engine()
         return self.__dict__['engine'].classify(x)

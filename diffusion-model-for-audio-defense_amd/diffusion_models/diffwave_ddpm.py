@@ -9,8 +9,11 @@ engine (libdmad_hip.so).  Same names, argument meaning and error behaviour as th
   ReffWave(model, diffusion_hyperparams, reverse_timestep, num_re).forward / diffusion /
   one_shot_denoise                                                                       (ref l.251-349)
 
-Inference only: the eps-network runs in hand-written HIP kernels without autograd.  There is no CPU
-path; inputs must be CUDA tensors (the reference itself hard-codes .cuda()).
+The eps-network runs in hand-written HIP kernels without autograd.  There is no CPU path; inputs must be
+CUDA tensors (the reference itself hard-codes .cuda()).  Callers that DIFFERENTIATE through the
+purifier (the white-box attack drivers: `x.requires_grad` with gradients enabled) get the torch
+restatement of dmad_hip/autograd.py on that branch — `DiffWave.forward`, `one_shot_denoise`, `compute_eps_t`
+and `model((x, t))`; every other call is the HIP engine's.
 
 Noise: the reference draws every Gaussian on the CPU default generator and copies it over
 (ref l.66,100).  `noise_source='torch_cpu'` reproduces exactly that stream (parity);
@@ -21,6 +24,7 @@ from typing import Union
 import numpy as np
 import torch
 
+from dmad_hip import autograd as _ag
 from dmad_hip import engine as _eng
 from .DiffWave_Unconditional.util import calc_diffusion_hyperparams
 
@@ -30,18 +34,26 @@ class WaveNetHIP(torch.nn.Module):
     callable on the tuple (audio [B,1,L], diffusion_steps [B,1]); all rows must carry the same step,
     which is what every inference caller of the reference passes (t * ones)."""
 
-    def __init__(self, engine: "_eng.Engine"):
+    def __init__(self, engine: "_eng.Engine", state_dict=None):
         super().__init__()
         self.engine = engine
+        # the differentiation branch (dmad_hip/autograd.py) evaluates the same folded weights with torch ops
+        self._folded = None
+        if state_dict is not None:
+            cyc = dict(engine.wavenet_geometry)['dilation_cycle']
+            self._folded = _ag.FoldedWaveNet(_eng.fold_wavenet_state_dict(state_dict, engine.num_res_layers), engine.num_res_layers, cyc)
 
     def forward(self, input_data):
         audio, diffusion_steps = input_data
-        if torch.is_grad_enabled() and audio.requires_grad:
-            raise NotImplementedError('the HIP eps-network is inference-only (no autograd)')
         steps = torch.as_tensor(diffusion_steps).detach().reshape(-1).float().cpu()
         t = float(steps[0])
         if not bool((steps == t).all()) or t != int(t):
             raise NotImplementedError('per-row / fractional diffusion steps are not supported by the HIP engine')
+        if _ag.needs_grad(audio):
+            if self._folded is None:
+                raise NotImplementedError('the HIP eps-network has no autograd; build the model with create_diffwave_model(...) or '
+                                          'WaveNetHIP(engine, state_dict=...) to get the torch restatement on the gradient branch')
+            return _ag.wavenet_eps(self._folded, audio, int(t))
         return self.engine.wavenet_eps(audio, int(t)).unsqueeze(1)
 
 
@@ -93,8 +105,32 @@ class DiffWave(torch.nn.Module):
                 [float(torch.sqrt(Alpha[t])) for t in range(ts)], [float(Sigma[t]) for t in range(ts)])
 
     # -- reference API ---------------------------------------------------------------------------
+    def _forward_autograd(self, x_0):
+        """DiffWave.forward = _diffusion + _reverse (ref l.36-104,143-164) as differentiable torch ops: the branch the white-box
+        attack drivers take.  Noise: the reference's CPU stream (noise_source='torch_cpu') or the engine's Philox draws keyed as
+        in the inference path (row i of this call = sample _draws + i; stream 0xD1FF for the diffusion draw, 1 + t per step)."""
+        _, Alpha, Alpha_bar, Sigma = self._tables()
+        assert x_0.ndim == 3
+        B, dev, base = x_0.shape[0], x_0.device, self._draws
+
+        def draw(stream):
+            z = self._noise(x_0.shape, dev)
+            return z if z is not None else self.engine.philox_normal(self.seed, base, stream, B).unsqueeze(1)
+        ts = self.reverse_timestep
+        x = torch.sqrt(Alpha_bar[ts - 1]).to(dev) * x_0 + torch.sqrt(1 - Alpha_bar[ts - 1]).to(dev) * draw(0xD1FF)
+        for t in range(ts - 1, -1, -1):
+            eps = self.model((x, t * torch.ones((B, 1))))
+            c = ((1 - Alpha[t]) / torch.sqrt(1 - Alpha_bar[t])).to(dev)
+            x = (x - c * eps) / torch.sqrt(Alpha[t]).to(dev)
+            if t > 0:
+                x = x + Sigma[t].to(dev) * draw(1 + t)
+        self._draws += B
+        return x
+
     def forward(self, waveforms: Union[torch.Tensor, np.ndarray]):
         waveforms = self._to_tensor(waveforms)
+        if _ag.needs_grad(waveforms):
+            return self._forward_autograd(waveforms)
         if self.noise_source == 'device':     # the whole chain in one library call (dmad_ddpm_purify)
             assert waveforms.ndim == 3
             ts, c_a, c_b, c_eps, c_div, c_sig = self.purify_coefficients()
@@ -146,19 +182,23 @@ class DiffWave(torch.nn.Module):
         mu_theta = (x_t - c * epsilon_theta) / torch.sqrt(Alpha[t]).to(x_t.device)
         return epsilon_theta, mu_theta, Sigma[t]
 
-    @torch.no_grad()
     def compute_eps_t(self, x_t, t):
         x_t = self._to_tensor(x_t)
-        return self.model((x_t, t * torch.ones((x_t.shape[0], 1))))
+        if _ag.needs_grad(x_t):
+            return self.model((x_t, t * torch.ones((x_t.shape[0], 1))))
+        with torch.no_grad():
+            return self.model((x_t, t * torch.ones((x_t.shape[0], 1))))
 
-    @torch.no_grad()
     def one_shot_denoise(self, x_t):
         x_t = self._to_tensor(x_t)
         t = self.reverse_timestep - 1
         Alpha_bar = self.diffusion_hyperparams["Alpha_bar"]
         c_a = float((1 / Alpha_bar).sqrt()[t])
         c_b = float((1 / Alpha_bar - 1).sqrt()[t])
-        return self.engine.one_shot(x_t, t, c_a, c_b).unsqueeze(1)
+        if _ag.needs_grad(x_t):               # ref l.174-182,195-205 through the differentiable eps-network
+            return c_a * x_t - c_b * self.model((x_t, t * torch.ones((x_t.shape[0], 1))))
+        with torch.no_grad():
+            return self.engine.one_shot(x_t, t, c_a, c_b).unsqueeze(1)
 
     @torch.no_grad()
     def two_shot_denoise(self, x_t):
@@ -303,5 +343,5 @@ def create_diffwave_model(model_path, config_path, reverse_timestep=25, state_di
     if engine is None and eng.has_wavenet and eng.wavenet_owner != _eng.state_fingerprint(state_dict):
         eng = _eng.get_engine(wavenet_config, precision=precision, max_batch=max_batch, fresh=True)   # a second, different DiffWave
     eng.bind('wavenet', state_dict, eng.load_wavenet)
-    return DiffWave(model=WaveNetHIP(eng), diffusion_hyperparams=diffusion_hyperparams,
+    return DiffWave(model=WaveNetHIP(eng, state_dict=state_dict), diffusion_hyperparams=diffusion_hyperparams,
                     reverse_timestep=reverse_timestep, noise_source=noise_source)

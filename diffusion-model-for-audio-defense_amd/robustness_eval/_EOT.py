@@ -5,10 +5,12 @@ Contract kept: EOT(model, loss, EOT_size, EOT_batch_size, use_grad)(x [n,1,L], y
 (EOT_size // EOT_batch_size) * EOT_batch_size times under the model's own randomness and returns
     scores    [n, C]  the per-model-call means (EOT_batch_size repeats each), averaged over the calls,
     loss      [n]     the same average of the per-example loss,
-    grad      None    (no autograd through the HIP purifier: use_grad=True raises),
+    grad      None with use_grad=False; with use_grad=True the gradient of the loss w.r.t. x, averaged like the scores
+              (the model is then called once per EOT batch on a leaf that requires grad, which sends the HIP-backed stages
+              down their differentiation branch, dmad_hip/autograd.py),
     decisions n lists of the arg-max of every single evaluation, in evaluation order.
-Built differently: all repeats are ONE batched query (AcousticSystem.query -> dmad_query_logits) instead of one model
-call per EOT batch; only the reduction order of the reference is reproduced on the returned [repeats, n, C] block."""
+Built differently: without gradients all repeats are ONE batched query (AcousticSystem.query -> dmad_query_logits) instead
+of one model call per EOT batch; only the reduction order of the reference is reproduced on the returned [repeats, n, C] block."""
 import torch
 import torch.nn as nn
 
@@ -30,14 +32,33 @@ class EOT(nn.Module):
         blocks = [self.model(x.repeat(per_call, 1, 1)).view(per_call, x.shape[0], -1) for _ in range(calls)]
         return torch.cat(blocks, 0)
 
+    def _forward_with_grad(self, x_batch, y_batch, per_call, calls):
+        """reference l.36-66 with use_grad: one model call per EOT batch on a leaf that requires grad."""
+        n, ch, L = x_batch.shape
+        scores = loss = grad = None
+        decisions = [[] for _ in range(n)]
+        with torch.enable_grad():
+            for _ in range(calls):
+                x_rep = x_batch.detach().repeat(per_call, 1, 1).requires_grad_(True)
+                out = self.model(x_rep)
+                l_rep = self.loss(out, y_batch.repeat(per_call))
+                l_rep.backward(torch.ones_like(l_rep))
+                s_c = out.detach().view(per_call, n, -1).mean(0)
+                l_c = l_rep.detach().view(per_call, n).mean(0)
+                g_c = x_rep.grad.view(per_call, n, ch, L).mean(0)
+                scores, loss, grad = (s_c, l_c, g_c) if scores is None else (scores + s_c, loss + l_c, grad + g_c)
+                picks = out.detach().argmax(1).view(per_call, n).cpu().numpy()
+                for i in range(n):
+                    decisions[i] += list(picks[:, i])
+        return scores / calls, loss / calls, grad / calls, decisions
+
     def forward(self, x_batch, y_batch, EOT_size=None, EOT_batch_size=None, use_grad=None):
         size = EOT_size or self.EOT_size
         per_call = EOT_batch_size or self.EOT_batch_size
         calls = size // per_call
-        if use_grad or self.use_grad:
-            raise NotImplementedError('EOT gradients need autograd through the purifier; the HIP engine is inference-only '
-                                      '(construct the wrapper with use_grad=False, as the black-box drivers do)')
         n = x_batch.shape[0]
+        if use_grad or self.use_grad:
+            return self._forward_with_grad(x_batch, y_batch, per_call, calls)
         logits = self._all_repeats(x_batch, per_call, calls)                     # [R, n, C]
         R, C = logits.shape[0], logits.shape[-1]
         per_eval_loss = self.loss(logits.reshape(R * n, C), y_batch.repeat(R)).view(calls, per_call, n)

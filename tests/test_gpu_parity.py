@@ -534,7 +534,7 @@ def test_eot_nes_query_path(engines, orc):
     want = sum(p.view(2, 2, 10).mean(0) for p in parts) / 2
     assert torch.allclose(s4, want, rtol=0, atol=1e-6) and [len(d) for d in d4] == [4, 4]
     with pytest.raises(NotImplementedError):
-        EOT(model, loss_fn, 2, 2, use_grad=True)(x, y)
+        EOT(model, loss_fn, 2, 2, use_grad=True)(x, y)          # this WaveNetHIP was built without weights for the gradient branch
 
     # NES: shapes, finiteness, the unperturbed probe first (ref l.20-21,41-47)
     nes = NES(samples_per_draw=4, samples_per_draw_batch=4, sigma=1e-3, EOT_wrapper=EOT(model, loss_fn, 1, 1, False))
@@ -1362,3 +1362,69 @@ def test_f16_engine_warns_about_weights_outside_the_half_range():
         warnings.simplefilter('error')
         eng.load_wavenet(sd)
     eng.close()
+
+
+def test_autograd_branch(engines, weights, sched):
+    """callers that differentiate through the system (x.requires_grad with gradients enabled: the white-box attack
+    drivers) get a torch restatement on that branch (dmad_hip/autograd.py) instead of the inference-only HIP engine.  Checked WITH
+    the HIP fp32 path: the branch's forward values equal the engine's stage by stage and end to end, and its gradient equals the
+    directional finite difference of the ENGINE's output along the gradient direction.  Calls without requires_grad stay on the
+    engine; CPU tensors are refused on both branches."""
+    from acoustic_system import AcousticSystem
+    from diffusion_models.diffwave_ddpm import DiffWave, WaveNetHIP
+    from dmad_hip._lib import DmadError
+    from dmad_hip.transforms import MelSpectrogramDB
+    from robustness_eval._EOT import EOT
+    from robustness_eval._utils import resolve_loss
+    eng = engines['fp32']
+    hp, coef = sched
+    den = DiffWave(WaveNetHIP(eng, state_dict=weights[0]), hp, reverse_timestep=2, noise_source='device', seed=3)
+    net = synth_vgg().cuda().bind_engine(eng)
+    mel = MelSpectrogramDB(eng)
+    model = AcousticSystem(classifier=net, transform=mel, defender=den, defense_type='wave')
+    x = torch.from_numpy(np.stack([synth.synthetic_clip(0), synth.synthetic_clip(5)])).cuda().unsqueeze(1)
+
+    # stage by stage: torch restatement (requires_grad) against the engine (no grad), same inputs
+    xg = x.clone().requires_grad_(True)
+    eps_t = den.model((xg, 40 * torch.ones(2, 1)))
+    eps_h = den.model((x, 40 * torch.ones(2, 1)))
+    assert eps_t.requires_grad and not eps_h.requires_grad and relmax(eps_t.detach().cpu().numpy(), eps_h.cpu().numpy()) < 1e-4
+    one_t, one_h = den.one_shot_denoise(xg), den.one_shot_denoise(x)
+    assert one_t.requires_grad and relmax(one_t.detach().cpu().numpy(), one_h.cpu().numpy()) < 1e-4
+    sp_t, sp_h = mel(xg), mel(x)
+    assert sp_t.requires_grad and float((sp_t.detach() - sp_h).abs().max()) < 5e-3                    # dB
+    sg = sp_h.clone().requires_grad_(True)
+    lg_t, lg_h = net(sg), net(sp_h)
+    assert lg_t.requires_grad and relmax(lg_t.detach().cpu().numpy(), lg_h.cpu().numpy()) < 2e-4
+
+    # end to end (DDPM t* = 2, device noise keyed by the sample counter): same keys on both branches
+    def logits_engine(xx):
+        den._draws = 0
+        with torch.no_grad():
+            return model(xx)
+    den._draws = 0
+    out = model(xg)
+    ref = logits_engine(x)
+    assert out.requires_grad and relmax(out.detach().cpu().numpy(), ref.cpu().numpy()) < 2e-3
+    cls = int(ref[0].argmax())
+    (g,) = torch.autograd.grad(out[:, cls].sum(), xg)
+    assert g.shape == x.shape and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+    v = g / g.norm()
+    h = 0.05 / float(g.norm())
+    fd = float((logits_engine(x + h * v)[:, cls].sum() - logits_engine(x - h * v)[:, cls].sum()) / (2 * h))
+    assert abs(fd - float(g.norm())) < 0.1 * float(g.norm()), (fd, float(g.norm()))
+
+    # EOT with gradients (reference _EOT.py:36-66): one model call per EOT batch on a leaf that requires grad
+    loss_fn, _ = resolve_loss('Margin', False, 0., 'SCR', None, False)
+    y = torch.tensor([0, 6]).cuda()
+    den._draws = 0
+    scores, loss, grad, decisions = EOT(model, loss_fn, EOT_size=2, EOT_batch_size=1, use_grad=True)(x, y)
+    assert grad.shape == x.shape and bool(torch.isfinite(grad).all()) and float(grad.abs().max()) > 0 and scores.shape == (2, 10)
+    assert [len(d) for d in decisions] == [2, 2]
+    # the branches refuse CPU tensors alike
+    with pytest.raises(DmadError):
+        den.model((x.cpu().requires_grad_(True), 40 * torch.ones(2, 1)))
+    with pytest.raises(DmadError):
+        mel(x.cpu().requires_grad_(True))
+    with pytest.raises(NotImplementedError):
+        net(sp_h.cpu().requires_grad_(True))

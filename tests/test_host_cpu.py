@@ -414,8 +414,16 @@ def test_eot_nes_contract_on_cpu():
     want_loss = sum(torch.nn.functional.cross_entropy(base + 0.1 * c, y, reduction='none') for c in (1, 2, 3)) / 3
     assert torch.allclose(loss, want_loss, atol=1e-6)
     assert [len(d) for d in dec] == [6, 6, 6] and dec[0][0] == int((base + 0.1).argmax(1)[0])
-    with pytest.raises(NotImplementedError):
-        EOT(model, loss_fn, 2, 2, use_grad=True)(x, y)
+    # with gradients (reference l.36-66): one call per EOT batch on a leaf that requires grad, gradient averaged like the scores
+    calls.clear()
+    sg, lg, gg, dg = EOT(model, loss_fn, 4, 2, use_grad=True)(x, y)
+    assert calls == [6, 6] and gg.shape == x.shape and [len(d) for d in dg] == [4, 4, 4]
+    xr = x.clone().requires_grad_(True)
+    want_g = torch.zeros_like(x)
+    for c in (1, 2):
+        (gc,) = torch.autograd.grad(torch.nn.functional.cross_entropy(xr[:, 0, :16] @ W.t() + 0.1 * c, y, reduction='sum'), xr)
+        want_g += gc / 2
+    assert torch.allclose(gg, want_g, atol=1e-6) and torch.allclose(sg, base + 0.1 * (1 + 2) / 2, atol=1e-6)
     calls.clear()
     torch.manual_seed(3)
     nes = NES(samples_per_draw=8, samples_per_draw_batch=4, sigma=0.01, EOT_wrapper=EOT(model, loss_fn, 2, 1, False))
