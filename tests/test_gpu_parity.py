@@ -1382,7 +1382,7 @@ def test_autograd_branch(engines, weights, sched):
     net = synth_vgg().cuda().bind_engine(eng)
     mel = MelSpectrogramDB(eng)
     model = AcousticSystem(classifier=net, transform=mel, defender=den, defense_type='wave')
-    x = torch.from_numpy(np.stack([synth.synthetic_clip(0), synth.synthetic_clip(5)])).cuda().unsqueeze(1)
+    x = torch.from_numpy(np.stack([synth.synthetic_clip(0), synth.synthetic_clip(5)])).cuda()          # [2, 1, 16000]
 
     # stage by stage: torch restatement (requires_grad) against the engine (no grad), same inputs
     xg = x.clone().requires_grad_(True)
