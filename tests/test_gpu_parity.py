@@ -851,6 +851,36 @@ def test_bench_contract():
     assert r.returncode != 0 and 'refusing' in r.stderr and not r.stdout.strip()
 
 
+def test_bench_two_ranks_rehearsal():
+    """The N > 1 form of bench.py, rehearsed as two ranks sharing this box's GPU (gloo for the collectives: DMAD_BENCH_BACKEND, a
+    rehearsal switch; the measured configuration is one rank per GPU over RCCL): the line carries n_gpus = 2, the aggregate
+    value of both ranks' steps, `certify_full` with one clip's samples SHARDED over the ranks (strong scaling), the C3 / C2 legs
+    and the C5 leg sharded the same way, and the exactness check on the timed keys of both ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(DMAD_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(29700 + os.getpid() % 200), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2',
+                        '--warmup', '1', '--samples-per-step', '16', '--max-batch', '16', '--full-n', '200', '--c5-n', '16', '--c2-iters', '1',
+                        '--c2-batch', '8', '--c3-clips', '1', '--check-steps', '1'], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == 2 and sum(j['votes']) == 2 * 16 * 2 and j['scaling'] == 'weak'
+    assert abs(j['value'] - 2 * 16 * 2 / (j['ms_per_step'] * 2e-3)) < 1e-6 * j['value']
+    assert j['exact_equals_fp32'] is True and j['exact_vs_fp32_check']['samples'] == 32
+    cf = j['certify_full']
+    assert cf['n'] == 200 and cf['n_gpus'] == 2 and 'strong' in cf['scaling'] and cf['clips_per_s'] > 0
+    assert j['c3_certify_n1000']['clips_per_s'] > 0 and j['c2_ddpm_mode']['clips_per_s'] > 0
+    c5 = j['c5_spec_mode']
+    assert c5['n'] == 32 and c5['n_gpus'] == 2 and sum(c5['votes']) == 32 and c5['exact_equals_fp32'] is True
+    assert 'cpu_baseline' not in j                                    # rank 0 at N = 1 only
+
+
 # ------------------------------------------------------------------------------------------ exact-vote mode, C4's sigmas
 @pytest.fixture(scope='module')
 def exact_engine(weights):
