@@ -459,3 +459,75 @@ def test_parity_noise_is_streamed_per_batch(monkeypatch):
     from oracle import dmad_oracle as orc
     torch.manual_seed(5)
     assert parts.tolist() == orc.CertifyOracle(clf, None, None).smooth_predict(x, num_sampling=70, sigma=0.5, batch_size=16).tolist()
+
+
+def test_certificate_calibration_and_audit_host_logic():
+    """RobustCertificate's exact-vote housekeeping on a scripted engine (no GPU): calibration runs on the first `calibrate_clips`
+    clips of a sigma and keeps the WIDEST bounds seen (never narrower from clip to clip), re-installs them when another sigma ran
+    in between, logs one line per measurement; audit() re-evaluates only samples that voted on the 16-bit tier (margin >= tau1)
+    and reports exactly the ones whose arg-max differs on the split-f16 tier."""
+    from diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    from dmad_hip.transforms import MelSpectrogramDB
+    from robustness_eval.certified_robust import RobustCertificate
+
+    class ScriptedEngine:
+        has_classifier = has_wavenet = True
+        precision, mode, num_classes = 2, 1, 10
+        recheck_margin, recheck_margin2 = 0.034, 1e-3
+
+        def __init__(self):
+            self.cal = [(0.040, 1.0e-3, 0.020, 1e-4), (0.036, 2.0e-3, 0.018, 9e-4), (0.9, 0.9, 0.5, 0.5)]
+            self.cal_calls, self.eval_calls, self.modes = [], [], []
+
+        def set_recheck_margin(self, v): self.recheck_margin = v
+        def set_recheck_margin2(self, v): self.recheck_margin2 = v
+        def set_mode(self, m): self.modes.append(m); self.mode = m
+
+        def calibrate_recheck(self, x, sigma, sc, t, c_a, c_b, n, n_fp32):
+            self.cal_calls.append((t, n, n_fp32))
+            t1, t2, e1, e2 = self.cal[len(self.cal_calls) - 1]
+            self.recheck_margin, self.recheck_margin2 = t1, t2
+            return t1, t2, e1, e2
+
+        def smooth_votes(self, x, sigma, sc, t, c_a, c_b, n, seed=0, sample0=0, **kw):
+            c = torch.zeros(10, dtype=torch.int64); c[3] = n
+            return c, None, None
+
+        def eval_samples(self, x, sigma, sc, t, c_a, c_b, idx, path=0, seed=0, **kw):
+            self.eval_calls.append((path, idx.tolist()))
+            lg = torch.zeros(len(idx), 10)
+            for r, i in enumerate(idx.tolist()):
+                if path == 0:                       # 16-bit tier: leader 3; sample i has margin 0.01 * (i % 8): < tau1 for i % 8 < 4
+                    lg[r, 3] = 1.0; lg[r, 5] = 1.0 - 0.01 * (i % 8)
+                else:                               # split-f16 tier: sample 7 flips to class 5, everything else agrees
+                    lg[r, 3] = 1.0; lg[r, 5] = 1.2 if i == 7 else 0.5
+            return lg
+
+    eng = ScriptedEngine()
+    cls = type('Cls', (), {})(); cls.engine = eng
+    den = type('Den', (), {})(); den.engine = eng
+    den.diffusion_hyperparams = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG); den.reverse_timestep = 0
+    lines = []
+    rc = RobustCertificate(classifier=cls, transform=MelSpectrogramDB(eng), denoiser=den, seed=4, calibrate=16, calibrate_clips=2, log=lines.append)
+    assert rc._fused()
+    x = torch.zeros(1, 16000)
+    assert rc.smooth_predict(x, num_sampling=20, sigma=0.5, batch_size=8).tolist()[3] == 20
+    assert eng.cal_calls == [(65, 16, 16)] and rc._calibrated[65] == (0.040, 1.0e-3, 0.020, 1e-4)
+    rc.smooth_predict(x, num_sampling=20, sigma=0.5, batch_size=8)                 # second clip: narrower tau1, wider tau2 -> elementwise max
+    assert rc._calibrated[65] == (0.040, 2.0e-3, 0.020, 9e-4) and (eng.recheck_margin, eng.recheck_margin2) == (0.040, 2.0e-3)
+    rc.smooth_predict(x, num_sampling=20, sigma=1.0, batch_size=8)                 # another sigma: its own calibration (third script row)
+    assert eng.cal_calls[-1][0] == 116 and eng.recheck_margin == 0.9
+    rc.smooth_predict(x, num_sampling=20, sigma=0.5, batch_size=8)                 # back: no new measurement, the sigma's bounds re-installed
+    assert len(eng.cal_calls) == 3 and (eng.recheck_margin, eng.recheck_margin2) == (0.040, 2.0e-3) and len(lines) == 3 and 'tau1' in lines[0]
+    # audit of the last smooth_predict: 16 of its 20 samples, tau1 = 0.04 -> the voters are those with i % 8 >= 4
+    rec = rc.audit(x, 16)
+    audited = eng.eval_calls[-2][1]
+    voters = [i for i in audited if i % 8 >= 4]
+    assert eng.eval_calls[-2][0] == 0 and eng.eval_calls[-1] == (2, voters) and len(audited) == 16 and audited == sorted(audited)
+    assert rec['audited'] == 16 and rec['voted_on_tier1'] == len(voters) and rec['tau1'] == 0.040
+    flips = [d for d in rec['disagreements']]
+    assert flips == ([(7, 3, 5, pytest.approx(0.07, abs=1e-6))] if 7 in voters else [])
+    assert eng.modes[-2:] == [0, 1] and rc.audit_log[-1] is rec and 'audit:' in lines[-1]
+    # certify(audit=k) audits every example
+    y, r = rc.certify(x.reshape(1, 1, 16000), torch.tensor([3]), sigma=0.5, n_0=10, n=40, batch_size=8, audit=8)
+    assert int(y[0]) == 3 and len(rc.audit_log) == 2 and rc.audit_log[-1]['audited'] == 8
