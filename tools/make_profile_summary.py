@@ -80,7 +80,11 @@ def main():
         fl, wl = mean_for(f, LAYER, 'FETCH_SIZE'), mean_for(w, LAYER, 'WRITE_SIZE')
         ff, wf = mean_for(f, FINAL, 'FETCH_SIZE'), mean_for(w, FINAL, 'WRITE_SIZE')
         traffic = (2 * fl + wl) * 1024 / a.clips_per_launch
-        json.dump({'layer_traffic_bytes_per_clip': traffic, 'fetch_kb': fl, 'write_kb': wl},
+        # the kernel source these counters belong to: bench.py drops `roofline.traffic` when the layer kernel has changed since
+        src = os.path.join(ROOT, 'diffusion-model-for-audio-defense_amd', 'csrc', 'wn_layer.hip')
+        import hashlib
+        json.dump({'layer_traffic_bytes_per_clip': traffic, 'fetch_kb': fl, 'write_kb': wl,
+                   'layer_kernel_sha16': hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16]},
                   open(os.path.join(prof, a.name + '_layer_traffic.json'), 'w'))
         md += ['', '## PMC (separate --pmc passes of the same program)', '',
                'Per launch of `%s` (%d clips), mean over the launches: FETCH_SIZE %.4g KB, WRITE_SIZE %.4g KB.' % ('wn_layer_p<T, false, false>', a.clips_per_launch, fl, wl),
