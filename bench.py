@@ -159,8 +159,9 @@ def main():
     ap.add_argument('--c2-batch', type=int, default=256, help='clips per batch of the C2 leg (BASELINE C2 names 256)')
     ap.add_argument('--c3-clips', type=int, default=4, help='clips certified with n=1000 for the BASELINE C3 leg; 0 = skip')
     ap.add_argument('--no-certify', action='store_true', help='skip the certify() run through the host mirror')
-    ap.add_argument('--c5-n', type=int, default=1024, help='Monte Carlo samples of the BASELINE C5 side measurement (spec-domain vote loop, '
-                                                           'Improved-Diffusion UNet purifier, t* = 25); 0 = skip; single-GPU runs only')
+    ap.add_argument('--c5-n', type=int, default=10000, help='Monte Carlo samples PER RANK of the BASELINE C5 leg (spec-domain vote loop, '
+                                                            'Improved-Diffusion UNet purifier, t* = 25; BASELINE C5 names N = 10 000: '
+                                                            'about 13 s in the exact-vote mode); 0 = skip')
     ap.add_argument('--classifier', choices=['vgg19_bn', 'resnext29'], default='vgg19_bn',
                     help='vgg19_bn = the configuration BASELINE.json names; resnext29 = the reference script\'s default classifier')
     args = ap.parse_args()
@@ -425,7 +426,7 @@ def main():
             return dt5, cnt.cpu().tolist(), eng5.spec_recheck_stats()
         n32 = max(1, min(args.c5_n, 512))                                    # the exact-fp32 leg: the same first keys, fewer of them
         c5_dt, c5_counts, (c5_voted, c5_re) = c5_run(E.MODE_EXACT_VOTES, args.c5_n)
-        f_dt, f_counts, _ = c5_run(E.MODE_FAST, args.c5_n)
+        f_dt, f_counts, _ = c5_run(E.MODE_FAST, n32)
         x_dt, x_counts, _ = c5_run(E.MODE_EXACT_VOTES, n32)
         p_dt, p_counts, _ = c5_run(E.MODE_FP32, n32)
         evals = (c5_t + 1) * UNET_FLOP_PER_SPEC
@@ -436,7 +437,7 @@ def main():
               "samples_per_s": args.c5_n * world / c5_dt, "n": args.c5_n * world, "n_gpus": world, "seconds": c5_dt, "engine_batch": c5_b,
               "dtype": "f16", "votes": c5_counts, "recheck_frac": c5_re / max(c5_voted, 1),
               "unet_tflops_per_gpu": args.c5_n * evals / c5_dt / 1e12, "frac_of_mfma16_peak": args.c5_n * evals / c5_dt / 1e12 / PEAK_MFMA16_TFLOPS,
-              "fast_mode": {"samples_per_s": args.c5_n * world / f_dt, "votes": f_counts},
+              "fast_mode": {"samples_per_s": n32 * world / f_dt, "n": n32 * world, "votes": f_counts},
               "fp32_mode": {"samples_per_s": n32 * world / p_dt, "n": n32 * world, "votes": p_counts, "unet_tflops_per_gpu": n32 * evals / p_dt / 1e12,
                             "frac_of_fp32_matrix_peak": n32 * evals / p_dt / 1e12 / PEAK_FP32_TFLOPS},
               "exact_equals_fp32": x_counts == p_counts, "votes_exact_same_keys": x_counts}

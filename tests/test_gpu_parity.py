@@ -832,7 +832,7 @@ def test_bench_contract():
     c5 = j['c5_spec_mode']                 # BASELINE C5 beside the headline: the spec-domain vote loop on its own fp32 engine
     assert c5['n'] == 16 and sum(c5['votes']) == 16 and c5['samples_per_s'] > 0 and c5['dtype'] == 'f16' and 0 <= c5['recheck_frac'] <= 1
     assert c5['exact_equals_fp32'] is True and sum(c5['fp32_mode']['votes']) == c5['fp32_mode']['n'] == 16 and 0 < c5['fp32_mode']['frac_of_fp32_matrix_peak'] < 1
-    assert c5['fast_mode']['samples_per_s'] > 0 and sum(c5['fast_mode']['votes']) == 16
+    assert c5['fast_mode']['samples_per_s'] > 0 and sum(c5['fast_mode']['votes']) == c5['fast_mode']['n'] == 16
     # the line proves its own exactness claim: the first timed step's keys in the exact-vote mode and on the exact-fp32 path
     ck = j['exact_vs_fp32_check']
     assert j['exact_equals_fp32'] is True and ck['votes_exact'] == ck['votes_fp32'] and sum(ck['votes_fp32']) == ck['samples'] == 8
