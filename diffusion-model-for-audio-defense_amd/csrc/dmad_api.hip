@@ -236,7 +236,7 @@ struct dmad_engine {
     bool un_h16 = false;
     h16_t* un_buf16[3] = {nullptr};
     std::vector<h16_t*> un_hs16;
-    h16_t *un_t1h = nullptr, *un_uph = nullptr, *un_atth = nullptr;
+    h16_t *un_t1h = nullptr, *un_uph = nullptr, *un_atth = nullptr, *un_qkvh = nullptr;
     float tau_spec = 0.f;                  // recheck bound of the spec-domain vote loop's 16-bit tier (dmad_set_spec_recheck_margin)
     int64_t st_spec_samples = 0, st_spec_rechecked = 0;
 
@@ -727,6 +727,7 @@ int finalize_unet(dmad_engine* e) {
         CHK(e->alloc(&e->un_t1h, B * 1024 * 384));
         CHK(e->alloc(&e->un_uph, B * 1024 * 256));
         CHK(e->alloc(&e->un_atth, B * 256 * 256));
+        CHK(e->alloc(&e->un_qkvh, B * 256 * 768));
         if (int r = gemm_h16_configure()) return fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS, f16 conv GEMM) failed: %d", r);
     }
     CHK(e->alloc(&e->un_ss_table, (size_t)(kUnSsSteps + 1) * e->un_ss_total));
@@ -839,7 +840,7 @@ GemmH16Args un_h16_args(const h16_t* A, const float* bias, const h16_t* X, float
 
 bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, int& H, float* dstf, h16_t* dsth, int& rot, hipStream_t s,
                     UMap* result, UMap in2 = UMap{nullptr, nullptr}, int c1 = 0) {
-    float *T2 = e->un_buf[4], *SK = e->un_buf[5], *QKV = e->un_buf[6];
+    float *T2 = e->un_buf[4], *SK = e->un_buf[5];
     h16_t *T1h = e->un_t1h, *ATTh = e->un_atth;
     float* outf = dstf;
     h16_t* outh = dsth;
@@ -864,8 +865,9 @@ bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, 
     } else if (o.kind == 2) {               // AttentionBlock._forward + QKVAttention, unet.py:225-258
         const int C = o.cin, T = H * H;
         if (launch_groupnorm_nhwc(in.f, o.gn1w, o.gn1b, nullptr, 0, nullptr, B, T, C, s, nullptr, 0, T1h)) { gn_fail(T, C); return false; }
-        launch_gemm_h16(un_h16_args(o.w1h, o.b1, T1h, QKV, nullptr, 3 * C, C, 1, B, H, 1, nullptr), s);
-        if (int rc = launch_qkv_attention(QKV, nullptr, B, T, kUnHeads, s, ATTh)) { fail(rc > 0 ? DMAD_ERR_HIP : DMAD_ERR_STATE, "UNet attention (T = %d): %s", T, rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported map size"); return false; }
+        if ((long)T * C > 256l * 256) { fail(DMAD_ERR_STATE, "UNet attention: %d tokens x %d channels exceed the f16 qkv buffer", T, C); return false; }
+        launch_gemm_h16(un_h16_args(o.w1h, o.b1, T1h, nullptr, e->un_qkvh, 3 * C, C, 1, B, H, 1, nullptr), s);      // qkv straight to f16
+        if (int rc = launch_qkv_attention_h16(e->un_qkvh, ATTh, B, T, kUnHeads, s)) { fail(rc > 0 ? DMAD_ERR_HIP : DMAD_ERR_STATE, "UNet attention (T = %d): %s", T, rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported map size"); return false; }
         launch_gemm_h16(un_h16_args(o.w2h, o.b2, ATTh, outf, outh, C, C, 1, B, H, 1, in.f), s);
     } else if (o.kind == 3) {               // Downsample: conv 3x3 stride 2, unet.py:82-111
         launch_gemm_h16(un_h16_args(o.w1h, o.b1, in.h, outf, outh, o.cout, o.cin, 9, B, H, 2, nullptr), s);

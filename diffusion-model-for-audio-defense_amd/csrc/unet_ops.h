@@ -27,6 +27,8 @@ void launch_upsample2x_nhwc_h16(const h16_t* in, h16_t* out, int B, int H, int W
 // T = 256, 64 or 16 (the 16x16, 8x8 and 4x4 maps this network attends at); returns -1 for any other T, a hipError_t > 0
 // if the kernel could not be configured.
 int launch_qkv_attention(const float* qkv, float* out, int B, int T, int heads, hipStream_t s, h16_t* out16 = nullptr);   // out16: write f16 there instead of out
+// The same on the 16-bit tier: qkv and out in f16, both products on the f16 matrix cores (fp32 accumulate, fp32 softmax).
+int launch_qkv_attention_h16(const h16_t* qkv, h16_t* out, int B, int T, int heads, hipStream_t s);
 // GaussianDiffusion.p_sample (gaussian_diffusion.py:232-257,331-387: epsilon prediction, clip_denoised, fixed variance):
 //   x0 = clamp(ca * x - cb * eps, -1, 1);  out = c1 * x0 + c2 * x + sig * z      (z may be null when sig == 0)
 void launch_unet_p_sample(const float* x, const float* eps, const float* z, float ca, float cb, float c1, float c2, float sig,

@@ -241,6 +241,102 @@ __global__ void __launch_bounds__(KT >= 8 ? 512 : 64 * KT) qkv_attention_kernel(
     }
 }
 
+// The same attention on the 16-bit tier: f16 q / k / v (the qkv conv's f16 output), v_mfma_f32_16x16x32_f16 for both products, fp32
+// scores / softmax / output accumulation, f16 output (proj_out's operand).  Same transposed scheme — S^T = K Q^T leaves lane (c, g)
+// with keys 4g + r of query c per 16-key tile — with the k-slot assignment of the second product chosen so that its B operand is
+// register-local again: one MFMA contracts the keys of TWO tiles, k-slot (q, j) = key 4q + j of tile 2p (j < 4) or of tile 2p + 1
+// (j >= 4), i.e. B = {P[2p][0..3], P[2p+1][0..3]} of the lane itself.  LDS: K as [key][64 ch] f16 (128-byte rows, chunks
+// XOR-swizzled by (key >> 1) & 7: conflict-free ds_read_b128 fragments); V as [key / 4][64 ch][4 keys] f16 with 128 bytes of padding
+// per key group (640-byte rows), so that the A fragment of the second product — 4 consecutive keys of one channel, twice — is two
+// conflict-free ds_read_b64.  16x less matrix time than the fp32 form; what remains is the softmax's exponentials and the LDS fill.
+constexpr int VG = 640;
+template <int KT>
+__global__ void __launch_bounds__(KT >= 8 ? 512 : 64 * KT) qkv_attention_h16_kernel(const h16_t* __restrict__ qkv, h16_t* __restrict__ out, int heads) {
+    extern __shared__ __attribute__((aligned(16))) char att_h[];
+    constexpr int T = 16 * KT, NW = KT >= 8 ? 8 : KT, KP = (KT + 1) / 2;
+    char* Ks = att_h;                                   // T rows of 128 B
+    char* Vg = att_h + T * 128;                         // T / 4 key groups of VG bytes
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C3 = 3 * HD * heads;
+    const h16_t* base = qkv + (long)b * T * C3 + h * 3 * HD;
+    for (int i = tid; i < T * 8; i += NW * 64) {
+        const int r = i >> 3, ch = i & 7;               // key r, channels 8 ch .. 8 ch + 7
+        const u32x4_t kv = *(const u32x4_t*)(base + (long)r * C3 + HD + ch * 8);
+        *(u32x4_t*)(Ks + r * 128 + ((ch ^ ((r >> 1) & 7)) * 16)) = kv;
+        const u32x4_t vv = *(const u32x4_t*)(base + (long)r * C3 + 2 * HD + ch * 8);
+        unsigned short* vd = (unsigned short*)(Vg + (r >> 2) * VG + (ch * 8) * 8 + (r & 3) * 2);      // channel d: + d * 8 bytes
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned w = vv[e];
+            vd[(2 * e) * 4] = (unsigned short)(w & 0xffffu);
+            vd[(2 * e + 1) * 4] = (unsigned short)(w >> 16);
+        }
+    }
+    __syncthreads();
+    const int sw = (c >> 1) & 7;
+    for (int qt = wv; qt < KT; qt += NW) {
+        // query row c of the tile: channels 8g .. 8g+7 and 32 + 8g .. , times scale^2 = 1/8 (exact in f16)
+        f16x8 qf[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const f16x8 v = *(const f16x8*)(base + (long)(qt * 16 + c) * C3 + hh * 32 + g * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[hh][e] = v[e] * (_Float16)0.125f;
+        }
+        f32x4 sacc[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            sacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const f16x8 kf = *(const f16x8*)(Ks + (kt * 16 + c) * 128 + (((4 * hh + g) ^ sw) * 16));
+                sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[hh], sacc[kt], 0, 0, 0);
+            }
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) m = fmaxf(fmaxf(fmaxf(sacc[kt][0], sacc[kt][1]), fmaxf(sacc[kt][2], sacc[kt][3])), m);
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float p = expf(sacc[kt][r] - m); sacc[kt][r] = p; l += p; }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        f32x4 oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            const bool two = 2 * kp + 1 < KT;
+            f16x8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = (_Float16)sacc[2 * kp][r];
+                pf[4 + r] = two ? (_Float16)sacc[two ? 2 * kp + 1 : 0][r] : (_Float16)0.f;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int d = dt * 16 + c;
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                const u32x2_t v0 = *(const u32x2_t*)(Vg + (8 * kp + g) * VG + d * 8);
+                u32x2_t v1 = u32x2_t{0u, 0u};
+                if (two) v1 = *(const u32x2_t*)(Vg + (8 * kp + 4 + g) * VG + d * 8);
+                const f16x8 vf = __builtin_bit_cast(f16x8, u32x4_t{v0[0], v0[1], v1[0], v1[1]});
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
+            }
+        }
+        const float inv = 1.f / l;
+        const long ooff = ((long)b * T + qt * 16 + c) * (HD * heads) + h * HD + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *(f16x4*)(out + ooff + dt * 16) = f16x4{(_Float16)(oacc[dt][0] * inv), (_Float16)(oacc[dt][1] * inv), (_Float16)(oacc[dt][2] * inv), (_Float16)(oacc[dt][3] * inv)};
+    }
+}
+
 __global__ void unet_p_sample_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ z, float ca,
                                      float cb, float c1, float c2, float sig, float* __restrict__ out, float* __restrict__ x0_out, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -335,6 +431,21 @@ int launch_qkv_attention(const float* qkv, float* out, int B, int T, int heads, 
         hipLaunchKernelGGL(qkv_attention_kernel<1>, dim3((unsigned)heads, (unsigned)B), dim3(64), lds, s, qkv, out, heads, out16);
     } else {
         return -1;                  // this network attends at 16x16, 8x8 (script_util.py attention_resolutions "16,8") and 4x4 (middle block)
+    }
+    return 0;
+}
+int launch_qkv_attention_h16(const h16_t* qkv, h16_t* out, int B, int T, int heads, hipStream_t s) {
+    const size_t lds = (size_t)T * 128 + (size_t)(T / 4) * VG;
+    if (T == 256) {
+        static const hipError_t once = hipFuncSetAttribute((const void*)qkv_attention_h16_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (once != hipSuccess) return (int)once;
+        hipLaunchKernelGGL(qkv_attention_h16_kernel<16>, dim3((unsigned)heads, (unsigned)B), dim3(512), lds, s, qkv, out, heads);
+    } else if (T == 64) {
+        hipLaunchKernelGGL(qkv_attention_h16_kernel<4>, dim3((unsigned)heads, (unsigned)B), dim3(256), lds, s, qkv, out, heads);
+    } else if (T == 16) {
+        hipLaunchKernelGGL(qkv_attention_h16_kernel<1>, dim3((unsigned)heads, (unsigned)B), dim3(64), lds, s, qkv, out, heads);
+    } else {
+        return -1;
     }
     return 0;
 }
