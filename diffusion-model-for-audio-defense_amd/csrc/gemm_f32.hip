@@ -25,6 +25,7 @@ namespace {
 constexpr int BN = 128, BK = 16;          // BM = 128, or 64 for layers / conv groups with at most 64 output channels
 constexpr int SLOT = 16384;                       // 128 A rows + 128 X rows of 64 B
 __device__ __attribute__((aligned(64))) float g_zero_page[16];                 // 64 B of zeros: source of every out-of-problem row
+__device__ __attribute__((aligned(128))) float g_zero_page_x3[32];             // 128 B of zeros: the split-f16 kernel stages 128-byte rows
 
 #define GF_WAIT_BARRIER(N)                                                          \
     do {                                                                            \
@@ -264,11 +265,15 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
 // flight: tile 256(M) x 128(N), 8 waves (4 x 2, wave tile 64 x 64, one workgroup per CU), pair = 48 KiB (A 2 x 16 KiB,
 // X 2 x 8 KiB), 3-pair ring = 144 KiB of dynamic LDS: two pairs in flight while one is contracted, one barrier per pair.
 // ----------------------------------------------------------------------------------------------------------------
-constexpr int X3_BM = 256, X3_STAGE = 24576, X3_PAIR = 2 * X3_STAGE, X3_LDS = 3 * X3_PAIR;
+constexpr int X3_BM = 256, X3_PAIR = 384 * 128, X3_LDS = 3 * X3_PAIR;
 // DIAG (error-attribution builds of tools/gpu_error_attribution.py, never the product launches): GemmF32Args::diag switches
 // single roundings of the 16-bit path on inside this fp32-grade pipeline — bit 0: the weights' lo parts are ignored (weights
 // = f16(w)), bit 1: the activations' lo parts are ignored (the MFMA eats f16(x), the stored value keeps its 22 bits), bit 2:
 // outputs in the split format are written with lo = 0 (the stored gate / residual stream is f16).
+// Round 3: a staged row is 128 bytes (32 values = the k-step PAIR in one row), so that eight consecutive lanes of an LDS-DMA
+// instruction fetch one whole cache line (64-byte rows asked L2 for every line twice); the eight 16-byte chunks of a row are
+// XOR-swizzled by (row >> 1) & 7 (conflict-free ds_read_b128 under the hardware's lane groups, tools/lds_bank_check.py); lane
+// (row, q) reads chunks q and q + 4: 8 hi and 8 lo halves = one K = 32 fragment of each part, as before.
 template <bool DIAG>
 __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
     constexpr int BM = X3_BM, MT = 4;
@@ -279,52 +284,58 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
     const int wm = wv >> 1, wn = wv & 1, q = lane >> 4, r16 = lane & 15;
     const long n0 = (long)blockIdx.x * BN;
     const int m0 = blockIdx.y * BM;
-    const int ksteps_per_tap = a.K / BK, npairs = (a.taps * ksteps_per_tap) >> 1;
-    // staging rows of this thread: A rows rloc and rloc + 128 of the 256, X row rloc of the 128 (8 waves x 16 rows per piece)
-    const int rloc = wv * 16 + (lane >> 2), chunk4 = ((lane & 3) ^ swz64(lane >> 2)) * 4;
-    const float* zero = g_zero_page;
-    const float* arow[2];
+    const int pairs_per_tap = a.K / 32, npairs = a.taps * pairs_per_tap;
+    // staging: six 64-row pieces of 8 KiB per pair (A rows 0-255, X rows 0-127); this thread's row of a piece: wave * 8 + lane / 8,
+    // its LDS slot lane & 7 holds chunk (lane & 7) ^ ((row >> 1) & 7) of that row (4 values = one split-format chunk)
+    const int rloc = wv * 8 + (lane >> 3), chunk4 = ((lane & 7) ^ ((rloc >> 1) & 7)) * 4;
+    const float* zero = g_zero_page_x3 + (lane & 7) * 4;
+    const float* arow[4];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) arow[p] = a.A + (size_t)(m0 + p * 128 + rloc) * a.K + chunk4;       // M is a multiple of 256 (launcher)
-    const long n = n0 + rloc;
-    const bool xok = n < a.N;
-    const long xb = xok ? n / a.rows_per_batch : 0;
-    const long xbase = xb * a.batch_stride + (xok ? n - xb * a.rows_per_batch : 0) * a.row_stride;
-    auto stage = [&](int ks, char* base) {          // base: this k-step's 24 KiB (A rows 0-255: 16 KiB, X rows 0-127: 8 KiB)
-        const int tap = ks / ksteps_per_tap, kc = (ks - tap * ksteps_per_tap) * BK;
+    for (int p = 0; p < 4; ++p) arow[p] = a.A + (size_t)(m0 + p * 64 + rloc) * a.K + chunk4;       // M is a multiple of 256 (launcher)
+    const float* xrow[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const long n = n0 + p * 64 + rloc;
+        xrow[p] = nullptr;
+        if (n < a.N) {
+            const long xb = n / a.rows_per_batch;
+            xrow[p] = a.X + xb * a.batch_stride + (n - xb * a.rows_per_batch) * a.row_stride + chunk4;
+        }
+    }
+    auto stage = [&](int pr, char* base) {          // base: this pair's 48 KiB (A rows 0-255: 32 KiB, X rows 0-127: 16 KiB)
+        const int tap = pr / pairs_per_tap, kc = (pr - tap * pairs_per_tap) * 32;
         char* la = base + wv * 1024;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) glds16(arow[p] + (size_t)tap * a.M * a.K + kc, la + p * 8192);
-        glds16(xok ? a.X + xbase + (long)(tap - (a.taps >> 1)) * a.tap_stride + kc + chunk4 : zero, la + 16384);
+        for (int p = 0; p < 4; ++p) glds16(arow[p] + (size_t)tap * a.M * a.K + kc, la + p * 8192);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) glds16(xrow[p] ? xrow[p] + (long)(tap - (a.taps >> 1)) * a.tap_stride + kc : zero, la + 32768 + p * 8192);
     };
     f32x4 acc[MT][4], cor[MT][4];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; cor[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const int frag = r16 * 64 + ((q ^ swz64(r16)) * 16);
-    stage(0, smem); stage(1, smem + X3_STAGE);
-    if (npairs > 1) { stage(2, smem + X3_PAIR); stage(3, smem + X3_PAIR + X3_STAGE); }
+    const int sw = (r16 >> 1) & 7;
+    const int f0 = r16 * 128 + ((q ^ sw) * 16), f1 = r16 * 128 + (((4 + q) ^ sw) * 16);
+    stage(0, smem);
+    if (npairs > 1) stage(1, smem + X3_PAIR);
     int slot = 0;
     for (int p = 0; p < npairs; ++p) {
         // pair p landed (the 6 pieces of pair p+1 may still fly); every wave is done reading pair p-1
         if (p + 1 < npairs) { GF_WAIT_BARRIER(6); } else { GF_WAIT_BARRIER(0); }
-        if (p + 2 < npairs) {
-            char* nb = smem + (slot == 0 ? 2 : slot - 1) * X3_PAIR;      // the slot pair p-1 occupied
-            stage(2 * p + 4, nb); stage(2 * p + 5, nb + X3_STAGE);
-        }
-        const char* A0 = smem + slot * X3_PAIR + wm * 4096 + frag;
-        const char* B0 = smem + slot * X3_PAIR + 16384 + wn * 4096 + frag;
+        if (p + 2 < npairs) stage(p + 2, smem + (slot == 0 ? 2 : slot - 1) * X3_PAIR);      // into the slot pair p-1 occupied
+        const char* A0 = smem + slot * X3_PAIR + wm * 8192;
+        const char* B0 = smem + slot * X3_PAIR + 32768 + wn * 8192;
         f16x8 ahi[MT], alo[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const u32x4_t c0 = *(const u32x4_t*)(A0 + i * 1024), c1 = *(const u32x4_t*)(A0 + X3_STAGE + i * 1024);
+            const u32x4_t c0 = *(const u32x4_t*)(A0 + i * 2048 + f0), c1 = *(const u32x4_t*)(A0 + i * 2048 + f1);
             ahi[i] = __builtin_bit_cast(f16x8, u32x4_t{c0[0], c0[1], c1[0], c1[1]});
             alo[i] = __builtin_bit_cast(f16x8, u32x4_t{c0[2], c0[3], c1[2], c1[3]});
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const u32x4_t c0 = *(const u32x4_t*)(B0 + j * 1024), c1 = *(const u32x4_t*)(B0 + X3_STAGE + j * 1024);
+            const u32x4_t c0 = *(const u32x4_t*)(B0 + j * 2048 + f0), c1 = *(const u32x4_t*)(B0 + j * 2048 + f1);
             const f16x8 bhi = __builtin_bit_cast(f16x8, u32x4_t{c0[0], c0[1], c1[0], c1[1]});
             const f16x8 blo = __builtin_bit_cast(f16x8, u32x4_t{c0[2], c0[3], c1[2], c1[3]});
 #pragma unroll
@@ -455,8 +466,7 @@ int gemm_x3_configure() {
 int launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab_floats, long n_ref) {
     GemmF32Args a = a0;
     if (a.x3) {                                   // split-f16 operands: WaveNet shapes only (checked here, not in the kernel)
-        const int nks = a.taps * (a.K / BK);
-        if (a.mode != 0 || (a.M % X3_BM) || (nks & 1) || a.scale || a.res || a.groups > 1 || (a.ldc & 3)) { ++g_bad_shapes; return kGemmBadShape; }
+        if (a.mode != 0 || (a.M % X3_BM) || (a.K % 32) || a.scale || a.res || a.groups > 1 || (a.ldc & 3)) { ++g_bad_shapes; return kGemmBadShape; }
         a.splits = 1; a.slab = nullptr;
         const dim3 grid((unsigned)((a.N + BN - 1) / BN), (unsigned)(a.M / X3_BM));
         if (a.diag) hipLaunchKernelGGL(gemm_x3_kernel<true>, grid, dim3(512), X3_LDS, s, a);
