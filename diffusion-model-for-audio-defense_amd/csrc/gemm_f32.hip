@@ -185,6 +185,12 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
         return;
     }
     if (BM == 128 && a.epi == 2) {          // h' = (h + res) * sqrt(1/2) + emb_next ; skip (+)= skip conv
+        long hrow[4];                       // stream row of position n, once per accumulator column (N < 2^31 positions)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned n32 = (unsigned)(n0 + wn * 64 + j * 16 + r16), bb = n32 / (unsigned)a.L;
+            hrow[j] = ((long)bb * a.LP + kPad + (n32 - bb * (unsigned)a.L)) * kC;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int m = m0 + wm * 64 + i * 16 + q * 4;
@@ -201,8 +207,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + ba[r];
                 if (is_res) {
-                    const long bb = n / a.L, t = n - bb * a.L;
-                    const long hoff = (bb * a.LP + kPad + t) * kC + m;
+                    const long hoff = hrow[j] + m;
                     const float4 h = *(const float4*)(a.hin + hoff);
                     const float k = 0.70710678118654752440f;
                     *(float4*)(a.hout + hoff) = float4{__fadd_rn(__fmul_rn(__fadd_rn(h.x, v[0]), k), ea[0]), __fadd_rn(__fmul_rn(__fadd_rn(h.y, v[1]), k), ea[1]),
@@ -384,6 +389,14 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
         return;
     }
     if (a.epi == 2) {                        // h' (split-f16, operand of the next layer) ; skip sum (fp32)
+        // row of position n inside the zero-padded residual stream, once per accumulator column (not per tile: a 64-bit division
+        // per (i, j) cost the K = 256 res launches a fifth of their time); N < 2^31 positions (launcher)
+        long hrow[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned n32 = (unsigned)(n0 + wn * 64 + j * 16 + r16), bb = n32 / (unsigned)a.L;
+            hrow[j] = ((long)bb * a.LP + kPad + (n32 - bb * (unsigned)a.L)) * kC;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int m = m0 + wm * 64 + i * 16 + q * 4;
@@ -400,8 +413,7 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + ba[r];
                 if (is_res) {
-                    const long bb = n / a.L, t = n - bb * a.L;
-                    const long hoff = (bb * a.LP + kPad + t) * kC + m;
+                    const long hoff = hrow[j] + m;
                     float h[4];
                     join4(*(const u32x4_t*)(a.hin + hoff), h);
                     const float k = 0.70710678118654752440f;
@@ -465,6 +477,7 @@ int gemm_x3_configure() {
 
 int launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab_floats, long n_ref) {
     GemmF32Args a = a0;
+    if (a.epi == 2 && (a.N >= (1l << 31) || a.L < 1)) { ++g_bad_shapes; return kGemmBadShape; }       // the update epilogue indexes positions in 32 bits
     if (a.x3) {                                   // split-f16 operands: WaveNet shapes only (checked here, not in the kernel)
         if (a.mode != 0 || (a.M % X3_BM) || (a.K % 32) || a.scale || a.res || a.groups > 1 || (a.ldc & 3)) { ++g_bad_shapes; return kGemmBadShape; }
         a.splits = 1; a.slab = nullptr;
