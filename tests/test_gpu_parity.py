@@ -483,6 +483,45 @@ def test_certification_driver_end_to_end(engines, tmp_path, monkeypatch):
     assert [r['y_true'] for r in again] == list(range(10))
 
 
+def test_certification_driver_audit_and_calibration(exact_engine, tmp_path):
+    """The driver on an exact-vote engine (the drop-in default): --calibrate_margins measures the recheck bounds on the first
+    --calibrate_clips clips (they can only widen) and logs what it saw; --audit k re-evaluates k tier-1 voters per example on
+    the split-f16 tier and writes the outcome into each record under "audit"; the reference's four keys are unchanged."""
+    import json
+    import wave
+    import certified_robustness_eval as drv
+    from datasets.sc_dataset import SC09_CLASSES
+    from diffusion_models.diffwave_ddpm import create_diffwave_model
+    from dmad_hip import engine as E
+    eng = exact_engine
+    data = tmp_path / 'test'
+    for ci, c in enumerate(SC09_CLASSES):
+        (data / c).mkdir(parents=True)
+        with wave.open(str(data / c / 'a.wav'), 'wb') as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes(np.clip(np.round(synth.synthetic_clip(ci)[0] * 32768.0), -32768, 32767).astype('<i2').tobytes())
+    cfg = str(tmp_path / 'config.json')
+    json.dump({'wavenet_config': synth.WAVENET_CONFIG, 'diffusion_config': synth.DIFFUSION_CONFIG}, open(cfg, 'w'))
+    den = create_diffwave_model(None, cfg, state_dict=synth.wavenet_state_dict(1234), engine=eng)
+    args = drv.build_parser().parse_args(['--data_path', str(data), '--num_per_class', '1', '--config', cfg, '--sigma', '0.5',
+                                          '--num_sampling', '24', '--batch_size', '4', '--dataload_workers_nums', '0',
+                                          '--save_path', str(tmp_path / 'records'), '--calibrate_margins', '32', '--calibrate_clips', '2',
+                                          '--audit', '8'])
+    old = (eng.recheck_margin, eng.recheck_margin2)
+    lines = []
+    try:
+        recs = drv.run(args, classifier=synth_vgg(), denoiser=den, log=lines.append)
+    finally:
+        eng.set_recheck_margin(old[0]); eng.set_recheck_margin2(old[1])
+    assert len(recs) == 10 and all(set(r) == {'id', 'y_true', 'y_pred', 'certified_radius', 'audit'} for r in recs)
+    for r in recs:
+        a = r['audit']
+        assert a['audited'] == 8 and 0 <= a['voted_on_tier1'] <= 8 and a['disagreements'] == [] and a['tau1'] >= E.DEFAULT_RECHECK_MARGIN[E.HALF_F16]
+    cal = [ln for ln in lines if ln.startswith('recheck bounds')]
+    assert len(cal) == 2 and 'clip 2 of 2' in cal[1] and sum(ln.startswith('audit:') for ln in lines) == 10
+    assert json.load(open(tmp_path / 'records' / 'sigma=0.5' / 'sigma=0.5_N=24.json')) == recs
+
+
 # ------------------------------------------------------------------------------------------ batched query path (N3)
 def test_eot_nes_query_path(engines, orc):
     """AcousticSystem(defender = t*-step DDPM purifier) queried through the EOT / NES wrappers of the black-box drivers
