@@ -1249,6 +1249,18 @@ def test_config5_exact_votes_on_the_16bit_unet_tier():
     cz, lz, _ = eng.spec_smooth_votes(*args, 100, batch=32, seed=11, want_logits=True)
     eng.set_spec_recheck_margin(old)
     assert torch.equal(lz, l32[:100]) and int(cz.sum()) == 100
+    # edge cases: an empty loop votes nothing; a NaN clip gives NaN logits on the 16-bit tier, is queued, re-run on the fp32 tier and
+    # votes as torch.max does (first NaN index), exactly like the fp32 mode
+    c0, _, _ = eng.spec_smooth_votes(*args, 0, seed=11)
+    assert c0.tolist() == [0] * 10
+    bad = clip.clone()
+    bad[0, 100] = float('nan')
+    bargs = (bad, sigma) + coef + (-100.0, 38.22)
+    eng.spec_recheck_stats(reset=True)
+    cn, ln, _ = eng.spec_smooth_votes(*bargs, 5, batch=4, seed=1, want_logits=True)
+    assert bool(torch.isnan(ln).all()) and cn.tolist() == [5, 0, 0, 0, 0, 0, 0, 0, 0, 0] and eng.spec_recheck_stats() == (5, 5)
+    eng.set_mode(E.MODE_FP32)
+    assert eng.spec_smooth_votes(*bargs, 5, batch=4, seed=1)[0].tolist() == cn.tolist()
     eng.close()
 
 
