@@ -121,7 +121,13 @@ def run(args, classifier=None, denoiser=None, log=print):
                              extra=[{'audit': a} for a in audits] if len(audits) == len(targets) else None)
         if rank == 0:
             records.flush()
-            log('certified %d / %d examples' % (len(records), len(test_dataset)))
+            msg = 'certified %d / %d examples' % (len(records), len(test_dataset))
+            eng = getattr(denoiser, 'engine', None)
+            if eng is not None and getattr(eng, 'precision', None) == 2:      # exact-vote engine: what the recheck tiers did so far (this rank)
+                voted, left16, to_fp32 = eng.recheck_stats(detail=True)
+                msg += '; of %d samples voted on this rank %d (%.2f %%) left the 16-bit tier and %d reached fp32 (bounds %.4g / %.3g)' % (
+                    voted, left16, 100.0 * left16 / max(voted, 1), to_fp32, eng.recheck_margin, eng.recheck_margin2)
+            log(msg)
     return records.records
 
 

@@ -519,6 +519,7 @@ def test_certification_driver_audit_and_calibration(exact_engine, tmp_path):
         assert a['audited'] == 8 and 0 <= a['voted_on_tier1'] <= 8 and a['disagreements'] == [] and a['tau1'] >= E.DEFAULT_RECHECK_MARGIN[E.HALF_F16]
     cal = [ln for ln in lines if ln.startswith('recheck bounds')]
     assert len(cal) == 2 and 'clip 2 of 2' in cal[1] and sum(ln.startswith('audit:') for ln in lines) == 10
+    assert 'left the 16-bit tier' in [ln for ln in lines if ln.startswith('certified')][-1]
     assert json.load(open(tmp_path / 'records' / 'sigma=0.5' / 'sigma=0.5_N=24.json')) == recs
 
 
