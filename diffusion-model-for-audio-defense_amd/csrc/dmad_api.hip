@@ -236,7 +236,7 @@ struct dmad_engine {
     bool un_h16 = false;
     h16_t* un_buf16[3] = {nullptr};
     std::vector<h16_t*> un_hs16;
-    h16_t *un_t1h = nullptr, *un_uph = nullptr, *un_atth = nullptr, *un_qkvh = nullptr;
+    h16_t *un_t1h = nullptr, *un_t2h = nullptr, *un_uph = nullptr, *un_atth = nullptr, *un_qkvh = nullptr;
     float tau_spec = 0.f;                  // recheck bound of the spec-domain vote loop's 16-bit tier (dmad_set_spec_recheck_margin)
     int64_t st_spec_samples = 0, st_spec_rechecked = 0;
 
@@ -725,6 +725,7 @@ int finalize_unet(dmad_engine* e) {
         }
         for (int i = 0; i < 3; ++i) CHK(e->alloc(&e->un_buf16[i], B * 1024 * 384));
         CHK(e->alloc(&e->un_t1h, B * 1024 * 384));
+        CHK(e->alloc(&e->un_t2h, B * 1024 * 256));
         CHK(e->alloc(&e->un_uph, B * 1024 * 256));
         CHK(e->alloc(&e->un_atth, B * 256 * 256));
         CHK(e->alloc(&e->un_qkvh, B * 256 * 768));
@@ -840,8 +841,8 @@ GemmH16Args un_h16_args(const h16_t* A, const float* bias, const h16_t* X, float
 
 bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, int& H, float* dstf, h16_t* dsth, int& rot, hipStream_t s,
                     UMap* result, UMap in2 = UMap{nullptr, nullptr}, int c1 = 0) {
-    float *T2 = e->un_buf[4], *SK = e->un_buf[5];
-    h16_t *T1h = e->un_t1h, *ATTh = e->un_atth;
+    float* SK = e->un_buf[5];
+    h16_t *T1h = e->un_t1h, *T2h = e->un_t2h, *ATTh = e->un_atth;
     float* outf = dstf;
     h16_t* outh = dsth;
     if (!outf) {
@@ -851,9 +852,10 @@ bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, 
     }
     if (o.kind == 1) {                      // ResBlock._forward, unet.py:186-199
         if (in2.f && o.cin == o.cout) { fail(DMAD_ERR_STATE, "a concatenated input needs the ResBlock's skip conv"); return false; }
-        if (launch_groupnorm_nhwc(in.f, o.gn1w, o.gn1b, nullptr, 1, nullptr, B, H * H, o.cin, s, in2.f, c1, T1h)) { gn_fail(H * H, o.cin); return false; }
-        launch_gemm_h16(un_h16_args(o.w1h, o.b1, T1h, T2, nullptr, o.cout, o.cin, 9, B, H, 1, nullptr), s);
-        if (launch_groupnorm_nhwc(T2, o.gn2w, o.gn2b, e->un_ss_cur + o.ss_off, 1, nullptr, B, H * H, o.cout, s, nullptr, 0, T1h)) { gn_fail(H * H, o.cout); return false; }
+        // GroupNorm reads the f16 twins (the network input of the first block excepted: it has none); the in_layers conv writes f16 only
+        if (launch_groupnorm_nhwc(in.f, o.gn1w, o.gn1b, nullptr, 1, nullptr, B, H * H, o.cin, s, in2.f, c1, T1h, in.h, in2.h)) { gn_fail(H * H, o.cin); return false; }
+        launch_gemm_h16(un_h16_args(o.w1h, o.b1, T1h, nullptr, T2h, o.cout, o.cin, 9, B, H, 1, nullptr), s);
+        if (launch_groupnorm_nhwc(nullptr, o.gn2w, o.gn2b, e->un_ss_cur + o.ss_off, 1, nullptr, B, H * H, o.cout, s, nullptr, 0, T1h, T2h)) { gn_fail(H * H, o.cout); return false; }
         const float* skip = in.f;
         if (o.cin != o.cout) {
             GemmH16Args g = un_h16_args(o.skwh, o.skb, in.h, SK, nullptr, o.cout, o.cin, 1, B, H, 1, nullptr);
@@ -864,7 +866,7 @@ bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, 
         launch_gemm_h16(un_h16_args(o.w2h, o.b2, T1h, outf, outh, o.cout, o.cout, 9, B, H, 1, skip), s);
     } else if (o.kind == 2) {               // AttentionBlock._forward + QKVAttention, unet.py:225-258
         const int C = o.cin, T = H * H;
-        if (launch_groupnorm_nhwc(in.f, o.gn1w, o.gn1b, nullptr, 0, nullptr, B, T, C, s, nullptr, 0, T1h)) { gn_fail(T, C); return false; }
+        if (launch_groupnorm_nhwc(in.f, o.gn1w, o.gn1b, nullptr, 0, nullptr, B, T, C, s, nullptr, 0, T1h, in.h)) { gn_fail(T, C); return false; }
         if ((long)T * C > 256l * 256) { fail(DMAD_ERR_STATE, "UNet attention: %d tokens x %d channels exceed the f16 qkv buffer", T, C); return false; }
         launch_gemm_h16(un_h16_args(o.w1h, o.b1, T1h, nullptr, e->un_qkvh, 3 * C, C, 1, B, H, 1, nullptr), s);      // qkv straight to f16
         if (int rc = launch_qkv_attention_h16(e->un_qkvh, ATTh, B, T, kUnHeads, s)) { fail(rc > 0 ? DMAD_ERR_HIP : DMAD_ERR_STATE, "UNet attention (T = %d): %s", T, rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported map size"); return false; }

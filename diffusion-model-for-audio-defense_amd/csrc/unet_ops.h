@@ -17,7 +17,8 @@ void launch_conv3x3_c128_to1(const float* in, const float* w, const float* bias,
 // x2 != nullptr: the input is the channel concatenation [x : c1 channels | x2 : C - c1 channels] (th.cat(dim=1), unet.py:473)
 // read from its two parts; y is always one map of C channels.
 int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* ss, int silu, float* y, int B, int HW,
-                          int C, hipStream_t s, const float* x2 = nullptr, int c1 = 0, h16_t* y16 = nullptr);      // y16 != nullptr: the result is written as f16 there (y unused)
+                          int C, hipStream_t s, const float* x2 = nullptr, int c1 = 0, h16_t* y16 = nullptr,      // y16 != nullptr: the result is written as f16 there (y unused)
+                          const h16_t* x16 = nullptr, const h16_t* x2_16 = nullptr);   // x16 != nullptr: the input is read from f16 map(s) x16 (/ x2_16) instead of x (/ x2)
 void launch_silu(const float* x, float* y, long n, hipStream_t s);
 // nearest-neighbour x2 (F.interpolate(scale_factor=2, mode="nearest"), unet.py:72)
 void launch_upsample2x_nhwc(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);

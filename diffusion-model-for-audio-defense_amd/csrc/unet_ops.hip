@@ -64,7 +64,9 @@ __global__ void __launch_bounds__(256) conv3x3_c128_to1_kernel(const float* __re
 // mean, the biased variance of the deviations (two-pass, like torch) and the affine / scale-shift / SiLU pass run without
 // touching memory again.  Group sums: per-thread partials to LDS, wave w adds the partials of group w in a fixed order
 // (deterministic: no atomics), everybody reads the G results.
-template <int PER>
+// IN16 (the UNet's 16-bit tier): the input map(s) are read from their f16 twins (x / x2 then point at f16 data; half the bytes of a
+// kernel that is bound by its memory traffic); statistics and arithmetic stay fp32.
+template <int PER, bool IN16>
 __global__ void __launch_bounds__(1024) groupnorm_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ ss, int silu,
                                                               float* __restrict__ y, int HW, int C, int G,
@@ -79,7 +81,9 @@ __global__ void __launch_bounds__(1024) groupnorm_nhwc_kernel(const float* __res
     // input: one map of C channels, or the concatenation [x (c1 channels) | x2 (C - c1 channels)] read in place
     const bool second = x2 && c >= c1;
     const int pitch = x2 ? (second ? C - c1 : c1) : C;
-    const float* src = second ? x2 + (long)b * HW * pitch + (c - c1) : x + (long)b * HW * pitch + c;
+    const long soff = second ? (long)b * HW * pitch + (c - c1) : (long)b * HW * pitch + c;        // in elements of the input type
+    const float* src = (second ? x2 : x) + soff;
+    const h16_t* src16 = (const h16_t*)(second ? x2 : x) + soff;
     const int p0 = t / R, pstep = NT / R;
     const float n = (float)((C >> 5) * HW);
     auto group_sum = [&](float v) -> float {
@@ -101,7 +105,9 @@ __global__ void __launch_bounds__(1024) groupnorm_nhwc_kernel(const float* __res
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int pix = p0 + k * pstep;
-        v[k] = pix < HW ? *(const float4*)(src + (long)pix * pitch) : float4{0.f, 0.f, 0.f, 0.f};
+        if (pix >= HW) v[k] = float4{0.f, 0.f, 0.f, 0.f};
+        else if (IN16) { const f16x4 hv = *(const f16x4*)(src16 + (long)pix * pitch); v[k] = float4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]}; }
+        else v[k] = *(const float4*)(src + (long)pix * pitch);
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
@@ -383,7 +389,9 @@ void launch_conv3x3_c128_to1(const float* in, const float* w, const float* bias,
     hipLaunchKernelGGL(conv3x3_c128_to1_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, in, w, bias, out, total);
 }
 int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* ss, int silu, float* y, int B, int HW,
-                          int C, hipStream_t s, const float* x2, int c1, h16_t* y16) {
+                          int C, hipStream_t s, const float* x2, int c1, h16_t* y16, const h16_t* x16, const h16_t* x2_16) {
+    const bool in16 = x16 != nullptr;
+    if (in16) { x = (const float*)x16; x2 = (const float*)x2_16; }      // the kernel reinterprets them (IN16)
     const int c4 = C >> 7;
     if (C % 128 || c4 < 1 || c4 > 4 || B < 1 || HW < 1) return -1;
     if (x2 && (c1 < 4 || c1 >= C || (c1 & 3))) return -1;       // 32 groups of 4, 8, 12 or 16 channels
@@ -398,7 +406,11 @@ int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta,
     const int want = HW >= 1024 ? 8 : HW >= 256 ? 4 : 2;          // float4s per thread: small maps are latency bound and want more threads
     while (per < want && NT > 64 && (NT / 2) % R == 0 && (NT / 2) % 64 == 0) { NT /= 2; per = (int)((n4 + NT - 1) / NT); }
     const dim3 grid((unsigned)(B * (32 / G)));
-#define GN_LAUNCH(PER) hipLaunchKernelGGL(groupnorm_nhwc_kernel<PER>, grid, dim3(NT), 0, s, x, gamma, beta, ss, silu, y, HW, C, G, x2, c1, y16)
+#define GN_LAUNCH(PER)                                                                                                                  \
+    do {                                                                                                                               \
+        if (in16) hipLaunchKernelGGL((groupnorm_nhwc_kernel<PER, true>), grid, dim3(NT), 0, s, x, gamma, beta, ss, silu, y, HW, C, G, x2, c1, y16);  \
+        else hipLaunchKernelGGL((groupnorm_nhwc_kernel<PER, false>), grid, dim3(NT), 0, s, x, gamma, beta, ss, silu, y, HW, C, G, x2, c1, y16);     \
+    } while (0)
     if (per <= 1) GN_LAUNCH(1);
     else if (per <= 2) GN_LAUNCH(2);
     else if (per <= 4) GN_LAUNCH(4);
