@@ -454,7 +454,7 @@ def main():
                                    "N=100000 clip" % (sigma, t + 1, 'VGG19_bn' if args.classifier == 'vgg19_bn' else 'ResNeXt29', S, -(-100000 // S)),
                        "samples_per_step_per_gpu": S, "engine_batch": args.max_batch, "sigma": sigma, "t_star": t + 1,
                        "mode": {"exact": "exact-vote: %s MFMA WaveNet + split-f16 / exact-fp32 re-evaluation of samples with top-2 logit margin < %.3g "
-                                         "(empirical bound: no vote differed from the fp32 path's on 36 864 + 100 000 samples; this "
+                                         "(empirical bound: no vote differed from the fp32 path's on 236 864 samples (36 864 + 2 x 100 000); this "
                                          "line's own check: exact_equals_fp32)" % (args.half, recheck_margin),
                                 "fast": "%s MFMA WaveNet alone (no recheck)" % args.half, "fp32": "exact-fp32 WaveNet alone"}[args.mode],
                        "noise": "device Philox4x32-10", "classifier": "VGG19_bn (synthetic seed 4321)" if args.classifier == 'vgg19_bn' else "ResNeXt29 8x64d (synthetic seed 2929)",
