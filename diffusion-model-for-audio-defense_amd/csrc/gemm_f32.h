@@ -28,10 +28,11 @@ struct GemmF32Args {
     //   epi 1  gate: the rows of A / shift are permuted so that every wave holds a gate channel's tanh row (accumulator
     //          tiles 0-1) and its sigmoid row (tiles 2-3): tile-local row wm*64 + i*16 + r of block bm is H row
     //          (i >= 2 ? 256 : 0) + bm*64 + wm*32 + (i&1)*16 + r.  C[n][ch] = tanh(H[ch]) * sigmoid(H[256+ch]), ldc = 256.
-    //   epi 2  update: rows [0, res_rows) are the res conv, the rest the skip conv:
-    //          hout[row(n)][m] = (hin[row(n)][m] + v) * sqrt(1/2) + emb_next[m],  skip[n][m - res_rows] (+)= v
-    //          (row(n) = position n inside the zero-padded residual stream; res_rows = 0 on the last layer, whose residual
-    //          output is never consumed; `first`: the skip sum starts here).
+    //   epi 2  update (M = 256 = res_rows, the res conv):
+    //          hout[row(n)][m] = (hin[row(n)][m] + v) * sqrt(1/2) + emb_next[m]
+    //          (row(n) = position n inside the zero-padded residual stream; the last layer, whose residual output is never
+    //          consumed, has no such launch; the skip convs run as one K = NL * 256 GEMM after the layer loop).
+    //          `first` / `skip` are unused since then.
     int epi, res_rows, first, L, LP;
     const float* hin;
     float* hout;

@@ -34,6 +34,13 @@ __device__ __attribute__((aligned(128))) float g_zero_page_x3[32];             /
         __builtin_amdgcn_s_barrier();                                               \
         asm volatile("" ::: "memory");                                              \
     } while (0)
+
+// LDS-DMA in its saddr form (as in wn_layer.hip): wave-uniform 64-bit base in an SGPR pair, 32-bit lane offset, wave-uniform LDS
+// byte address in M0 (the hardware adds lane * 16).  hipcc does not count these loads: every wait on them is an explicit
+// counted s_waitcnt (GF_WAIT_BARRIER).
+__device__ __forceinline__ void x3_dma16(const void* sbase, unsigned voff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
 }  // namespace
 
 template <int BM, bool TWO>               // TWO: the input channels come from two maps (GemmF32Args::X2); an instantiation of its own
@@ -184,43 +191,35 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
         }
         return;
     }
-    if (BM == 128 && a.epi == 2) {          // h' = (h + res) * sqrt(1/2) + emb_next ; skip (+)= skip conv
+    if (BM == 128 && a.epi == 2) {          // h' = (h + res) * sqrt(1/2) + emb_next (M = 256 res-conv rows)
         long hrow[4];                       // stream row of position n, once per accumulator column (N < 2^31 positions)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const unsigned n32 = (unsigned)(n0 + wn * 64 + j * 16 + r16), bb = n32 / (unsigned)a.L;
+            unsigned n32 = (unsigned)(n0 + wn * 64 + j * 16 + r16);
+            if ((long)n32 >= a.N) n32 = (unsigned)(a.N - 1);                 // (never stored)
+            const unsigned bb = n32 / (unsigned)a.L;
             hrow[j] = ((long)bb * a.LP + kPad + (n32 - bb * (unsigned)a.L)) * kC;
         }
+        // all residual rows first, then the stores: hin / hout are distinct buffers, which the compiler cannot know — left to it,
+        // every load waits (vmcnt(0)) behind the previous tile's store and the epilogue becomes 16 serial HBM round trips
+        float4 hv[MT][4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hv[i][j] = *(const float4*)(a.hin + hrow[j] + m0 + wm * 64 + i * 16 + q * 4);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int m = m0 + wm * 64 + i * 16 + q * 4;
-            const float4 b4 = *(const float4*)(a.shift + m);
-            const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
-            const bool is_res = m < a.res_rows;
-            float ea[4] = {0.f, 0.f, 0.f, 0.f};
-            if (is_res) { const float4 e4 = *(const float4*)(a.emb_next + m); ea[0] = e4.x; ea[1] = e4.y; ea[2] = e4.z; ea[3] = e4.w; }
+            const float4 b4 = *(const float4*)(a.shift + m), e4 = *(const float4*)(a.emb_next + m);
+            const float ba[4] = {b4.x, b4.y, b4.z, b4.w}, ea[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const long n = n0 + wn * 64 + j * 16 + r16;
                 if (n >= a.N) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + ba[r];
-                if (is_res) {
-                    const long hoff = hrow[j] + m;
-                    const float4 h = *(const float4*)(a.hin + hoff);
-                    const float k = 0.70710678118654752440f;
-                    *(float4*)(a.hout + hoff) = float4{__fadd_rn(__fmul_rn(__fadd_rn(h.x, v[0]), k), ea[0]), __fadd_rn(__fmul_rn(__fadd_rn(h.y, v[1]), k), ea[1]),
-                                                       __fadd_rn(__fmul_rn(__fadd_rn(h.z, v[2]), k), ea[2]), __fadd_rn(__fmul_rn(__fadd_rn(h.w, v[3]), k), ea[3])};
-                } else {
-                    float4* ps = (float4*)(a.skip + n * 256 + (m - a.res_rows));
-                    if (a.first) {
-                        *ps = float4{v[0], v[1], v[2], v[3]};
-                    } else {
-                        const float4 o = *ps;
-                        *ps = float4{__fadd_rn(o.x, v[0]), __fadd_rn(o.y, v[1]), __fadd_rn(o.z, v[2]), __fadd_rn(o.w, v[3])};
-                    }
-                }
+                const float4 h = hv[i][j];
+                const float k = 0.70710678118654752440f;
+                *(float4*)(a.hout + hrow[j] + m) = float4{__fadd_rn(__fmul_rn(__fadd_rn(h.x, acc[i][j][0] + ba[0]), k), ea[0]), __fadd_rn(__fmul_rn(__fadd_rn(h.y, acc[i][j][1] + ba[1]), k), ea[1]),
+                                                          __fadd_rn(__fmul_rn(__fadd_rn(h.z, acc[i][j][2] + ba[2]), k), ea[2]), __fadd_rn(__fmul_rn(__fadd_rn(h.w, acc[i][j][3] + ba[3]), k), ea[3])};
             }
         }
         return;
@@ -281,39 +280,43 @@ constexpr int X3_BM = 256, X3_PAIR = 384 * 128, X3_LDS = 3 * X3_PAIR;
 // (row, q) reads chunks q and q + 4: 8 hi and 8 lo halves = one K = 32 fragment of each part, as before.
 template <bool DIAG>
 __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
-    constexpr int BM = X3_BM, MT = 4;
+    constexpr int MT = 4;
     const bool drop_alo = DIAG && (a.diag & 1), drop_blo = DIAG && (a.diag & 2), hi_only = DIAG && (a.diag & 4);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1, q = lane >> 4, r16 = lane & 15;
     const long n0 = (long)blockIdx.x * BN;
-    const int m0 = blockIdx.y * BM;
+    const int m0 = blockIdx.y * X3_BM;
     const int pairs_per_tap = a.K / 32, npairs = a.taps * pairs_per_tap;
     // staging: six 64-row pieces of 8 KiB per pair (A rows 0-255, X rows 0-127); this thread's row of a piece: wave * 8 + lane / 8,
-    // its LDS slot lane & 7 holds chunk (lane & 7) ^ ((row >> 1) & 7) of that row (4 values = one split-format chunk)
+    // its LDS slot lane & 7 holds chunk (lane & 7) ^ ((row >> 1) & 7) of that row (4 values = one split-format chunk).
+    // Source address = wave-uniform base (SGPR pair: operand + tap + k offset + piece) + one 32-bit lane offset per operand row.
     const int rloc = wv * 8 + (lane >> 3), chunk4 = ((lane & 7) ^ ((rloc >> 1) & 7)) * 4;
-    const float* zero = g_zero_page_x3 + (lane & 7) * 4;
-    const float* arow[4];
+    const char* Ab = (const char*)(a.A + (size_t)m0 * a.K);                       // M is a multiple of 256 (launcher)
+    const unsigned voffA = (unsigned)((rloc * a.K + chunk4) * 4);
+    const size_t a_piece = (size_t)64 * a.K * 4, a_tap = (size_t)a.M * a.K * 4;
+    auto rowoff = [&](long n) { const long xb = n / a.rows_per_batch; return xb * a.batch_stride + (n - xb * a.rows_per_batch) * a.row_stride; };
+    const long off0 = rowoff(n0);
+    const char* Xb = (const char*)(a.X + off0 - (long)(a.taps >> 1) * a.tap_stride);          // row n0 of tap 0
+    unsigned voffX[2];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) arow[p] = a.A + (size_t)(m0 + p * 64 + rloc) * a.K + chunk4;       // M is a multiple of 256 (launcher)
-    const float* xrow[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const long n = n0 + p * 64 + rloc;
-        xrow[p] = nullptr;
-        if (n < a.N) {
-            const long xb = n / a.rows_per_batch;
-            xrow[p] = a.X + xb * a.batch_stride + (n - xb * a.rows_per_batch) * a.row_stride + chunk4;
-        }
+    for (int p = 0; p < 2; ++p) {            // columns past N read row N-1 (valid memory; their results are never stored)
+        long n = n0 + p * 64 + rloc;
+        if (n >= a.N) n = a.N - 1;
+        voffX[p] = (unsigned)((rowoff(n) - off0 + chunk4) * 4);
     }
-    auto stage = [&](int pr, char* base) {          // base: this pair's 48 KiB (A rows 0-255: 32 KiB, X rows 0-127: 16 KiB)
-        const int tap = pr / pairs_per_tap, kc = (pr - tap * pairs_per_tap) * 32;
-        char* la = base + wv * 1024;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) glds16(arow[p] + (size_t)tap * a.M * a.K + kc, la + p * 8192);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) glds16(xrow[p] ? xrow[p] + (long)(tap - (a.taps >> 1)) * a.tap_stride + kc : zero, la + 32768 + p * 8192);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    int st_tap = 0, st_kq = 0;               // staging cursor: the next pair to stage is (tap st_tap, k-pair st_kq)
+    const char *st_a = Ab, *st_x = Xb;
+    auto st_advance = [&]() {
+        if (++st_kq == pairs_per_tap) { st_kq = 0; ++st_tap; }
+        st_a = Ab + (size_t)st_tap * a_tap + (size_t)st_kq * 128;
+        st_x = Xb + ((long)st_tap * a.tap_stride + (long)st_kq * 32) * 4;
+    };
+    auto piece = [&](int k, unsigned slot_lds) {          // one of the six 8 KiB DMA pieces of the cursor's pair
+        if (k < 4) x3_dma16(st_a + (size_t)k * a_piece, voffA, slot_lds + k * 8192 + wv * 1024);
+        else x3_dma16(st_x, voffX[k - 4], slot_lds + 32768 + (k - 4) * 8192 + wv * 1024);
     };
     f32x4 acc[MT][4], cor[MT][4];
 #pragma unroll
@@ -322,36 +325,110 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
         for (int j = 0; j < 4; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; cor[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const int sw = (r16 >> 1) & 7;
     const int f0 = r16 * 128 + ((q ^ sw) * 16), f1 = r16 * 128 + (((4 + q) ^ sw) * 16);
-    stage(0, smem);
-    if (npairs > 1) stage(1, smem + X3_PAIR);
+    const int aoff = wm * 8192, boff = 32768 + wn * 8192;
+
+    // Fragment registers: operand halves A0 / A1 (accumulator rows i = 0,1 / 2,3) and B0 / B1 (columns j = 0,1 / 2,3), each two
+    // 16-row tiles x (hi, lo) = 16 registers.  A tile's two chunks c0 = [hi0-3 | lo0-3], c1 = [hi4-7 | lo4-7] are read straight
+    // into (H, L) and turned into H = 8 hi, L = 8 lo by exchanging two registers (`fix`), one phase after the read.
+    u32x4_t AH[2][2], AL[2][2], BH[2][2], BL[2][2];
+#ifdef X3_NO_LDS
+    auto ld = [&](u32x4_t& H, u32x4_t& L, const char* tile) { asm volatile("" : "+v"(H), "+v"(L)); };
+#else
+    auto ld = [&](u32x4_t& H, u32x4_t& L, const char* tile) { H = *(const u32x4_t*)(tile + f0); L = *(const u32x4_t*)(tile + f1); };
+#endif
+    auto fix = [&](u32x4_t& H, u32x4_t& L) { const unsigned x = H[2], y = H[3]; H[2] = L[0]; H[3] = L[1]; L[0] = x; L[1] = y; };
+    auto hv = [](const u32x4_t& v) { return __builtin_bit_cast(f16x8, v); };
+#define X3_MFMA(k, ah, bh)                                                                                                        \
+    do {                                                                                                                           \
+        constexpr int t_ = (k) & 1, u_ = ((k) >> 1) & 1, i_ = 2 * (ah) + t_, j_ = 2 * (bh) + u_;                                   \
+        if ((k) < 4) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv(AH[ah][t_]), hv(BH[bh][u_]), acc[i_][j_], 0, 0, 0);   \
+        else if ((k) < 8) { if (!drop_blo) cor[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv(AH[ah][t_]), hv(BL[bh][u_]), cor[i_][j_], 0, 0, 0); } \
+        else { if (!drop_alo) cor[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv(AL[ah][t_]), hv(BH[bh][u_]), cor[i_][j_], 0, 0, 0); }             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+    } while (0)
+    // One phase = the 12 MFMAs of quadrant (A half ah) x (B half bh): 4 x hi*hi, 4 x hi*lo, 4 x lo*hi (the two products that share a
+    // `cor` accumulator are four issues apart).  Before them the half read during the previous phase is fixed (FIXH, FIXT: which
+    // operand / half); between them the four fragment reads of the half that is free (LDH: 0 = A, 1 = B; LDT: half; from `lbase`)
+    // and, in the second half of an iteration, three of the six DMA pieces of the pair three ahead.
+#define X3_PHASE(ah, bh, FIXB, FIXT, LDB, LDT, lbase, DMA0, dma_slot)                                                             \
+    do {                                                                                                                           \
+        if (FIXB) { fix(BH[FIXT][0], BL[FIXT][0]); fix(BH[FIXT][1], BL[FIXT][1]); }                                               \
+        else { fix(AH[FIXT][0], AL[FIXT][0]); fix(AH[FIXT][1], AL[FIXT][1]); }                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        if (LDB) ld(BH[LDT][0], BL[LDT][0], (lbase) + boff + (LDT) * 4096); else ld(AH[LDT][0], AL[LDT][0], (lbase) + aoff + (LDT) * 4096); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        X3_MFMA(0, ah, bh); X3_MFMA(1, ah, bh);                                                                                    \
+        if (LDB) ld(BH[LDT][1], BL[LDT][1], (lbase) + boff + (LDT) * 4096 + 2048); else ld(AH[LDT][1], AL[LDT][1], (lbase) + aoff + (LDT) * 4096 + 2048); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        X3_MFMA(2, ah, bh); X3_MFMA(3, ah, bh);                                                                                    \
+        if ((DMA0) >= 0 && do_dma) { piece((DMA0), (dma_slot)); __builtin_amdgcn_sched_barrier(0); }                               \
+        X3_MFMA(4, ah, bh); X3_MFMA(5, ah, bh); X3_MFMA(6, ah, bh);                                                                \
+        if ((DMA0) >= 0 && do_dma) { piece((DMA0) + 1, (dma_slot)); __builtin_amdgcn_sched_barrier(0); }                           \
+        X3_MFMA(7, ah, bh); X3_MFMA(8, ah, bh); X3_MFMA(9, ah, bh);                                                                \
+        if ((DMA0) >= 0 && do_dma) { piece((DMA0) + 2, (dma_slot)); __builtin_amdgcn_sched_barrier(0); }                           \
+        X3_MFMA(10, ah, bh); X3_MFMA(11, ah, bh);                                                                                  \
+    } while (0)
+
+    // prologue: pairs 0-2 in flight, pair 0 landed, A0 / B0 of pair 0 in registers
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+        if (s < npairs) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) piece(k, lds0 + s * X3_PAIR);
+            st_advance();
+        }
+    if (npairs >= 3) { GF_WAIT_BARRIER(12); } else if (npairs == 2) { GF_WAIT_BARRIER(6); } else { GF_WAIT_BARRIER(0); }
+    ld(AH[0][0], AL[0][0], smem + aoff); ld(AH[0][1], AL[0][1], smem + aoff + 2048);
+    ld(BH[0][0], BL[0][0], smem + boff); ld(BH[0][1], BL[0][1], smem + boff + 2048);
+    fix(AH[0][0], AL[0][0]); fix(AH[0][1], AL[0][1]);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // Pair p computes in four phases; its fragments are read from ring slot p % 3 during phases 3, 4 of pair p-1 and phases 1, 2 of
+    // pair p.  The ONE barrier of a pair sits between phases 2 and 3: behind it pair p+1 has landed (counted vmcnt: only the six
+    // pieces of pair p+2 may still fly), every wave has its last fragments of slot p % 3 in registers, and the six pieces of pair
+    // p+3 go into that slot under the MFMAs of phases 3, 4.  Even and odd pairs walk the quadrants in mirrored order, so that
+    // every phase replaces exactly one operand half — the one no later phase of the pair reads:
+    //   even: (A0,B0) (A0,B1) | (A1,B1) (A1,B0)      odd: (A0,B1) (A0,B0) | (A1,B0) (A1,B1)
     int slot = 0;
-    for (int p = 0; p < npairs; ++p) {
-        // pair p landed (the 6 pieces of pair p+1 may still fly); every wave is done reading pair p-1
-        if (p + 1 < npairs) { GF_WAIT_BARRIER(6); } else { GF_WAIT_BARRIER(0); }
-        if (p + 2 < npairs) stage(p + 2, smem + (slot == 0 ? 2 : slot - 1) * X3_PAIR);      // into the slot pair p-1 occupied
-        const char* A0 = smem + slot * X3_PAIR + wm * 8192;
-        const char* B0 = smem + slot * X3_PAIR + 32768 + wn * 8192;
-        f16x8 ahi[MT], alo[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const u32x4_t c0 = *(const u32x4_t*)(A0 + i * 2048 + f0), c1 = *(const u32x4_t*)(A0 + i * 2048 + f1);
-            ahi[i] = __builtin_bit_cast(f16x8, u32x4_t{c0[0], c0[1], c1[0], c1[1]});
-            alo[i] = __builtin_bit_cast(f16x8, u32x4_t{c0[2], c0[3], c1[2], c1[3]});
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u32x4_t c0 = *(const u32x4_t*)(B0 + j * 2048 + f0), c1 = *(const u32x4_t*)(B0 + j * 2048 + f1);
-            const f16x8 bhi = __builtin_bit_cast(f16x8, u32x4_t{c0[0], c0[1], c1[0], c1[1]});
-            const f16x8 blo = __builtin_bit_cast(f16x8, u32x4_t{c0[2], c0[3], c1[2], c1[3]});
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], bhi, acc[i][j], 0, 0, 0);
-                if (!drop_blo) cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], blo, cor[i][j], 0, 0, 0);
-                if (!drop_alo) cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[i], bhi, cor[i][j], 0, 0, 0);
-            }
-        }
-        slot = slot == 2 ? 0 : slot + 1;
+    for (int p = 0; p < npairs; p += 2) {
+        const int s1 = slot == 2 ? 0 : slot + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+        const char* L0 = smem + slot * X3_PAIR;
+        const char* L1 = smem + s1 * X3_PAIR;
+        const char* L2 = smem + s2 * X3_PAIR;
+        bool do_dma = false;
+        // ---- even pair p (slot `slot`)
+        X3_PHASE(0, 0, 1, 0, 1, 1, L0, -1, 0u);                  // fix B0;  (A0,B0);  read B1(p)
+        X3_PHASE(0, 1, 1, 1, 0, 1, L0, -1, 0u);                  // fix B1;  (A0,B1);  read A1(p)
+#ifndef X3_NO_BARRIER
+        if (p + 2 < npairs) { GF_WAIT_BARRIER(6); } else { GF_WAIT_BARRIER(0); }
+#endif
+        do_dma = p + 3 < npairs;
+#ifdef X3_NO_DMA
+        do_dma = false;
+#endif
+        X3_PHASE(1, 1, 0, 1, 0, 0, L1, 0, lds0 + slot * X3_PAIR);    // fix A1;  (A1,B1);  read A0(p+1);  pieces 0-2 of pair p+3
+        X3_PHASE(1, 0, 0, 0, 1, 1, L1, 3, lds0 + slot * X3_PAIR);    // fix A0;  (A1,B0);  read B1(p+1);  pieces 3-5
+        if (do_dma) st_advance();
+        if (p + 1 >= npairs) break;
+        // ---- odd pair p+1 (slot s1)
+        do_dma = false;
+        X3_PHASE(0, 1, 1, 1, 1, 0, L1, -1, 0u);                  // fix B1;  (A0,B1);  read B0(p+1)
+        X3_PHASE(0, 0, 1, 0, 0, 1, L1, -1, 0u);                  // fix B0;  (A0,B0);  read A1(p+1)
+#ifndef X3_NO_BARRIER
+        if (p + 3 < npairs) { GF_WAIT_BARRIER(6); } else { GF_WAIT_BARRIER(0); }
+#endif
+        do_dma = p + 4 < npairs;
+#ifdef X3_NO_DMA
+        do_dma = false;
+#endif
+        X3_PHASE(1, 0, 0, 1, 0, 0, L2, 0, lds0 + s1 * X3_PAIR);      // fix A1;  (A1,B0);  read A0(p+2);  pieces 0-2 of pair p+4
+        X3_PHASE(1, 1, 0, 0, 1, 0, L2, 3, lds0 + s1 * X3_PAIR);      // fix A0;  (A1,B1);  read B0(p+2);  pieces 3-5
+        if (do_dma) st_advance();
+        slot = s2;
     }
+#undef X3_PHASE
+#undef X3_MFMA
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // the reads past the last pair (never used) are retired before the epilogue
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -388,48 +465,39 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
         }
         return;
     }
-    if (a.epi == 2) {                        // h' (split-f16, operand of the next layer) ; skip sum (fp32)
+    if (a.epi == 2) {                        // h' = (h + res) * sqrt(1/2) + emb_next in the split format (operand of the next layer)
         // row of position n inside the zero-padded residual stream, once per accumulator column (not per tile: a 64-bit division
         // per (i, j) cost the K = 256 res launches a fifth of their time); N < 2^31 positions (launcher)
         long hrow[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const unsigned n32 = (unsigned)(n0 + wn * 64 + j * 16 + r16), bb = n32 / (unsigned)a.L;
+            unsigned n32 = (unsigned)(n0 + wn * 64 + j * 16 + r16);
+            if ((long)n32 >= a.N) n32 = (unsigned)(a.N - 1);                 // (never stored)
+            const unsigned bb = n32 / (unsigned)a.L;
             hrow[j] = ((long)bb * a.LP + kPad + (n32 - bb * (unsigned)a.L)) * kC;
         }
+        // all sixteen residual chunks first, then the stores (see the fp32 kernel: hin / hout may alias as far as the compiler knows)
+        u32x4_t hv[MT][4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hv[i][j] = *(const u32x4_t*)(a.hin + hrow[j] + m0 + wm * 64 + i * 16 + q * 4);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int m = m0 + wm * 64 + i * 16 + q * 4;
-            const float4 b4 = *(const float4*)(a.shift + m);
-            const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
-            const bool is_res = m < a.res_rows;
-            float ea[4] = {0.f, 0.f, 0.f, 0.f};
-            if (is_res) { const float4 e4 = *(const float4*)(a.emb_next + m); ea[0] = e4.x; ea[1] = e4.y; ea[2] = e4.z; ea[3] = e4.w; }
+            const float4 b4 = *(const float4*)(a.shift + m), e4 = *(const float4*)(a.emb_next + m);
+            const float ba[4] = {b4.x, b4.y, b4.z, b4.w}, ea[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const long n = n0 + wn * 64 + j * 16 + r16;
                 if (n >= a.N) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + ba[r];
-                if (is_res) {
-                    const long hoff = hrow[j] + m;
-                    float h[4];
-                    join4(*(const u32x4_t*)(a.hin + hoff), h);
-                    const float k = 0.70710678118654752440f;
-                    u32x4_t hs = split4(__fadd_rn(__fmul_rn(__fadd_rn(h[0], v[0]), k), ea[0]), __fadd_rn(__fmul_rn(__fadd_rn(h[1], v[1]), k), ea[1]),
-                                        __fadd_rn(__fmul_rn(__fadd_rn(h[2], v[2]), k), ea[2]), __fadd_rn(__fmul_rn(__fadd_rn(h[3], v[3]), k), ea[3]));
-                    if (hi_only) { hs[2] = 0u; hs[3] = 0u; }
-                    *(u32x4_t*)(a.hout + hoff) = hs;
-                } else {
-                    float4* ps = (float4*)(a.skip + n * 256 + (m - a.res_rows));
-                    if (a.first) {
-                        *ps = float4{v[0], v[1], v[2], v[3]};
-                    } else {
-                        const float4 o = *ps;
-                        *ps = float4{__fadd_rn(o.x, v[0]), __fadd_rn(o.y, v[1]), __fadd_rn(o.z, v[2]), __fadd_rn(o.w, v[3])};
-                    }
-                }
+                float h[4];
+                join4(hv[i][j], h);
+                const float k = 0.70710678118654752440f;
+                u32x4_t hs = split4(__fadd_rn(__fmul_rn(__fadd_rn(h[0], acc[i][j][0] + ba[0]), k), ea[0]), __fadd_rn(__fmul_rn(__fadd_rn(h[1], acc[i][j][1] + ba[1]), k), ea[1]),
+                                    __fadd_rn(__fmul_rn(__fadd_rn(h[2], acc[i][j][2] + ba[2]), k), ea[2]), __fadd_rn(__fmul_rn(__fadd_rn(h[3], acc[i][j][3] + ba[3]), k), ea[3]));
+                if (hi_only) { hs[2] = 0u; hs[3] = 0u; }
+                *(u32x4_t*)(a.hout + hrow[j] + m) = hs;
             }
         }
         return;
@@ -477,7 +545,8 @@ int gemm_x3_configure() {
 
 int launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab_floats, long n_ref) {
     GemmF32Args a = a0;
-    if (a.epi == 2 && (a.N >= (1l << 31) || a.L < 1)) { ++g_bad_shapes; return kGemmBadShape; }       // the update epilogue indexes positions in 32 bits
+    // the update epilogue indexes positions in 32 bits and serves M = 256 residual rows (the skip convs are one GEMM of their own)
+    if (a.epi == 2 && (a.N >= (1l << 31) || a.L < 1 || a.M != 256 || a.res_rows != a.M || !a.hin || !a.hout || !a.emb_next)) { ++g_bad_shapes; return kGemmBadShape; }
     if (a.x3) {                                   // split-f16 operands: WaveNet shapes only (checked here, not in the kernel)
         if (a.mode != 0 || (a.M % X3_BM) || (a.K % 32) || a.scale || a.res || a.groups > 1 || (a.ldc & 3)) { ++g_bad_shapes; return kGemmBadShape; }
         a.splits = 1; a.slab = nullptr;
