@@ -25,7 +25,7 @@ namespace {
 constexpr int BN = 128, BK = 16;          // BM = 128, or 64 for layers / conv groups with at most 64 output channels
 constexpr int SLOT = 16384;                       // 128 A rows + 128 X rows of 64 B
 __device__ __attribute__((aligned(64))) float g_zero_page[16];                 // 64 B of zeros: source of every out-of-problem row
-__device__ __attribute__((aligned(128))) float g_zero_page_x3[32];             // 128 B of zeros: the split-f16 kernel stages 128-byte rows
+
 
 #define GF_WAIT_BARRIER(N)                                                          \
     do {                                                                            \
@@ -286,8 +286,13 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1, q = lane >> 4, r16 = lane & 15;
-    const long n0 = (long)blockIdx.x * BN;
-    const int m0 = blockIdx.y * X3_BM;
+    // Workgroup -> tile: workgroups go round-robin over the 8 XCDs (id % 8), each with its own L2.  The M / 256 row blocks of one
+    // column tile are consecutive on ONE XCD, so the second block's X rows (the same rows) are L2 hits instead of a second HBM read.
+    const unsigned ny = (unsigned)(a.M / X3_BM), jx = blockIdx.x >> 3;
+    const unsigned tile_x = (jx / ny) * 8u + (blockIdx.x & 7u);
+    if ((long)tile_x * BN >= a.N) return;                    // the grid is padded to 8 * ny * ceil(nx / 8)
+    const long n0 = (long)tile_x * BN;
+    const int m0 = (int)(jx % ny) * X3_BM;
     const int pairs_per_tap = a.K / 32, npairs = a.taps * pairs_per_tap;
     // staging: six 64-row pieces of 8 KiB per pair (A rows 0-255, X rows 0-127); this thread's row of a piece: wave * 8 + lane / 8,
     // its LDS slot lane & 7 holds chunk (lane & 7) ^ ((row >> 1) & 7) of that row (4 values = one split-format chunk).
@@ -307,6 +312,8 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
         voffX[p] = (unsigned)((rowoff(n) - off0 + chunk4) * 4);
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    bool x3_steady = false;            // (ablation builds X3_ONLY_A / X3_ONLY_X: the prologue always stages both operands)
+    (void)x3_steady;
     int st_tap = 0, st_kq = 0;               // staging cursor: the next pair to stage is (tap st_tap, k-pair st_kq)
     const char *st_a = Ab, *st_x = Xb;
     auto st_advance = [&]() {
@@ -315,6 +322,12 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
         st_x = Xb + ((long)st_tap * a.tap_stride + (long)st_kq * 32) * 4;
     };
     auto piece = [&](int k, unsigned slot_lds) {          // one of the six 8 KiB DMA pieces of the cursor's pair
+#ifdef X3_ONLY_A
+        if (k >= 4 && x3_steady) return;
+#endif
+#ifdef X3_ONLY_X
+        if (k < 4 && x3_steady) return;
+#endif
         if (k < 4) x3_dma16(st_a + (size_t)k * a_piece, voffA, slot_lds + k * 8192 + wv * 1024);
         else x3_dma16(st_x, voffX[k - 4], slot_lds + 32768 + (k - 4) * 8192 + wv * 1024);
     };
@@ -336,7 +349,11 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
 #else
     auto ld = [&](u32x4_t& H, u32x4_t& L, const char* tile) { H = *(const u32x4_t*)(tile + f0); L = *(const u32x4_t*)(tile + f1); };
 #endif
+#ifdef X3_NO_FIX
+    auto fix = [&](u32x4_t& H, u32x4_t& L) {};
+#else
     auto fix = [&](u32x4_t& H, u32x4_t& L) { const unsigned x = H[2], y = H[3]; H[2] = L[0]; H[3] = L[1]; L[0] = x; L[1] = y; };
+#endif
     auto hv = [](const u32x4_t& v) { return __builtin_bit_cast(f16x8, v); };
 #define X3_MFMA(k, ah, bh)                                                                                                        \
     do {                                                                                                                           \
@@ -389,6 +406,13 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
     // p+3 go into that slot under the MFMAs of phases 3, 4.  Even and odd pairs walk the quadrants in mirrored order, so that
     // every phase replaces exactly one operand half — the one no later phase of the pair reads:
     //   even: (A0,B0) (A0,B1) | (A1,B1) (A1,B0)      odd: (A0,B1) (A0,B0) | (A1,B0) (A1,B1)
+#ifdef X3_STAMPS
+    unsigned long long x3_t[4] = {0, 0, 0, 0}, x3_prev = __builtin_amdgcn_s_memtime();
+#define X3_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); x3_t[k] += now_ - x3_prev; x3_prev = now_; } while (0)
+#else
+#define X3_STAMP(k) do {} while (0)
+#endif
+    x3_steady = true;
     int slot = 0;
     for (int p = 0; p < npairs; p += 2) {
         const int s1 = slot == 2 ? 0 : slot + 1, s2 = s1 == 2 ? 0 : s1 + 1;
@@ -396,12 +420,17 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
         const char* L1 = smem + s1 * X3_PAIR;
         const char* L2 = smem + s2 * X3_PAIR;
         bool do_dma = false;
+        X3_STAMP(0);
         // ---- even pair p (slot `slot`)
         X3_PHASE(0, 0, 1, 0, 1, 1, L0, -1, 0u);                  // fix B0;  (A0,B0);  read B1(p)
         X3_PHASE(0, 1, 1, 1, 0, 1, L0, -1, 0u);                  // fix B1;  (A0,B1);  read A1(p)
-#ifndef X3_NO_BARRIER
+        X3_STAMP(1);
+#ifdef X3_NO_VMWAIT
+        __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier();
+#elif !defined(X3_NO_BARRIER)
         if (p + 2 < npairs) { GF_WAIT_BARRIER(6); } else { GF_WAIT_BARRIER(0); }
 #endif
+        X3_STAMP(2);
         do_dma = p + 3 < npairs;
 #ifdef X3_NO_DMA
         do_dma = false;
@@ -409,14 +438,19 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
         X3_PHASE(1, 1, 0, 1, 0, 0, L1, 0, lds0 + slot * X3_PAIR);    // fix A1;  (A1,B1);  read A0(p+1);  pieces 0-2 of pair p+3
         X3_PHASE(1, 0, 0, 0, 1, 1, L1, 3, lds0 + slot * X3_PAIR);    // fix A0;  (A1,B0);  read B1(p+1);  pieces 3-5
         if (do_dma) st_advance();
+        X3_STAMP(3);
         if (p + 1 >= npairs) break;
         // ---- odd pair p+1 (slot s1)
         do_dma = false;
         X3_PHASE(0, 1, 1, 1, 1, 0, L1, -1, 0u);                  // fix B1;  (A0,B1);  read B0(p+1)
         X3_PHASE(0, 0, 1, 0, 0, 1, L1, -1, 0u);                  // fix B0;  (A0,B0);  read A1(p+1)
-#ifndef X3_NO_BARRIER
+        X3_STAMP(1);
+#ifdef X3_NO_VMWAIT
+        __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier();
+#elif !defined(X3_NO_BARRIER)
         if (p + 3 < npairs) { GF_WAIT_BARRIER(6); } else { GF_WAIT_BARRIER(0); }
 #endif
+        X3_STAMP(2);
         do_dma = p + 4 < npairs;
 #ifdef X3_NO_DMA
         do_dma = false;
@@ -424,8 +458,15 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
         X3_PHASE(1, 0, 0, 1, 0, 0, L2, 0, lds0 + s1 * X3_PAIR);      // fix A1;  (A1,B0);  read A0(p+2);  pieces 0-2 of pair p+4
         X3_PHASE(1, 1, 0, 0, 1, 0, L2, 3, lds0 + s1 * X3_PAIR);      // fix A0;  (A1,B1);  read B0(p+2);  pieces 3-5
         if (do_dma) st_advance();
+        X3_STAMP(3);
         slot = s2;
     }
+#ifdef X3_STAMPS
+    if (npairs == 288 && (blockIdx.x == 100 || blockIdx.x == 1501) && lane == 0 && (wv == 0 || wv == 4 || wv == 3))
+        printf("x3 stamps block %d wave %d: loop-top %llu  ph1+2 %llu  barrier %llu  ph3+4 %llu cycles per pair\n", (int)blockIdx.x, wv,
+               x3_t[0] / 288, x3_t[1] / 288, x3_t[2] / 288, x3_t[3] / 288);
+#endif
+#undef X3_STAMP
 #undef X3_PHASE
 #undef X3_MFMA
     __builtin_amdgcn_s_waitcnt(0xC07F);          // the reads past the last pair (never used) are retired before the epilogue
@@ -550,7 +591,9 @@ int launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab
     if (a.x3) {                                   // split-f16 operands: WaveNet shapes only (checked here, not in the kernel)
         if (a.mode != 0 || (a.M % X3_BM) || (a.K % 32) || a.scale || a.res || a.groups > 1 || (a.ldc & 3)) { ++g_bad_shapes; return kGemmBadShape; }
         a.splits = 1; a.slab = nullptr;
-        const dim3 grid((unsigned)((a.N + BN - 1) / BN), (unsigned)(a.M / X3_BM));
+        const long nx = (a.N + BN - 1) / BN;
+        if (((nx + 7) / 8) * 8 * (a.M / X3_BM) > 0x7fffffffl) { ++g_bad_shapes; return kGemmBadShape; }
+        const dim3 grid((unsigned)(((nx + 7) / 8) * 8 * (a.M / X3_BM)));
         if (a.diag) hipLaunchKernelGGL(gemm_x3_kernel<true>, grid, dim3(512), X3_LDS, s, a);
         else hipLaunchKernelGGL(gemm_x3_kernel<false>, grid, dim3(512), X3_LDS, s, a);
         return 0;
