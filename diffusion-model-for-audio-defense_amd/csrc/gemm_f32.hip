@@ -224,7 +224,17 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
         }
         return;
     }
+    // scale / shift, then per row tile the optional residual with its four loads ahead of the tile's stores (hipcc cannot know that
+    // `res` and `C` do not overlap and would serialise load -> wait -> store per accumulator tile), ReLU, stores
     const bool vec = ((a.ldc & 3) == 0);
+    long nrow[4];
+    bool nok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long n = n0 + wn * 64 + j * 16 + r16;
+        nok[j] = n < a.N;
+        nrow[j] = (nok[j] ? n : a.N - 1) * a.ldc;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = m0 + wm * (BM / 2) + i * 16 + q * 4;
@@ -235,17 +245,37 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
             sh[r] = (a.shift && m + r < a.M) ? a.shift[m + r] : 0.f;
         }
 #pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = a.scale ? acc[i][j][r] * sc[r] + sh[r] : acc[i][j][r] + sh[r];
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + q * 4;
+        if (a.res) {                         // the four residual chunks of this row tile ahead of its stores
+            float rr[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (vec && m + 3 < a.M) {
+                    const float4 r4 = *(const float4*)(a.res + nrow[j] + m);
+                    rr[j][0] = r4.x; rr[j][1] = r4.y; rr[j][2] = r4.z; rr[j][3] = r4.w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rr[j][r] = m + r < a.M ? a.res[nrow[j] + m + r] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += rr[j][r];
+        }
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const long n = n0 + wn * 64 + j * 16 + r16;
-            if (n >= a.N) continue;
+            if (!nok[j]) continue;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = a.scale ? acc[i][j][r] * sc[r] + sh[r] : acc[i][j][r] + sh[r];
-                if (a.res && m + r < a.M) t += a.res[n * a.ldc + m + r];
-                v[r] = a.relu ? relu_nan(t) : t;
-            }
-            float* dst = a.C + n * a.ldc + m;
+            for (int r = 0; r < 4; ++r) v[r] = a.relu ? relu_nan(acc[i][j][r]) : acc[i][j][r];
+            float* dst = a.C + nrow[j] + m;
             if (vec && m + 3 < a.M) {
                 *(float4*)dst = float4{v[0], v[1], v[2], v[3]};
             } else {

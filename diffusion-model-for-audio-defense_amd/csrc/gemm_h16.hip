@@ -117,27 +117,43 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
         }
         slot = slot == 2 ? 0 : slot + 1;
     }
-    // epilogue: bias, optional residual; fp32 map and / or its f16 twin
+    // epilogue: bias, optional residual; fp32 map and / or its f16 twin.  All loads come first: hipcc cannot know that `res` and
+    // the outputs do not overlap and would otherwise wait (vmcnt(0)) for every tile's store before it loads the next residual chunk —
+    // sixteen serial HBM round trips per workgroup.  (res == C, an in-place add, stays correct: a lane reads what it later writes.)
+    long nn[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long n = n0 + wn * 64 + j * 16 + r16;
+        ok[j] = n < a.N;
+        nn[j] = (ok[j] ? n : a.N - 1) * a.ldc + m0 + wm * 64 + q * 4;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + q * 4;
-        const float4 b4 = a.shift ? *(const float4*)(a.shift + m) : float4{0.f, 0.f, 0.f, 0.f};
-        const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+        const float4 b4 = a.shift ? *(const float4*)(a.shift + m0 + wm * 64 + i * 16 + q * 4) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w; }
+    }
+    if (a.res) {
+        float4 rr[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rr[i][j] = *(const float4*)(a.res + nn[j] + i * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[i][j][0] += rr[i][j].x; acc[i][j][1] += rr[i][j].y; acc[i][j][2] += rr[i][j].z; acc[i][j][3] += rr[i][j].w; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const long n = n0 + wn * 64 + j * 16 + r16;
-            if (n >= a.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + ba[r];
-            if (a.res) {
-                const float4 rr = *(const float4*)(a.res + n * a.ldc + m);
-                v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-            }
-            if (a.C) *(float4*)(a.C + n * a.ldc + m) = float4{v[0], v[1], v[2], v[3]};
-            if (a.C16) *(f16x4*)(a.C16 + n * a.ldc + m) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            if (!ok[j]) continue;
+            const f32x4 v = acc[i][j];
+            if (a.C) *(float4*)(a.C + nn[j] + i * 16) = float4{v[0], v[1], v[2], v[3]};
+            if (a.C16) *(f16x4*)(a.C16 + nn[j] + i * 16) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
         }
-    }
 }
 
 int gemm_h16_configure() {

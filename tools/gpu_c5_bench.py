@@ -10,6 +10,9 @@ import json, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'diffusion-model-for-audio-defense_amd')]
+from dmad_hip import _lib
+if os.environ.get('DMAD_LIB'):                   # A/B of two builds on one box
+    _lib.LIB_PATH = os.environ['DMAD_LIB']
 from dmad_hip import engine as E, synth
 from diffusion_models.improved_diffusion_ddpm import create_improved_diffusion
 N, TSTAR, B = int(os.environ.get('N', 10000)), int(os.environ.get('TSTAR', 25)), int(os.environ.get('B', 512))
