@@ -14,6 +14,7 @@
 // channels are a multiple of 128 only), 8 waves of 64 x 64, 3-slot LDS ring of 48 KiB (144 KiB, one workgroup per CU, two waves
 // per SIMD), two k-steps in flight while one is contracted, one barrier per k-step.
 #include "gemm_h16.h"
+#include <stdlib.h>
 
 namespace dmad {
 
@@ -156,6 +157,193 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
         }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile (layers with M % 256 == 0, one input map, enough pixels to fill the chip): wave tile 128 x 64 = 32 accumulator tiles,
+// 64 MFMAs per wave and k-step for 24 fragment reads and 8 DMA pieces (the 256 x 128 kernel above: 32 MFMAs for 16 + 6).  A k-step
+// (512 rows x 128 B = 64 KiB) lives in a 2-slot ring; what makes two slots enough is that fragments are prefetched into REGISTERS a
+// phase ahead, as in the split-f16 kernel (gemm_f32.hip): a k-step computes in four phases of 16 MFMAs,
+//     (A0,B)k0  (A1,B)k0  (A0,B)k1 | (A1,B)k1          A0 / A1: the wave's row tiles 0-3 / 4-7, k0 / k1: the two 32-wide k halves
+// each phase reading the A unit (4 x ds_read_b128) of the next phase — and every second one the next B unit — into the register set
+// the previous phase released (two A sets, two B sets: 64 fragment registers).  The slot of k-step s has been read completely after
+// phase 3; the ONE barrier sits there: behind it k-step s+1 has landed (vmcnt(0): nothing younger is in flight), phase 4 reads its
+// first units from the other slot, and the eight pieces of k-step s+2 go into the slot just freed under the MFMAs of phase 4.
+// Weight pieces go out in the saddr form (inline asm), the gathered pixel rows through the builtin (64-bit lane addresses, recomputed
+// once per tap); rows outside the image come from a zero page long enough to take the k offset.
+// ----------------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int BIG_SLOT = 512 * 128, BIG_LDS = 2 * BIG_SLOT, BIG_KMAX = 1024;
+__device__ __attribute__((aligned(128))) unsigned short g_zero_page_big[BIG_KMAX + 64];
+__device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void dma16v(const void* vaddr, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds) : "memory");
+}
+}  // namespace
+
+__global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 2, wn = wv & 3, q = lane >> 4, r16 = lane & 15;
+    // workgroup -> tile: the M / 256 row blocks of one pixel tile run back to back on one XCD (id % 8): their pixel rows are L2 hits
+    const unsigned ny = (unsigned)(a.M >> 8), jx = blockIdx.x >> 3;
+    const unsigned tile_x = (jx / ny) * 8u + (blockIdx.x & 7u);
+    if ((long)tile_x * 256 >= a.N) return;                    // the grid is padded to 8 * ny * ceil(nx / 8)
+    const long n0 = (long)tile_x * 256;
+    const int m0 = (int)(jx % ny) * 256;
+    const int steps_per_tap = a.K / HK, nsteps = a.taps * steps_per_tap;
+    const int rloc = wv * 8 + (lane >> 3), ch8 = ((lane & 7) ^ ((rloc >> 1) & 7)) * 8;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    // weights: uniform base + one lane offset; piece p adds 64 rows
+    const char* Ab = (const char*)(a.A + (size_t)m0 * a.K);
+    const unsigned voffA = (unsigned)((rloc * a.K + ch8) * 2);
+    const size_t a_piece = (size_t)64 * a.K * 2, a_tap = (size_t)a.M * a.K * 2;
+    // pixel rows: (image base pixel, y, x) per staged row of this lane, 4 pieces of 64 rows
+    const int st = a.stride > 1 ? a.stride : 1;
+    const int Wo = (a.W - 1) / st + 1, Ho = (a.H - 1) / st + 1, hw = Ho * Wo;
+    int xpix[4], xyx[4];                                     // image base pixel (or -1: row past N), (y << 16) | x
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const long n = n0 + p * 64 + rloc;
+        xpix[p] = -1; xyx[p] = 0;
+        if (n < a.N) {
+            const int b = (int)(n / hw), pix = (int)(n - (long)b * hw);
+            xpix[p] = b * a.H * a.W;
+            xyx[p] = (((pix / Wo) * st) << 16) | ((pix % Wo) * st);
+        }
+    }
+    const h16_t* xrow[4];                                     // this tap's source row (k offset 0) per piece, or the zero page
+    auto tap_rows = [&](int tap) {
+        const int dy = a.taps == 9 ? tap / 3 - 1 : 0, dx = a.taps == 9 ? tap % 3 - 1 : 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int yy = (xyx[p] >> 16) + dy, xq = (xyx[p] & 0xffff) + dx;
+            const bool ok = xpix[p] >= 0 && (unsigned)yy < (unsigned)a.H && (unsigned)xq < (unsigned)a.W;
+            xrow[p] = ok ? a.X + ((long)xpix[p] + yy * a.W + xq) * a.ldx + ch8 : g_zero_page_big + (lane & 7) * 8;
+        }
+    };
+    int st_tap = 0, st_kq = 0;                                // staging cursor
+    const char* st_a = Ab;
+    tap_rows(0);
+    auto st_advance = [&]() {
+        if (++st_kq == steps_per_tap) { st_kq = 0; ++st_tap; if (st_tap < a.taps) tap_rows(st_tap); }
+        st_a = Ab + (size_t)st_tap * a_tap + (size_t)st_kq * 128;
+    };
+    auto piece = [&](int k, unsigned slot_lds) {              // k 0-3: pixel rows, 4-7: weights
+        if (k < 4) dma16v(xrow[k] + st_kq * HK, slot_lds + 32768 + k * 8192 + wv * 1024);
+        else dma16s(st_a + (size_t)(k - 4) * a_piece, voffA, slot_lds + (k - 4) * 8192 + wv * 1024);
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int sw = (r16 >> 1) & 7;
+    const int fk[2] = {r16 * 128 + ((q ^ sw) * 16), r16 * 128 + (((4 + q) ^ sw) * 16)};
+    const int aoff = wm * 16384, boff = 32768 + wn * 8192;
+    f16x8 AX[4], AY[4], BP[4], BQ[4];
+    auto ldA = [&](f16x8 (&U)[4], const char* slot, int half, int kh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) U[i] = *(const f16x8*)(slot + aoff + half * 8192 + i * 2048 + fk[kh]);
+    };
+    auto ldB = [&](f16x8 (&U)[4], const char* slot, int kh) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) U[j] = *(const f16x8*)(slot + boff + j * 2048 + fk[kh]);
+    };
+#define BIG_MFMA4(AU, BU, i0, ii)                                                                                    \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                             \
+            acc[(i0) + (ii)][j_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AU[ii], BU[j_], acc[(i0) + (ii)][j_], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+
+    // prologue: k-steps 0, 1 staged; k-step 0 landed; its first units in registers
+#pragma unroll
+    for (int k = 0; k < 8; ++k) piece(k, lds0);
+    st_advance();
+    if (nsteps > 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) piece(k, lds0 + BIG_SLOT);
+        st_advance();
+        GH_WAIT_BARRIER(8);
+    } else {
+        GH_WAIT_BARRIER(0);
+    }
+    ldA(AX, smem, 0, 0);
+    ldB(BP, smem, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < nsteps; ++s) {
+        const char* cur = smem + (s & 1) * BIG_SLOT;
+        const char* nxt = smem + ((s & 1) ^ 1) * BIG_SLOT;
+        const unsigned cur_lds = lds0 + (s & 1) * BIG_SLOT;
+        // phase 1: (A0, B) k0; read A1 k0
+        ldA(AY, cur, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        BIG_MFMA4(AX, BP, 0, 0); BIG_MFMA4(AX, BP, 0, 1); BIG_MFMA4(AX, BP, 0, 2); BIG_MFMA4(AX, BP, 0, 3);
+        // phase 2: (A1, B) k0; read A0 k1, B k1
+        ldA(AX, cur, 0, 1);
+        ldB(BQ, cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        BIG_MFMA4(AY, BP, 4, 0); BIG_MFMA4(AY, BP, 4, 1); BIG_MFMA4(AY, BP, 4, 2); BIG_MFMA4(AY, BP, 4, 3);
+        // phase 3: (A0, B) k1; read A1 k1
+        ldA(AY, cur, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        BIG_MFMA4(AX, BQ, 0, 0); BIG_MFMA4(AX, BQ, 0, 1); BIG_MFMA4(AX, BQ, 0, 2); BIG_MFMA4(AX, BQ, 0, 3);
+        // k-step s+1 landed, every wave holds its last fragments of this slot
+        GH_WAIT_BARRIER(0);
+        // phase 4: (A1, B) k1; read A0 k0, B k0 of k-step s+1; stage k-step s+2 into this slot
+        ldA(AX, nxt, 0, 0);
+        ldB(BP, nxt, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef BIG_NO_DMA
+        const bool more = false;
+#else
+        const bool more = s + 2 < nsteps;
+#endif
+        if (more) { piece(0, cur_lds); piece(1, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        BIG_MFMA4(AY, BQ, 4, 0);
+        if (more) { piece(2, cur_lds); piece(3, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        BIG_MFMA4(AY, BQ, 4, 1);
+        if (more) { piece(4, cur_lds); piece(5, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        BIG_MFMA4(AY, BQ, 4, 2);
+        if (more) { piece(6, cur_lds); piece(7, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        BIG_MFMA4(AY, BQ, 4, 3);
+        if (more) st_advance();
+    }
+#undef BIG_MFMA4
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // the reads past the last k-step (never used) are retired
+    // epilogue: bias, optional residual (per row tile: its four loads ahead of its stores), fp32 map and / or f16 twin
+    long nn[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long n = n0 + wn * 64 + j * 16 + r16;
+        ok[j] = n < a.N;
+        nn[j] = (ok[j] ? n : a.N - 1) * a.ldc + m0 + wm * 128 + q * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4 b4 = a.shift ? *(const float4*)(a.shift + m0 + wm * 128 + i * 16 + q * 4) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w; }
+        if (a.res) {
+            float4 rr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rr[j] = *(const float4*)(a.res + nn[j] + i * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[i][j][0] += rr[j].x; acc[i][j][1] += rr[j].y; acc[i][j][2] += rr[j].z; acc[i][j][3] += rr[j].w; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!ok[j]) continue;
+            const f32x4 v = acc[i][j];
+            if (a.C) *(float4*)(a.C + nn[j] + i * 16) = float4{v[0], v[1], v[2], v[3]};
+            if (a.C16) *(f16x4*)(a.C16 + nn[j] + i * 16) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        }
+    }
+}
+
 int gemm_h16_configure() {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_h16_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS);
     if (e != hipSuccess) return (int)e;
@@ -163,7 +351,9 @@ int gemm_h16_configure() {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_h16_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS);
     if (e != hipSuccess) return (int)e;
-    return (int)hipFuncSetAttribute((const void*)gemm_h16_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS);
+    e = hipFuncSetAttribute((const void*)gemm_h16_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipFuncSetAttribute((const void*)gemm_h16_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
 }
 
 int gemm_h16_take_bad_shapes() { const int n = g_bad; g_bad = 0; return n; }
@@ -177,6 +367,14 @@ int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
     }
     // 256-row tiles where the output channels fill them; 128 x 256 otherwise (128-channel layers, 384 / 768-row qkv convs use
     // whichever divides M)
+    // the 256 x 256 tile where it fills the chip: >= 256 workgroups (DMAD_H16_BIG=0 switches it off: A/B runs)
+    static const bool big_on = []() { const char* v = getenv("DMAD_H16_BIG"); return !(v && v[0] == '0'); }();
+    if (big_on && !two && a.M % 256 == 0 && a.K <= BIG_KMAX && ((a.N + 255) / 256) * (a.M / 256) >= 256 && a.H < 32768 && a.W < 32768 &&
+        a.N * (long)a.ldx < (1l << 31)) {
+        const long nx = (a.N + 255) / 256;
+        hipLaunchKernelGGL(gemm_h16_big_kernel, dim3((unsigned)(((nx + 7) / 8) * 8 * (a.M / 256))), dim3(512), BIG_LDS, s, a);
+        return 0;
+    }
     if (a.M % 256 == 0) {
         const dim3 grid((unsigned)((a.N + 127) / 128), (unsigned)(a.M / 256));
         if (two) hipLaunchKernelGGL((gemm_h16_kernel<256, true>), grid, dim3(512), H16_LDS, s, a);

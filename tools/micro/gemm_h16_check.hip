@@ -91,6 +91,7 @@ static void timeit(int B, int H, int cin, int cout, int taps) {
 int main() {
     if (gemm_h16_configure()) { printf("configure failed\n"); return 2; }
     int bad = 0;
+    if (getenv("ONLY_TIME")) { timeit(512, 16, 256, 256, 9); timeit(512, 16, 256, 256, 9); timeit(512, 16, 512, 256, 9); timeit(512, 32, 128, 256, 9); return 0; }
     bad += check(2, 8, 64, 128, 9, 1, 0, false);
     bad += check(3, 8, 128, 256, 9, 1, 0, true);
     bad += check(2, 16, 128, 128, 9, 2, 0, false);
@@ -100,6 +101,11 @@ int main() {
     bad += check(3, 16, 256, 768, 1, 1, 0, false);
     bad += check(2, 8, 512, 256, 1, 1, 256, true);
     bad += check(1, 32, 128, 128, 9, 1, 0, true);
+    // the 256 x 256 tile (>= 256 workgroups): 3x3 with residual, N tail, stride 2, 1x1 with three row blocks
+    bad += check(256, 16, 256, 256, 9, 1, 0, true);
+    bad += check(257, 16, 256, 256, 9, 1, 0, true);
+    bad += check(256, 32, 128, 256, 9, 2, 0, false);
+    bad += check(128, 16, 256, 768, 1, 1, 0, false);
     printf(bad ? "FAILED %d case(s)\n" : "all cases ok\n", bad);
     timeit(512, 32, 128, 128, 9);
     timeit(512, 32, 384, 128, 9);
