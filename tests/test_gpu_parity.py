@@ -677,6 +677,28 @@ def test_unet_purifier_vs_reference_fixture(golden_dir):
     f32.close()
 
 
+@pytest.mark.gpu
+def test_unet_16bit_tier_large_batch_uses_the_256_tile_and_stays_batch_invariant():
+    """At 256 spectrograms the 256-channel 16x16 convs and the M = 768 qkv convs fill the chip with 256 x 256 tiles and go to
+    gemm_h16_big_kernel (csrc/gemm_h16.hip); smaller batches run the 384-row kernel.  Both accumulate every output in the same
+    order, so a sample's eps is the same bits in a batch of 256 and in a batch of 2 (batch invariance across the kernel switch),
+    and the tier stays within the f16 tolerance of the exact-fp32 tier at the large batch too."""
+    from dmad_hip import engine as E
+    from diffusion_models.improved_diffusion_ddpm import create_improved_diffusion
+    eng = E.Engine(max_batch=256, precision=E.EXACT, with_classifier=False, with_wavenet=False)
+    create_improved_diffusion(None, reverse_timestep=3, state_dict=synth.unet_state_dict(31), engine=eng)
+    x = torch.randn(256, 32, 32, generator=torch.Generator().manual_seed(5)).cuda()
+    eng.set_mode(E.MODE_FAST)
+    big = eng.unet_eps(x, 7)
+    assert bool(torch.isfinite(big).all())
+    for lo in (0, 77, 254):
+        assert torch.equal(eng.unet_eps(x[lo:lo + 2].contiguous(), 7), big[lo:lo + 2]), lo
+    eng.set_mode(E.MODE_FP32)
+    ref = eng.unet_eps(x[:64].contiguous(), 7)
+    assert 1e-5 < relmax(big[:64].cpu().numpy(), ref.cpu().numpy()) < F16_MAX_TOL
+    eng.close()
+
+
 # ------------------------------------------------------------------------------------------ BASELINE.json configs at full size
 @pytest.fixture(scope='module')
 def big_engine(weights):
