@@ -307,11 +307,14 @@ __global__ void __launch_bounds__(KT >= 8 ? 512 : 64 * KT) qkv_attention_h16_ker
         for (int kt = 0; kt < KT; ++kt) m = fmaxf(fmaxf(fmaxf(sacc[kt][0], sacc[kt][1]), fmaxf(sacc[kt][2], sacc[kt][3])), m);
         m = fmaxf(m, __shfl_xor(m, 16));
         m = fmaxf(m, __shfl_xor(m, 32));
+        // exp(s - m) as one FMA + one v_exp (1 ulp; the weights go to the second product as f16 anyway) instead of libm's expf: the
+        // 4 KT exponentials per lane and query tile were most of this kernel's vector instructions
+        const float m2 = m * 1.4426950408889634f;
         float l = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float p = expf(sacc[kt][r] - m); sacc[kt][r] = p; l += p; }
+            for (int r = 0; r < 4; ++r) { const float p = fast_exp2(__builtin_fmaf(sacc[kt][r], 1.4426950408889634f, -m2)); sacc[kt][r] = p; l += p; }
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
         f32x4 oacc[4];
