@@ -283,6 +283,7 @@ __global__ void __launch_bounds__(KT >= 8 ? 512 : 64 * KT) qkv_attention_h16_ker
     }
     __syncthreads();
     const int sw = (c >> 1) & 7;
+#pragma unroll 1
     for (int qt = wv; qt < KT; qt += NW) {
         // query row c of the tile: channels 8g .. 8g+7 and 32 + 8g .. , times scale^2 = 1/8 (exact in f16)
         f16x8 qf[2];
@@ -301,6 +302,8 @@ __global__ void __launch_bounds__(KT >= 8 ? 512 : 64 * KT) qkv_attention_h16_ker
                 const f16x8 kf = *(const f16x8*)(Ks + (kt * 16 + c) * 128 + (((4 * hh + g) ^ sw) * 16));
                 sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[hh], sacc[kt], 0, 0, 0);
             }
+            // hipcc otherwise hoists all 2 KT fragment reads above the first MFMA: 128 registers at KT = 16, 92 spilled
+            if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         float m = -INFINITY;
 #pragma unroll
@@ -339,6 +342,7 @@ __global__ void __launch_bounds__(KT >= 8 ? 512 : 64 * KT) qkv_attention_h16_ker
                 const f16x8 vf = __builtin_bit_cast(f16x8, u32x4_t{v0[0], v0[1], v1[0], v1[1]});
                 oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
             }
+            if (kp & 1) __builtin_amdgcn_sched_barrier(0);
         }
         const float inv = 1.f / l;
         const long ooff = ((long)b * T + qt * 16 + c) * (HD * heads) + h * HD + g * 4;
