@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
 // once per tap); rows outside the image come from a zero page long enough to take the k offset.
 // ----------------------------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int BIG_SLOT = 512 * 128, BIG_LDS = 2 * BIG_SLOT, BIG_KMAX = 1024;
+constexpr int BIG_LDS_256 = 2 * 512 * 128, BIG_LDS_128 = 2 * 640 * 128, BIG_KMAX = 1024;      // 128 KiB / 160 KiB (all of a CU's LDS)
 __device__ __attribute__((aligned(128))) unsigned short g_zero_page_big[BIG_KMAX + 64];
 __device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, unsigned lds) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
@@ -181,17 +181,19 @@ __device__ __forceinline__ void dma16v(const void* vaddr, unsigned lds) {
 }
 }  // namespace
 
+template <int BM>               // 256: 256 x 256 tile, waves 2 (M) x 4 (N); 128: 128 x 512 tile, waves 1 x 8 (the 128-channel layers)
 __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
+    constexpr int BN = BM == 256 ? 256 : 512, AP = BM / 64, XP = BN / 64, NP = AP + XP, SLOTB = (BM + BN) * 128, WN = BN / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wv >> 2, wn = wv & 3, q = lane >> 4, r16 = lane & 15;
+    const int wm = wv / WN, wn = wv % WN, q = lane >> 4, r16 = lane & 15;
     // workgroup -> tile: the M / 256 row blocks of one pixel tile run back to back on one XCD (id % 8): their pixel rows are L2 hits
-    const unsigned ny = (unsigned)(a.M >> 8), jx = blockIdx.x >> 3;
+    const unsigned ny = (unsigned)(a.M / BM), jx = blockIdx.x >> 3;
     const unsigned tile_x = (jx / ny) * 8u + (blockIdx.x & 7u);
-    if ((long)tile_x * 256 >= a.N) return;                    // the grid is padded to 8 * ny * ceil(nx / 8)
-    const long n0 = (long)tile_x * 256;
-    const int m0 = (int)(jx % ny) * 256;
+    if ((long)tile_x * BN >= a.N) return;                     // the grid is padded to 8 * ny * ceil(nx / 8)
+    const long n0 = (long)tile_x * BN;
+    const int m0 = (int)(jx % ny) * BM;
     const int steps_per_tap = a.K / HK, nsteps = a.taps * steps_per_tap;
     const int rloc = wv * 8 + (lane >> 3), ch8 = ((lane & 7) ^ ((rloc >> 1) & 7)) * 8;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
@@ -202,9 +204,9 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
     // pixel rows: (image base pixel, y, x) per staged row of this lane, 4 pieces of 64 rows
     const int st = a.stride > 1 ? a.stride : 1;
     const int Wo = (a.W - 1) / st + 1, Ho = (a.H - 1) / st + 1, hw = Ho * Wo;
-    int xpix[4], xyx[4];                                     // image base pixel (or -1: row past N), (y << 16) | x
+    int xpix[XP], xyx[XP];                                     // image base pixel (or -1: row past N), (y << 16) | x
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < XP; ++p) {
         const long n = n0 + p * 64 + rloc;
         xpix[p] = -1; xyx[p] = 0;
         if (n < a.N) {
@@ -213,11 +215,11 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
             xyx[p] = (((pix / Wo) * st) << 16) | ((pix % Wo) * st);
         }
     }
-    const h16_t* xrow[4];                                     // this tap's source row (k offset 0) per piece, or the zero page
+    const h16_t* xrow[XP];                                     // this tap's source row (k offset 0) per piece, or the zero page
     auto tap_rows = [&](int tap) {
         const int dy = a.taps == 9 ? tap / 3 - 1 : 0, dx = a.taps == 9 ? tap % 3 - 1 : 0;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < XP; ++p) {
             const int yy = (xyx[p] >> 16) + dy, xq = (xyx[p] & 0xffff) + dx;
             const bool ok = xpix[p] >= 0 && (unsigned)yy < (unsigned)a.H && (unsigned)xq < (unsigned)a.W;
             xrow[p] = ok ? a.X + ((long)xpix[p] + yy * a.W + xq) * a.ldx + ch8 : g_zero_page_big + (lane & 7) * 8;
@@ -230,9 +232,9 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
         if (++st_kq == steps_per_tap) { st_kq = 0; ++st_tap; if (st_tap < a.taps) tap_rows(st_tap); }
         st_a = Ab + (size_t)st_tap * a_tap + (size_t)st_kq * 128;
     };
-    auto piece = [&](int k, unsigned slot_lds) {              // k 0-3: pixel rows, 4-7: weights
-        if (k < 4) dma16v(xrow[k] + st_kq * HK, slot_lds + 32768 + k * 8192 + wv * 1024);
-        else dma16s(st_a + (size_t)(k - 4) * a_piece, voffA, slot_lds + (k - 4) * 8192 + wv * 1024);
+    auto piece = [&](int k, unsigned slot_lds) {              // k < XP: pixel rows, then the AP weight pieces
+        if (k < XP) dma16v(xrow[k] + st_kq * HK, slot_lds + BM * 128 + k * 8192 + wv * 1024);
+        else dma16s(st_a + (size_t)(k - XP) * a_piece, voffA, slot_lds + (k - XP) * 8192 + wv * 1024);
     };
     f32x4 acc[8][4];
 #pragma unroll
@@ -241,7 +243,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int sw = (r16 >> 1) & 7;
     const int fk[2] = {r16 * 128 + ((q ^ sw) * 16), r16 * 128 + (((4 + q) ^ sw) * 16)};
-    const int aoff = wm * 16384, boff = 32768 + wn * 8192;
+    const int aoff = wm * 16384, boff = BM * 128 + wn * 8192;
     f16x8 AX[4], AY[4], BP[4], BQ[4];
     auto ldA = [&](f16x8 (&U)[4], const char* slot, int half, int kh) {
 #pragma unroll
@@ -260,13 +262,13 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
 
     // prologue: k-steps 0, 1 staged; k-step 0 landed; its first units in registers
 #pragma unroll
-    for (int k = 0; k < 8; ++k) piece(k, lds0);
+    for (int k = 0; k < NP; ++k) piece(k, lds0);
     st_advance();
     if (nsteps > 1) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) piece(k, lds0 + BIG_SLOT);
+        for (int k = 0; k < NP; ++k) piece(k, lds0 + SLOTB);
         st_advance();
-        GH_WAIT_BARRIER(8);
+        if (NP == 8) { GH_WAIT_BARRIER(8); } else { GH_WAIT_BARRIER(10); }
     } else {
         GH_WAIT_BARRIER(0);
     }
@@ -274,9 +276,9 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
     ldB(BP, smem, 0);
     __builtin_amdgcn_sched_barrier(0);
     for (int s = 0; s < nsteps; ++s) {
-        const char* cur = smem + (s & 1) * BIG_SLOT;
-        const char* nxt = smem + ((s & 1) ^ 1) * BIG_SLOT;
-        const unsigned cur_lds = lds0 + (s & 1) * BIG_SLOT;
+        const char* cur = smem + (s & 1) * SLOTB;
+        const char* nxt = smem + ((s & 1) ^ 1) * SLOTB;
+        const unsigned cur_lds = lds0 + (s & 1) * SLOTB;
         // phase 1: (A0, B) k0; read A1 k0
         ldA(AY, cur, 1, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -301,9 +303,9 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
 #else
         const bool more = s + 2 < nsteps;
 #endif
-        if (more) { piece(0, cur_lds); piece(1, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        if (more) { piece(0, cur_lds); piece(1, cur_lds); if (NP == 10) piece(8, cur_lds); __builtin_amdgcn_sched_barrier(0); }
         BIG_MFMA4(AY, BQ, 4, 0);
-        if (more) { piece(2, cur_lds); piece(3, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        if (more) { piece(2, cur_lds); piece(3, cur_lds); if (NP == 10) piece(9, cur_lds); __builtin_amdgcn_sched_barrier(0); }
         BIG_MFMA4(AY, BQ, 4, 1);
         if (more) { piece(4, cur_lds); piece(5, cur_lds); __builtin_amdgcn_sched_barrier(0); }
         BIG_MFMA4(AY, BQ, 4, 2);
@@ -353,7 +355,9 @@ int gemm_h16_configure() {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_h16_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS);
     if (e != hipSuccess) return (int)e;
-    return (int)hipFuncSetAttribute((const void*)gemm_h16_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+    e = hipFuncSetAttribute((const void*)gemm_h16_big_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipFuncSetAttribute((const void*)gemm_h16_big_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
 }
 
 int gemm_h16_take_bad_shapes() { const int n = g_bad; g_bad = 0; return n; }
@@ -369,11 +373,17 @@ int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
     // whichever divides M)
     // the 256 x 256 tile where it fills the chip: >= 256 workgroups (DMAD_H16_BIG=0 switches it off: A/B runs)
     static const bool big_on = []() { const char* v = getenv("DMAD_H16_BIG"); return !(v && v[0] == '0'); }();
-    if (big_on && !two && a.M % 256 == 0 && a.K <= BIG_KMAX && ((a.N + 255) / 256) * (a.M / 256) >= 256 && a.H < 32768 && a.W < 32768 &&
-        a.N * (long)a.ldx < (1l << 31)) {
-        const long nx = (a.N + 255) / 256;
-        hipLaunchKernelGGL(gemm_h16_big_kernel, dim3((unsigned)(((nx + 7) / 8) * 8 * (a.M / 256))), dim3(512), BIG_LDS, s, a);
-        return 0;
+    if (big_on && !two && a.K <= BIG_KMAX && a.H < 32768 && a.W < 32768 && a.N * (long)a.ldx < (1l << 31)) {
+        if (a.M % 256 == 0 && ((a.N + 255) / 256) * (a.M / 256) >= 256) {
+            const long nx = (a.N + 255) / 256;
+            hipLaunchKernelGGL(gemm_h16_big_kernel<256>, dim3((unsigned)(((nx + 7) / 8) * 8 * (a.M / 256))), dim3(512), BIG_LDS_256, s, a);
+            return 0;
+        }
+        if (a.M == 128 && (a.N + 511) / 512 >= 256) {
+            const long nx = (a.N + 511) / 512;
+            hipLaunchKernelGGL(gemm_h16_big_kernel<128>, dim3((unsigned)(((nx + 7) / 8) * 8)), dim3(512), BIG_LDS_128, s, a);
+            return 0;
+        }
     }
     if (a.M % 256 == 0) {
         const dim3 grid((unsigned)((a.N + 127) / 128), (unsigned)(a.M / 256));

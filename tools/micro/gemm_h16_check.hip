@@ -91,7 +91,7 @@ static void timeit(int B, int H, int cin, int cout, int taps) {
 int main() {
     if (gemm_h16_configure()) { printf("configure failed\n"); return 2; }
     int bad = 0;
-    if (getenv("ONLY_TIME")) { timeit(512, 16, 256, 256, 9); timeit(512, 16, 256, 256, 9); timeit(512, 16, 512, 256, 9); timeit(512, 32, 128, 256, 9); return 0; }
+    if (getenv("ONLY_TIME")) { timeit(512, 16, 256, 256, 9); timeit(512, 32, 128, 128, 9); timeit(512, 32, 128, 128, 9); timeit(512, 32, 384, 128, 9); return 0; }
     bad += check(2, 8, 64, 128, 9, 1, 0, false);
     bad += check(3, 8, 128, 256, 9, 1, 0, true);
     bad += check(2, 16, 128, 128, 9, 2, 0, false);
@@ -106,6 +106,11 @@ int main() {
     bad += check(257, 16, 256, 256, 9, 1, 0, true);
     bad += check(256, 32, 128, 256, 9, 2, 0, false);
     bad += check(128, 16, 256, 768, 1, 1, 0, false);
+    // the 128 x 512 tile (M = 128, >= 256 workgroups): 3x3 with residual, N tail, stride 2, K = 384
+    bad += check(128, 32, 128, 128, 9, 1, 0, true);
+    bad += check(129, 32, 128, 128, 9, 1, 0, false);
+    bad += check(512, 32, 128, 128, 9, 2, 0, false);
+    bad += check(128, 32, 384, 128, 9, 1, 0, true);
     printf(bad ? "FAILED %d case(s)\n" : "all cases ok\n", bad);
     timeit(512, 32, 128, 128, 9);
     timeit(512, 32, 384, 128, 9);
