@@ -826,22 +826,24 @@ const float* unet_apply(dmad_engine* e, const dmad_engine::UnOp& o, const float*
     return out;
 }
 
-// ---- the same network on the 16-bit tier: every conv / 1x1 through gemm_h16 (f16 operands, fp32 accumulate), GroupNorm, softmax,
-// bias / residual sums and the maps themselves in fp32; a block output also exists as an f16 twin for the GEMMs that read it raw
+// ---- the same network on the 16-bit tier: every conv / 1x1 through gemm_h16 (f16 operands, fp32 accumulate); GroupNorm statistics,
+// softmax and the bias / residual sums in fp32; the hidden state itself exists as f16 maps ONLY (a block output costs 2 bytes per
+// value to write and 2 to read back as the next residual, against 4 + 2 and 4 with an fp32 copy beside it).  UMap::f of a block
+// output is only the identity of its buffer slot on this tier (never written or read); the network input has f alone.
 struct UMap { const float* f; const h16_t* h; };
 
 GemmH16Args un_h16_args(const h16_t* A, const float* bias, const h16_t* X, float* C, h16_t* C16, int cout, int cin, int taps, int B, int H,
-                        int stride, const float* res) {
+                        int stride, const h16_t* res16) {
     GemmH16Args g{};
     const int Ho = (H - 1) / (stride > 1 ? stride : 1) + 1;
-    g.A = A; g.X = X; g.C = C; g.C16 = C16; g.shift = bias; g.res = res; g.M = cout; g.K = cin; g.taps = taps; g.ldc = cout;
+    g.A = A; g.X = X; g.C = C; g.C16 = C16; g.shift = bias; g.res16 = res16; g.M = cout; g.K = cin; g.taps = taps; g.ldc = cout;
     g.N = (long)B * Ho * Ho; g.H = H; g.W = H; g.ldx = cin; g.stride = stride;
     return g;
 }
 
 bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, int& H, float* dstf, h16_t* dsth, int& rot, hipStream_t s,
                     UMap* result, UMap in2 = UMap{nullptr, nullptr}, int c1 = 0) {
-    float* SK = e->un_buf[5];
+    h16_t* SK16 = (h16_t*)e->un_buf[5];        // the skip conv's output, f16 (the fp32 tier's buffer, reused)
     h16_t *T1h = e->un_t1h, *T2h = e->un_t2h, *ATTh = e->un_atth;
     float* outf = dstf;
     h16_t* outh = dsth;
@@ -856,28 +858,28 @@ bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, 
         if (launch_groupnorm_nhwc(in.f, o.gn1w, o.gn1b, nullptr, 1, nullptr, B, H * H, o.cin, s, in2.f, c1, T1h, in.h, in2.h)) { gn_fail(H * H, o.cin); return false; }
         launch_gemm_h16(un_h16_args(o.w1h, o.b1, T1h, nullptr, T2h, o.cout, o.cin, 9, B, H, 1, nullptr), s);
         if (launch_groupnorm_nhwc(nullptr, o.gn2w, o.gn2b, e->un_ss_cur + o.ss_off, 1, nullptr, B, H * H, o.cout, s, nullptr, 0, T1h, T2h)) { gn_fail(H * H, o.cout); return false; }
-        const float* skip = in.f;
+        const h16_t* skip = in.h;
         if (o.cin != o.cout) {
-            GemmH16Args g = un_h16_args(o.skwh, o.skb, in.h, SK, nullptr, o.cout, o.cin, 1, B, H, 1, nullptr);
+            GemmH16Args g = un_h16_args(o.skwh, o.skb, in.h, nullptr, SK16, o.cout, o.cin, 1, B, H, 1, nullptr);
             if (in2.f) { g.ldx = c1; g.X2 = in2.h; g.ksplit = c1; g.ldx2 = o.cin - c1; }
             launch_gemm_h16(g, s);
-            skip = SK;
+            skip = SK16;
         }
-        launch_gemm_h16(un_h16_args(o.w2h, o.b2, T1h, outf, outh, o.cout, o.cout, 9, B, H, 1, skip), s);
+        launch_gemm_h16(un_h16_args(o.w2h, o.b2, T1h, nullptr, outh, o.cout, o.cout, 9, B, H, 1, skip), s);
     } else if (o.kind == 2) {               // AttentionBlock._forward + QKVAttention, unet.py:225-258
         const int C = o.cin, T = H * H;
         if (launch_groupnorm_nhwc(in.f, o.gn1w, o.gn1b, nullptr, 0, nullptr, B, T, C, s, nullptr, 0, T1h, in.h)) { gn_fail(T, C); return false; }
         if ((long)T * C > 256l * 256) { fail(DMAD_ERR_STATE, "UNet attention: %d tokens x %d channels exceed the f16 qkv buffer", T, C); return false; }
         launch_gemm_h16(un_h16_args(o.w1h, o.b1, T1h, nullptr, e->un_qkvh, 3 * C, C, 1, B, H, 1, nullptr), s);      // qkv straight to f16
         if (int rc = launch_qkv_attention_h16(e->un_qkvh, ATTh, B, T, kUnHeads, s)) { fail(rc > 0 ? DMAD_ERR_HIP : DMAD_ERR_STATE, "UNet attention (T = %d): %s", T, rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported map size"); return false; }
-        launch_gemm_h16(un_h16_args(o.w2h, o.b2, ATTh, outf, outh, C, C, 1, B, H, 1, in.f), s);
+        launch_gemm_h16(un_h16_args(o.w2h, o.b2, ATTh, nullptr, outh, C, C, 1, B, H, 1, in.h), s);
     } else if (o.kind == 3) {               // Downsample: conv 3x3 stride 2, unet.py:82-111
-        launch_gemm_h16(un_h16_args(o.w1h, o.b1, in.h, outf, outh, o.cout, o.cin, 9, B, H, 2, nullptr), s);
+        launch_gemm_h16(un_h16_args(o.w1h, o.b1, in.h, nullptr, outh, o.cout, o.cin, 9, B, H, 2, nullptr), s);
         H /= 2;
     } else if (o.kind == 4) {               // Upsample: nearest x2 + conv 3x3, unet.py:49-79
         launch_upsample2x_nhwc_h16(in.h, e->un_uph, B, H, H, o.cin, s);
         H *= 2;
-        launch_gemm_h16(un_h16_args(o.w1h, o.b1, e->un_uph, outf, outh, o.cout, o.cin, 9, B, H, 1, nullptr), s);
+        launch_gemm_h16(un_h16_args(o.w1h, o.b1, e->un_uph, nullptr, outh, o.cout, o.cin, 9, B, H, 1, nullptr), s);
     } else {                                // input conv 1 -> 128 (direct kernel, fp32 arithmetic)
         if (launch_conv1ch_3x3(in.f, o.w1, o.b1, outf, B, o.cout, s, outh)) { fail(DMAD_ERR_STATE, "input conv: %d output channels > 128", o.cout); return false; }
     }
@@ -913,7 +915,7 @@ int unet_eps(dmad_engine* e, const float* x, int t, int B, float* eps, hipStream
                 if (!ok) return DMAD_ERR_STATE;
             }
         }
-        if (launch_groupnorm_nhwc(h.f, e->un_outgw, e->un_outgb, nullptr, 1, e->un_buf[3], B, 1024, kUnMC, s)) { gn_fail(1024, kUnMC); return DMAD_ERR_STATE; }
+        if (launch_groupnorm_nhwc(h.f, e->un_outgw, e->un_outgb, nullptr, 1, e->un_buf[3], B, 1024, kUnMC, s, nullptr, 0, nullptr, h.h)) { gn_fail(1024, kUnMC); return DMAD_ERR_STATE; }
         launch_conv3x3_c128_to1(e->un_buf[3], e->un_outw, e->un_outb, eps, B, s);
         LASTCHK();
         return 0;

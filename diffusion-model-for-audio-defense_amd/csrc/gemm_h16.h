@@ -11,6 +11,7 @@ struct GemmH16Args {
     h16_t* C16;           // f16 twin of the output [N][ldc] or nullptr (for consumers that are GEMMs)
     const float* shift;   // [M] bias or nullptr
     const float* res;     // optional fp32 residual [N][ldc] added to the output
+    const h16_t* res16;   // ... or the residual as an f16 map [N][ldc] (the UNet's 16-bit tier keeps its hidden state in f16 only); not both
     int M, K, taps, ldc;  // taps: 9 (3x3, zero padding 1) or 1 (1x1)
     long N;               // output pixels: B * Ho * Wo
     int H, W;             // input height / width

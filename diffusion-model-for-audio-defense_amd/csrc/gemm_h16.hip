@@ -146,6 +146,19 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { acc[i][j][0] += rr[i][j].x; acc[i][j][1] += rr[i][j].y; acc[i][j][2] += rr[i][j].z; acc[i][j][3] += rr[i][j].w; }
     }
+    if (a.res16) {
+        f16x4 rh[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rh[i][j] = *(const f16x4*)(a.res16 + nn[j] + i * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)rh[i][j][r];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -336,6 +349,15 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { acc[i][j][0] += rr[j].x; acc[i][j][1] += rr[j].y; acc[i][j][2] += rr[j].z; acc[i][j][3] += rr[j].w; }
         }
+        if (a.res16) {
+            f16x4 rh[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rh[j] = *(const f16x4*)(a.res16 + nn[j] + i * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)rh[j][r];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (!ok[j]) continue;
@@ -365,7 +387,7 @@ int gemm_h16_take_bad_shapes() { const int n = g_bad; g_bad = 0; return n; }
 int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
     const bool two = a.X2 != nullptr;
     if ((a.taps != 9 && a.taps != 1) || (a.K % HK) || a.K < HK || (a.M % 128) || (a.ldc & 3) || a.N < 1 || (!a.C && !a.C16) ||
-        (a.ldx & 7) || (two && ((a.ksplit % HK) || a.ksplit <= 0 || a.ksplit >= a.K || (a.ldx2 & 7)))) {
+        (a.res && a.res16) || (a.ldx & 7) || (two && ((a.ksplit % HK) || a.ksplit <= 0 || a.ksplit >= a.K || (a.ldx2 & 7)))) {
         ++g_bad;
         return -1;
     }
