@@ -1,5 +1,6 @@
 // See unet_ops.h.
 #include "unet_ops.h"
+#include <stdlib.h>
 
 namespace dmad {
 
@@ -140,6 +141,86 @@ __global__ void __launch_bounds__(1024) groupnorm_nhwc_kernel(const float* __res
         }
         if (y16) *(f16x4*)(y16 + base + (long)pix * C) = f16x4{(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
         else *(float4*)(y + base + (long)pix * C) = float4{o[0], o[1], o[2], o[3]};
+    }
+}
+
+// GroupNorm + SiLU (+ scale-shift) of the UNet's 16-bit tier in streaming form: f16 map(s) in, f16 (or fp32) map out, the same
+// (sample, G groups) slab per workgroup as above — but nothing is held in registers: pass 1 streams the slab and accumulates the
+// shifted sums S1 = sum(x - K), S2 = sum((x - K)^2) per group (K = the group's first value: the cancellation in S2 - S1^2 / n is then
+// bounded by the group's spread, not by its mean), pass 2 re-reads it (64 KiB per workgroup: L2 hits) and writes the result.  A
+// workgroup is 192 / 256 threads with 76 registers, so 6 of them share a CU and their load / reduce / store phases overlap, where the
+// register-resident form runs ONE 1024-thread workgroup per CU through its phases in turn (2.2 TB/s on the 32 x 32 maps); and it takes
+// TWICE the groups per workgroup, so that a pixel's slice is whole 128-byte lines of the f16 map too (with the fp32 form's G a pixel
+// contributes 64 bytes: that alone made this kernel 3 % slower than the register-resident one; with it, 2.4 % faster on C5).  The
+// fp32 tier keeps the register-resident two-pass form (torch's arithmetic); here the output is f16 and the statistics differ from
+// it by ~1e-6 relative.  Fixed summation order: a sample's result does not depend on the batch.
+__global__ void __launch_bounds__(256) groupnorm16_stream_kernel(const h16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ ss, int silu, float* __restrict__ y, int HW, int C, int G,
+                                                                 const h16_t* __restrict__ x2, int c1, h16_t* __restrict__ y16) {
+    __shared__ float part[2][256];
+    __shared__ float gs[2][16];
+    const int NT = blockDim.x, t = threadIdx.x, lane = t & 63, wv = t >> 6, nwaves = NT >> 6;
+    const int c4 = C >> 7, R = G * c4, upb = 32 / G;
+    const int b = blockIdx.x / upb, g0 = (blockIdx.x % upb) * G;
+    const int j = t % R, grp = j / c4, cpg = C >> 5, c = (g0 + grp) * cpg + (j % c4) * 4;
+    const bool second = x2 && c >= c1;
+    const int pitch = x2 ? (second ? C - c1 : c1) : C;
+    const h16_t* src = (second ? x2 : x) + (second ? (long)b * HW * pitch + (c - c1) : (long)b * HW * pitch + c);
+    // the group's shift: its first channel at pixel 0 (every thread of the group reads the same value)
+    const int cg = (g0 + grp) * cpg;
+    const bool gsecond = x2 && cg >= c1;
+    const int gpitch = x2 ? (gsecond ? C - c1 : c1) : C;
+    const _Float16 kh = *(const _Float16*)((gsecond ? x2 : x) + (gsecond ? (long)b * HW * gpitch + (cg - c1) : (long)b * HW * gpitch + cg));
+    const float K = (float)kh;
+    const int p0 = t / R, pstep = NT / R;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+    for (int pix = p0; pix < HW; pix += pstep) {
+        const f16x4 hv = *(const f16x4*)(src + (long)pix * pitch);
+        const float d0 = (float)hv[0] - K, d1 = (float)hv[1] - K, d2 = (float)hv[2] - K, d3 = (float)hv[3] - K;
+        s1 += (d0 + d1) + (d2 + d3);
+        s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    part[0][t] = s1; part[1][t] = s2;
+    __syncthreads();
+    const int members = c4 * pstep;
+    for (int w = wv; w < 2 * G; w += nwaves) {                    // wave w: sum `w & 1` (S1 / S2) of group w >> 1, fixed order
+        const int gi = w >> 1, which = w & 1;
+        float a = 0.f;
+        for (int i = lane; i < members; i += 64) a += part[which][(i / c4) * R + gi * c4 + (i % c4)];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0) gs[which][gi] = a;
+    }
+    __syncthreads();
+    const float n = (float)(cpg * HW);
+    const float S1 = gs[0][grp], S2 = gs[1][grp];
+    const float mean = K + S1 / n;
+    const float var = fmaxf((S2 - S1 * (S1 / n)) / n, 0.f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
+    float4 q1 = float4{0.f, 0.f, 0.f, 0.f}, q2 = q1;
+    if (ss) { q1 = *(const float4*)(ss + c); q2 = *(const float4*)(ss + C + c); }
+    // (x - mean) * rstd * gamma + beta, then * (1 + scale) + shift: one FMA per value with the constants folded
+    float mul[4] = {rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w}, add[4] = {be.x, be.y, be.z, be.w};
+    const float s1a[4] = {q1.x, q1.y, q1.z, q1.w}, s2a[4] = {q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        add[r] -= mean * mul[r];
+        if (ss) { mul[r] *= 1.f + s1a[r]; add[r] = add[r] * (1.f + s1a[r]) + s2a[r]; }
+    }
+    const long obase = (long)b * HW * C + c;
+#pragma unroll 8
+    for (int pix = p0; pix < HW; pix += pstep) {
+        const f16x4 hv = *(const f16x4*)(src + (long)pix * pitch);
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float u = (float)hv[r] * mul[r] + add[r];
+            if (silu) u = u * fast_rcp(1.f + fast_exp2(u * -1.4426950408889634f));
+            o[r] = u;
+        }
+        if (y16) *(f16x4*)(y16 + obase + (long)pix * C) = f16x4{(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+        else *(float4*)(y + obase + (long)pix * C) = float4{o[0], o[1], o[2], o[3]};
     }
 }
 
@@ -415,6 +496,13 @@ int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta,
     const int want = HW >= 1024 ? 8 : HW >= 256 ? 4 : 2;          // float4s per thread: small maps are latency bound and want more threads
     while (per < want && NT > 64 && (NT / 2) % R == 0 && (NT / 2) % 64 == 0) { NT /= 2; per = (int)((n4 + NT - 1) / NT); }
     const dim3 grid((unsigned)(B * (32 / G)));
+    static const bool stream_on = []() { const char* v = getenv("DMAD_GN_STREAM"); return !(v && v[0] == '0'); }();
+    if (in16 && stream_on) {
+        const int G2 = 2 * G;                                   // f16 input: twice the groups for the same whole 128-byte lines per pixel
+        const int R2 = G2 * c4, nt = (R2 % 3 == 0) ? 192 : 256; // a multiple of R2 (16, 24 or 48) and of 64 (128 / 512 threads measured slower)
+        hipLaunchKernelGGL(groupnorm16_stream_kernel, dim3((unsigned)(B * (32 / G2))), dim3(nt), 0, s, x16, gamma, beta, ss, silu, y, HW, C, G2, x2_16, c1, y16);
+        return 0;
+    }
 #define GN_LAUNCH(PER)                                                                                                                  \
     do {                                                                                                                               \
         if (in16) hipLaunchKernelGGL((groupnorm_nhwc_kernel<PER, true>), grid, dim3(NT), 0, s, x, gamma, beta, ss, silu, y, HW, C, G, x2, c1, y16);  \
