@@ -308,6 +308,10 @@ constexpr int X3_BM = 256, X3_PAIR = 384 * 128, X3_LDS = 3 * X3_PAIR;
 // instruction fetch one whole cache line (64-byte rows asked L2 for every line twice); the eight 16-byte chunks of a row are
 // XOR-swizzled by (row >> 1) & 7 (conflict-free ds_read_b128 under the hardware's lane groups, tools/lds_bank_check.py); lane
 // (row, q) reads chunks q and q + 4: 8 hi and 8 lo halves = one K = 32 fragment of each part, as before.
+// Compile-time switches, ablation builds only (tools/x3_ablation.sh builds them into libdmad_hip.so.<variant>; the product library
+// defines none): X3_NO_DMA / X3_ONLY_A / X3_ONLY_X (steady-state LDS-DMA off / weight pieces only / activation pieces only),
+// X3_NO_LDS (no fragment reads), X3_NO_FIX (no hi / lo register exchange), X3_NO_BARRIER, X3_NO_VMWAIT (barrier without the counted
+// vmcnt wait), X3_STAMPS (s_memtime per phase group, printed for the K = 9216 skip GEMM).  Results of such builds are meaningless.
 template <bool DIAG>
 __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
     constexpr int MT = 4;
