@@ -65,4 +65,13 @@ if __name__ == '__main__':
     # 5. epilogue read: thread (t = idx/32, cg = idx%32) reads 2 x 16 B at t*1040 + cg*32 (+16)
     c, n = read_b128(lambda l: (l // 32) * 1040 + (l % 32) * 32)
     print('epi read', c, '/', n)
+    # 6. the 128-byte-row images of gemm_x3 / gemm_h16 (csrc/gemm_f32.hip, gemm_h16.hip): eight 16-byte chunks per row, XOR-swizzled
+    #    by (row >> 1) & 7; lane (row = l & 15, q = l >> 4) reads chunk q (first k half) or 4 + q (second)
+    for base in (0, 16, 64, 240):
+        for half in (0, 1):
+            c, n = read_b128(lambda l: (base + (l & 15)) * 128 + (((4 * half + (l >> 4)) ^ (((base + (l & 15)) >> 1) & 7)) * 16))
+            ok &= c == n
+    print('frag128 (gemm_x3 / gemm_h16)', c, '/', n)
+    c, n = read_b128(lambda l: (l & 15) * 128 + (l >> 4) * 16)
+    print('frag128 unswizzled', c, '/', n)
     sys.exit(0 if ok else 1)
