@@ -144,6 +144,9 @@ __global__ void __launch_bounds__(1024) groupnorm_nhwc_kernel(const float* __res
     }
 }
 
+#ifndef GN_UNROLL
+#define GN_UNROLL 4
+#endif
 // GroupNorm + SiLU (+ scale-shift) of the UNet's 16-bit tier in streaming form: f16 map(s) in, f16 (or fp32) map out, the same
 // (sample, G groups) slab per workgroup as above — but nothing is held in registers: pass 1 streams the slab and accumulates the
 // shifted sums S1 = sum(x - K), S2 = sum((x - K)^2) per group (K = the group's first value: the cancellation in S2 - S1^2 / n is then
@@ -174,7 +177,7 @@ __global__ void __launch_bounds__(256) groupnorm16_stream_kernel(const h16_t* __
     const float K = (float)kh;
     const int p0 = t / R, pstep = NT / R;
     float s1 = 0.f, s2 = 0.f;
-#pragma unroll 8
+#pragma unroll GN_UNROLL
     for (int pix = p0; pix < HW; pix += pstep) {
         const f16x4 hv = *(const f16x4*)(src + (long)pix * pitch);
         const float d0 = (float)hv[0] - K, d1 = (float)hv[1] - K, d2 = (float)hv[2] - K, d3 = (float)hv[3] - K;
@@ -209,7 +212,7 @@ __global__ void __launch_bounds__(256) groupnorm16_stream_kernel(const h16_t* __
         if (ss) { mul[r] *= 1.f + s1a[r]; add[r] = add[r] * (1.f + s1a[r]) + s2a[r]; }
     }
     const long obase = (long)b * HW * C + c;
-#pragma unroll 8
+#pragma unroll GN_UNROLL
     for (int pix = p0; pix < HW; pix += pstep) {
         const f16x4 hv = *(const f16x4*)(src + (long)pix * pitch);
         float o[4];
