@@ -89,6 +89,23 @@ uint16_t f2h_census(float f) {
     if (a >= 65520.f) ++g_h_ovf;
     return f2h(f);
 }
+// Development switch of the low-toggle-weights experiment (tools/gpu_weight_toggle.py): DMAD_WEIGHT_MASK_BITS = k
+// rounds the f16 weight images of the 16-bit WaveNet path to 10 - k mantissa bits (round to nearest even on the f16 pattern, the
+// k low bits then zero: fewer toggling bits on the L2 -> LDS -> register path at a precision cost); DMAD_WEIGHT_MASK_WHICH selects
+// the images (bit 0 dilated conv, 1 res conv, 2 skip convs, 3 final_conv.0; default 3).  Unset / 0 = the product.
+thread_local int g_mask_bits = 0;
+uint16_t f2h_census_masked(float f) {
+    uint32_t h = f2h_census(f);
+    const int k = g_mask_bits;
+    if (k > 0 && (h & 0x7c00u) != 0x7c00u) {
+        const uint32_t sign = h & 0x8000u;
+        uint32_t m = h & 0x7fffu;
+        m = (m + ((1u << (k - 1)) - 1u) + ((m >> k) & 1u)) & ~((1u << k) - 1u);      // a carry moves into the exponent as it should
+        if (m > 0x7bffu) m = 0x7bffu & ~((1u << k) - 1u);
+        h = sign | m;
+    }
+    return (uint16_t)h;
+}
 void census_close_tensor() {
     ++g_h_tensors;
     const double share = g_h_sq > 0.0 ? g_h_sq_sub / g_h_sq : 0.0;
@@ -331,6 +348,14 @@ int finalize_wavenet(dmad_engine* e) {
     if (e->bf16) {
         uint16_t (*cvt)(float) = e->f16 ? f2h_census : f2bf;
         g_h_sq = g_h_sq_sub = g_h_worst = 0.0; g_h_bad_tensors = g_h_ovf = g_h_tensors = 0;
+        int mask_bits = 0, mask_which = 3;              // development switch, see f2h_census_masked
+        if (const char* mb = getenv("DMAD_WEIGHT_MASK_BITS")) mask_bits = atoi(mb);
+        if (const char* mw = getenv("DMAD_WEIGHT_MASK_WHICH")) mask_which = atoi(mw);
+        if (mask_bits < 0 || mask_bits > 9 || !e->f16) mask_bits = 0;
+        auto cvt_for = [&](int which) -> uint16_t (*)(float) {
+            g_mask_bits = mask_bits;
+            return (mask_bits && (mask_which >> which & 1)) ? f2h_census_masked : cvt;
+        };
         int rmap[512];
         // tile row R = wm*128 + half*64 + mt*16 + i  <->  gate row half*256 + (mt*64 + wm*16 + i): channel ownership is
         // interleaved over the M-waves so that GEMM2 can start on channels [64 mt, 64 mt + 64) as soon as tiles mt are gated
@@ -350,19 +375,19 @@ int finalize_wavenet(dmad_engine* e) {
                 for (int oc = 0; oc < 512; ++oc)
                     for (int ci = 0; ci < 256; ++ci)     // rows pre-scaled to exp2 arguments: tanh half by -2*log2(e), sigmoid half by -log2(e)
                         tapw[(size_t)oc * 256 + ci] = dw[((size_t)oc * 256 + ci) * 3 + tap] * (oc < 256 ? -2.8853900817779268f : -1.4426950408889634f);
-                pack_rows(cvt, tapw.data(), 512, 256, 256, rmap, w1p, (size_t)n * 24 * 512 * 32, 3, tap);   // stage = 3 * kchunk + tap
+                pack_rows(cvt_for(0), tapw.data(), 512, 256, 256, rmap, w1p, (size_t)n * 24 * 512 * 32, 3, tap);   // stage = 3 * kchunk + tap
             }
             census_close_tensor();
             for (int R = 0; R < 512; ++R) b1p[(size_t)n * 512 + R] = db[rmap[R]];
             std::vector<float> rws(rw.size());                      // res conv pre-scaled by sqrt(1/2): h' = h*sqrt(1/2) + (W_res' g + c)
             for (size_t i = 0; i < rw.size(); ++i) rws[i] = rw[i] * 0.70710678118654752440f;
-            pack_rows(cvt, rws.data(), 256, 256, 256, nullptr, w2p, (size_t)n * 8 * 256 * 32);
+            pack_rows(cvt_for(1), rws.data(), 256, 256, 256, nullptr, w2p, (size_t)n * 8 * 256 * 32);
             census_close_tensor();
-            pack_rows(cvt, sw.data(), 256, 256, 256, nullptr, wsp, (size_t)n * 8 * 256 * 32);
+            pack_rows(cvt_for(2), sw.data(), 256, 256, 256, nullptr, wsp, (size_t)n * 8 * 256 * 32);
             census_close_tensor();
             for (int c = 0; c < 256; ++c) { b2[(size_t)n * 256 + c] = rb[c]; bsum[c] += sb[c]; }
         }
-        pack_rows(cvt, f0w.data(), 256, 256, 256, nullptr, wf0p, 0);
+        pack_rows(cvt_for(3), f0w.data(), 256, 256, 256, nullptr, wf0p, 0);
         census_close_tensor();
         CHK(e->upload_bf(&e->w1p, w1p)); CHK(e->upload_bf(&e->w2p, w2p)); CHK(e->upload_bf(&e->wsp, wsp));
         CHK(e->upload_bf(&e->wf0p, wf0p));
