@@ -21,6 +21,9 @@ Philox key.  The bound is a measured one, so the equality 
 empirical guarantee — and the line itself checks it: `exact_equals_fp32` re-runs the first timed steps' sample range in
 the exact-vote mode and on the exact-fp32 path and prints both vote vectors.  The line also carries
   fast_mode / fp32_mode — the same step with the recheck off (16-bit path alone) and on the exact-fp32 path alone;
+  sigma_grid     — the other sigmas of BASELINE C4's grid (0.25 and 1.0; README.md:12-14, scripts/certified_robust_eval.sh:3-6):
+                   a few timed steps each in the exact-vote mode and on the 16-bit tier alone, their recheck fractions, and
+                   exact == fp32 on the first timed step's keys of that sigma;
   c2_ddpm_mode   — BASELINE C2: DiffWave DDPM purification t* = 5 of a batch of 256 clips + mel-dB + VGG19_bn on a bf16
                    engine (dmad_query_logits, sampler 1): clips/s, network evaluations/s, layer-kernel roofline fraction;
   c3_certify_n1000 — BASELINE C3: RobustCertificate.certify(n_0=100, n=1000) through the host mirror, clips/s;
@@ -162,6 +165,10 @@ def main():
     ap.add_argument('--c5-n', type=int, default=10000, help='Monte Carlo samples PER RANK of the BASELINE C5 leg (spec-domain vote loop, '
                                                             'Improved-Diffusion UNet purifier, t* = 25; BASELINE C5 names N = 10 000: '
                                                             'about 13 s in the exact-vote mode); 0 = skip')
+    ap.add_argument('--sigma-grid', type=str, default='0.25,1.0',
+                    help='the other sigmas of BASELINE C4\'s grid (README.md:12-14): each gets --grid-steps timed steps in the exact-vote mode '
+                         '(+ the 16-bit tier alone, + exact == fp32 on its own keys); empty = skip')
+    ap.add_argument('--grid-steps', type=int, default=4)
     ap.add_argument('--classifier', choices=['vgg19_bn', 'resnext29'], default='vgg19_bn',
                     help='vgg19_bn = the configuration BASELINE.json names; resnext29 = the reference script\'s default classifier')
     args = ap.parse_args()
@@ -216,19 +223,23 @@ def main():
     hp = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
     ab = hp['Alpha_bar']
     sigma = args.sigma
-    abar_star = 1 / (1 + sigma ** 2)
-    t = int(torch.abs(ab - abar_star).min(0, keepdim=True)[1].item())      # t* - 1
-    c_a, c_b = float((1 / ab).sqrt()[t]), float((1 / ab - 1).sqrt()[t])
-    sc = float(torch.tensor(abar_star ** 0.5, dtype=torch.float32))
+
+    def sigma_cfg(sig):
+        """(sigma, sqrt(alpha_bar*), t* - 1, c_a, c_b) of certified_robust.py:51-54,102-110 + diffwave_ddpm.py:199-203."""
+        abar = 1 / (1 + sig ** 2)
+        tt = int(torch.abs(ab - abar).min(0, keepdim=True)[1].item())
+        return (sig, float(torch.tensor(abar ** 0.5, dtype=torch.float32)), tt, float((1 / ab).sqrt()[tt]), float((1 / ab - 1).sqrt()[tt]))
+    cfg0 = sigma_cfg(sigma)
+    _, sc, t, c_a, c_b = cfg0
     clip = torch.from_numpy(synth.synthetic_clip(0)).cuda()
     S = args.samples_per_step
     total = torch.zeros(10, dtype=torch.int64, device='cuda')
     MODES = {'exact': E.MODE_EXACT_VOTES, 'fast': E.MODE_FAST, 'fp32': E.MODE_FP32}
 
-    def step(i):
+    def step(i, cfg=cfg0):
         # global sample index range of this step: [i*S*world, (i+1)*S*world), rank r takes its slice
         base = (i * world + rank) * S
-        counts, _, _ = eng.smooth_votes(clip, sigma, sc, t, c_a, c_b, S, seed=2024, sample0=base)
+        counts, _, _ = eng.smooth_votes(clip, cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], S, seed=2024, sample0=base)
         if dist is not None:
             if backend == 'gloo':
                 c = counts.cpu()
@@ -243,11 +254,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(mode, steps, warmup, first_step, profile=False):
+    def timed(mode, steps, warmup, first_step, profile=False, cfg=cfg0):
         """`steps` timed steps in `mode`; -> (seconds (max over ranks), votes, recheck fraction, layer/final timings)."""
         eng.set_mode(MODES[mode])
         for i in range(warmup):
-            step(first_step + i)
+            step(first_step + i, cfg)
         fence()
         chunks_per_step = (S + args.max_batch - 1) // args.max_batch
         if profile:
@@ -257,7 +268,7 @@ def main():
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(first_step + warmup + i)
+            step(first_step + warmup + i, cfg)
         fence()
         dt = time.perf_counter() - t0
         prof = None
@@ -310,6 +321,28 @@ def main():
         check = {"exact_equals_fp32": v_exact == v_fp32, "votes_exact": v_exact, "votes_fp32": v_fp32, "samples": k * S * world,
                  "sample_range": [args.warmup * S * world, (args.warmup + k) * S * world],
                  "note": "the same Philox keys as the first %d timed steps, evaluated in the exact-vote mode and on the exact-fp32 path" % k}
+
+    # ---- the other sigmas of BASELINE C4's grid, a few steps each (same engine, same clip, their own sample range) -------------
+    grid = []
+    for sg in [float(v) for v in args.sigma_grid.split(',') if v.strip()] if args.grid_steps > 0 else []:
+        if abs(sg - sigma) < 1e-9:
+            continue
+        gcfg = sigma_cfg(sg)
+        gdt, gvotes, gfrac, _ = timed('exact', args.grid_steps, 1, first, cfg=gcfg)
+        fdt, _, _, _ = timed('fast', args.grid_steps, 1, first, cfg=gcfg)
+
+        def gvotes_of(mode):
+            eng.set_mode(MODES[mode])
+            total.zero_()
+            step(first + 1, gcfg)               # the first timed step's keys
+            fence()
+            return total.cpu().tolist()
+        gx, gp = gvotes_of('exact'), gvotes_of('fp32')
+        first += args.grid_steps + 1
+        grid.append({"sigma": sg, "t_star": gcfg[2] + 1, "steps": args.grid_steps, "clips_per_s": args.grid_steps * S * world / gdt,
+                     "fast_mode_clips_per_s": args.grid_steps * S * world / fdt, "exact_over_fast": fdt / gdt,
+                     "recheck_frac": gfrac[0], "recheck_frac_fp32": gfrac[1], "votes": gvotes,
+                     "exact_equals_fp32": gx == gp, "votes_exact_first_step": gx, "votes_fp32_first_step": gp, "check_samples": S * world})
 
     full = None
     if not args.no_certify and args.classifier == 'vgg19_bn':
@@ -495,6 +528,8 @@ def main():
                                          "matrix_tflops_same_launch": 2.0 * L * 256 * (36 * 256 + 256) * fclips / (favg * 1e-3) / 1e12}
         for mode, rec in side.items():
             out[mode + "_mode"] = rec
+        if grid:
+            out["sigma_grid"] = grid
         if full is not None:
             out["certify_full"] = full
             if c3 is not None:

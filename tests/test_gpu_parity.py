@@ -867,12 +867,19 @@ def test_bench_contract():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--samples-per-step', '8',
                         '--max-batch', '8', '--cpu-samples', '2', '--full-n', '64', '--c5-n', '16', '--c2-iters', '1', '--c2-batch', '8', '--c3-clips', '1',
-                        '--check-steps', '1'], capture_output=True, text=True, timeout=600, cwd=root)
+                        '--check-steps', '1', '--grid-steps', '1'], capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
     j = json.loads(lines[0])
     base = json.load(open(os.path.join(root, 'BASELINE.json')))
+    # BASELINE C4's whole sigma grid rides in the line: 0.25 and 1.0 beside the headline's 0.5, each with its own exactness check
+    sg = {round(g['sigma'], 2): g for g in j['sigma_grid']}
+    assert sorted(sg) == [0.25, 1.0] and sg[0.25]['t_star'] == 34 and sg[1.0]['t_star'] == 117
+    for g in sg.values():
+        assert g['clips_per_s'] > 0 and g['fast_mode_clips_per_s'] > 0 and sum(g['votes']) == 8 * g['steps']
+        assert g['exact_equals_fp32'] is True and g['votes_exact_first_step'] == g['votes_fp32_first_step'] and g['check_samples'] == 8
+        assert 0.0 <= g['recheck_frac_fp32'] <= g['recheck_frac'] <= 1.0
     assert j['metric'] == base['metric'] and j['unit'] == 'clips/s' and j['n_gpus'] == 1 and j['steps'] == 1 and j['warmup'] == 1
     assert j['higher_is_better'] is True and j['scaling'] == 'weak' and j['vs_baseline'] is None and j['dtype'] == 'f16' and j['data'] == 'synthetic'
     assert 'workload' in j['config'] and 'model' not in j['config']
