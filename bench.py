@@ -24,6 +24,9 @@ the exact-vote mode and on the exact-fp32 path and prints both vote vectors.  Th
   sigma_grid     — the other sigmas of BASELINE C4's grid (0.25 and 1.0; README.md:12-14, scripts/certified_robust_eval.sh:3-6):
                    a few timed steps each in the exact-vote mode and on the 16-bit tier alone, their recheck fractions, and
                    exact == fp32 on the first timed step's keys of that sigma;
+  resnext29_mode — the same step with the reference script's DEFAULT classifier (ResNeXt29 8x64d, certified_robustness_eval.py:57):
+                   tier 1 runs the classifier's 16-bit tier (gemm_h16), the recheck tiers the fp32 one; clips/s, recheck fractions,
+                   exact == fp32 on its first timed step's keys;
   c2_ddpm_mode   — BASELINE C2: DiffWave DDPM purification t* = 5 of a batch of 256 clips + mel-dB + VGG19_bn on a bf16
                    engine (dmad_query_logits, sampler 1): clips/s, network evaluations/s, layer-kernel roofline fraction;
   c3_certify_n1000 — BASELINE C3: RobustCertificate.certify(n_0=100, n=1000) through the host mirror, clips/s;
@@ -169,6 +172,8 @@ def main():
                     help='the other sigmas of BASELINE C4\'s grid (README.md:12-14): each gets --grid-steps timed steps in the exact-vote mode '
                          '(+ the 16-bit tier alone, + exact == fp32 on its own keys); empty = skip')
     ap.add_argument('--grid-steps', type=int, default=4)
+    ap.add_argument('--resnext-steps', type=int, default=6, help='timed steps of the ResNeXt29 leg (the reference script\'s default classifier on an '
+                                                                 'exact-vote engine of its own, ~30 s incl. the engine build); 0 = skip')
     ap.add_argument('--classifier', choices=['vgg19_bn', 'resnext29'], default='vgg19_bn',
                     help='vgg19_bn = the configuration BASELINE.json names; resnext29 = the reference script\'s default classifier')
     args = ap.parse_args()
@@ -236,10 +241,12 @@ def main():
     total = torch.zeros(10, dtype=torch.int64, device='cuda')
     MODES = {'exact': E.MODE_EXACT_VOTES, 'fast': E.MODE_FAST, 'fp32': E.MODE_FP32}
 
+    cur = {'eng': eng}                         # the engine the step / timed helpers drive (the ResNeXt29 leg swaps it)
+
     def step(i, cfg=cfg0):
         # global sample index range of this step: [i*S*world, (i+1)*S*world), rank r takes its slice
         base = (i * world + rank) * S
-        counts, _, _ = eng.smooth_votes(clip, cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], S, seed=2024, sample0=base)
+        counts, _, _ = cur['eng'].smooth_votes(clip, cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], S, seed=2024, sample0=base)
         if dist is not None:
             if backend == 'gloo':
                 c = counts.cpu()
@@ -256,6 +263,7 @@ def main():
 
     def timed(mode, steps, warmup, first_step, profile=False, cfg=cfg0):
         """`steps` timed steps in `mode`; -> (seconds (max over ranks), votes, recheck fraction, layer/final timings)."""
+        eng = cur['eng']
         eng.set_mode(MODES[mode])
         for i in range(warmup):
             step(first_step + i, cfg)
@@ -476,6 +484,36 @@ def main():
               "exact_equals_fp32": x_counts == p_counts, "votes_exact_same_keys": x_counts}
         eng5.close()
 
+    # The reference script's DEFAULT classifier (certified_robustness_eval.py:57: ResNeXt29 8x64d) in place of VGG19_bn: the same step on
+    # an exact-vote engine of its own (tier 1 = f16 WaveNet + the classifier's 16-bit tier, recheck tiers = split-f16 / fp32 WaveNet + fp32
+    # classifier), a few timed steps, the 16-bit tiers alone, and exact == fp32 on the first timed step's keys
+    rxm = None
+    if args.resnext_steps > 0 and args.classifier == 'vgg19_bn':
+        eng.close()
+        engr = E.Engine(max_batch=args.max_batch, precision=E.EXACT, half_type=half, recheck_batch=min(args.recheck_batch, args.max_batch),
+                        recheck_margin=args.recheck_margin)
+        engr.load_wavenet(wsd)
+        engr.load_resnext29(synth.resnext29_state_dict(2929))
+        cur['eng'] = engr
+        rdt, rvotes, rfrac, _ = timed('exact', args.resnext_steps, 2, first)
+        fdt, _, _, _ = timed('fast', args.resnext_steps, 1, first)
+
+        def rvotes_of(mode):
+            engr.set_mode(MODES[mode])
+            total.zero_()
+            step(first + 2)                     # the first timed step's keys
+            fence()
+            return total.cpu().tolist()
+        rx_, rp_ = rvotes_of('exact'), rvotes_of('fp32')
+        rxm = {"workload": "the headline's step with the reference script's default classifier: ResNeXt29 8x64d (synthetic seed 2929), sigma=%.2f" % sigma,
+               "clips_per_s": args.resnext_steps * S * world / rdt, "steps": args.resnext_steps, "fast_mode_clips_per_s": args.resnext_steps * S * world / fdt,
+               "vs_vgg_headline": (args.resnext_steps * S * world / rdt) / (clips / dt), "recheck_frac": rfrac[0], "recheck_frac_fp32": rfrac[1],
+               "recheck_margin": engr.recheck_margin, "votes": rvotes, "exact_equals_fp32": rx_ == rp_, "votes_exact_first_step": rx_,
+               "votes_fp32_first_step": rp_, "check_samples": S * world,
+               "classifier_tiers": "tier 1: gemm_h16 (f16 operands, fp32 accumulate); recheck tiers and dmad_classify: fp32 matrix cores"}
+        engr.close()
+        cur['eng'] = eng
+
     if rank == 0:
         out = {
             "metric": "purified+classified 1s clips/sec at N=100k sigma=0.5; 1/2/4/8 GPUs",
@@ -538,6 +576,8 @@ def main():
             out["c2_ddpm_mode"] = c2
         if c5 is not None:
             out["c5_spec_mode"] = c5
+        if rxm is not None:
+            out["resnext29_mode"] = rxm
         if world == 1 and not args.no_cpu_baseline and args.classifier == 'vgg19_bn':
             out["cpu_baseline"] = cpu_baseline(args.cpu_samples)
         print(json.dumps(out), flush=True)

@@ -214,12 +214,17 @@ struct dmad_engine {
     long slab_floats = 0;
     // ResNeXt29 8x64d (models/resnext.py): 9 bottlenecks, every conv with its folded eval-BatchNorm scale/shift
     int cls_kind = 0;                      // 0 = VGG19_bn, 1 = ResNeXt29
-    struct RxConv { float *w = nullptr, *scale = nullptr, *shift = nullptr; };
+    struct RxConv { float *w = nullptr, *scale = nullptr, *shift = nullptr; h16_t* wh = nullptr; };   // wh: f16 image with the BN scale folded in (16-bit tier)
     struct RxBlock { RxConv reduce, conv, expand, shortc; bool has_short = false; int cin = 0, cout = 0, D = 0, stride = 1; };
     RxBlock rx[9];
     RxConv rxconv1;
     float *rxfcw = nullptr, *rxfcb = nullptr;
     float *rxX = nullptr, *rxY = nullptr, *rxT1 = nullptr, *rxT2 = nullptr, *rxS = nullptr;   // NHWC work buffers
+    // ResNeXt29's 16-bit tier (engines with a 16-bit side): every conv through gemm_h16 on f16 operands (fp32 accumulate, BN shift /
+    // shortcut add / ReLU in fp32), maps kept as f16 between the convs; tier 1 of the exact-vote loop uses it, the recheck tiers and
+    // dmad_classify stay on the fp32 matrix cores
+    bool rx_h16 = false;
+    h16_t *rxX16 = nullptr, *rxY16 = nullptr, *rxT1h = nullptr, *rxT2h = nullptr, *rxS16 = nullptr;
     // Improved-Diffusion UNet purifier on 1x32x32 mel spectrograms (improved_diffusion/unet.py:278-477)
     struct UnOp {                          // one module of a TimestepEmbedSequential
         int kind = 0;                      // 0 conv_in, 1 res, 2 attn, 3 down, 4 up
@@ -534,12 +539,25 @@ GemmF32Args plain_gemm(const float* A, const float* X, float* C, const float* sc
 // rx.fc.{w,b}.  GEMM images: 1x1 convs [M][K]; the grouped 3x3 conv per group [tap][M/8][K/8] (models/resnext.py:23-62).
 int finalize_resnext(dmad_engine* e) {
     const HostW* w;
-    auto up3 = [&](const std::string& base, dmad_engine::RxConv& c, const std::vector<float>& A, int M) -> int {
+    // A: the fp32 GEMM image; rows_of(i) = the output channel whose BN scale multiplies element i of the f16 image Ah (null: Ah = A)
+    auto up3 = [&](const std::string& base, dmad_engine::RxConv& c, const std::vector<float>& A, int M, const std::vector<float>* Ah = nullptr,
+                   const std::vector<int>* ch_of = nullptr, long row_len = 0) -> int {
         CHK(e->upload(&c.w, A));
         w = e->get(base + ".scale", {M}); if (!w) return DMAD_ERR_STATE;
-        CHK(e->upload(&c.scale, w->v));
+        const std::vector<float> scale = w->v;
+        CHK(e->upload(&c.scale, scale));
         w = e->get(base + ".shift", {M}); if (!w) return DMAD_ERR_STATE;
         CHK(e->upload(&c.shift, w->v));
+        if (e->rx_h16 && row_len > 0) {     // f16 image, BN scale folded into the rows (the 16-bit kernel's epilogue only adds the shift)
+            const std::vector<float>& S = Ah ? *Ah : A;
+            std::vector<uint16_t> Hh(S.size());
+            for (size_t i = 0; i < S.size(); ++i) {
+                const long row = (long)(i / (size_t)row_len);
+                const int ch = ch_of ? (*ch_of)[row] : (int)(row % M);
+                Hh[i] = f2h(ch >= 0 ? S[i] * scale[ch] : 0.f);
+            }
+            CHK(e->upload_bf(&c.wh, Hh));
+        }
         return 0;
     };
     w = e->get("rx.conv1.w", {64, 1, 3, 3}); if (!w) return DMAD_ERR_STATE;
@@ -555,7 +573,7 @@ int finalize_resnext(dmad_engine* e) {
         b.has_short = b.cin != b.cout;
         const std::string base = "rx.b" + std::to_string(i);
         w = e->get(base + ".reduce.w", {b.D, b.cin}); if (!w) return DMAD_ERR_STATE;
-        CHK(up3(base + ".reduce", b.reduce, w->v, b.D));
+        CHK(up3(base + ".reduce", b.reduce, w->v, b.D, nullptr, nullptr, b.cin));
         const int G = b.D / 8;
         w = e->get(base + ".conv.w", {b.D, G, 3, 3}); if (!w) return DMAD_ERR_STATE;
         std::vector<float> A((size_t)8 * 9 * G * G);
@@ -564,12 +582,26 @@ int finalize_resnext(dmad_engine* e) {
                 for (int kk = 0; kk < G; ++kk)
                     for (int t = 0; t < 9; ++t)
                         A[(((size_t)g * 9 + t) * G + m) * G + kk] = w->v[(((size_t)g * G + m) * G + kk) * 9 + t];
-        CHK(up3(base + ".conv", b.conv, A, b.D));
+        {   // f16 image of the grouped conv: [group][tap][Mg][Kg].  gemm_h16 needs Mg % 128 == 0: the 64-channel groups of stage 1
+            // are paired into 128 x 128 block-diagonal groups (the off-diagonal blocks are zeros: twice the MFMAs on 17 % of the network)
+            const int pair = G < 128 ? 2 : 1, Gp = G * pair, ngp = 8 / pair;
+            std::vector<float> Ah((size_t)ngp * 9 * Gp * Gp, 0.f);
+            std::vector<int> ch_of((size_t)ngp * 9 * Gp);
+            for (int gp = 0; gp < ngp; ++gp)
+                for (int t = 0; t < 9; ++t)
+                    for (int m = 0; m < Gp; ++m) {
+                        const int g = gp * pair + m / G, mm = m % G;
+                        ch_of[((size_t)gp * 9 + t) * Gp + m] = g * G + mm;
+                        for (int kk = 0; kk < G; ++kk)
+                            Ah[(((size_t)gp * 9 + t) * Gp + m) * Gp + (m / G) * G + kk] = w->v[(((size_t)g * G + mm) * G + kk) * 9 + t];
+                    }
+            CHK(up3(base + ".conv", b.conv, A, b.D, &Ah, &ch_of, Gp));
+        }
         w = e->get(base + ".expand.w", {b.cout, b.D}); if (!w) return DMAD_ERR_STATE;
-        CHK(up3(base + ".expand", b.expand, w->v, b.cout));
+        CHK(up3(base + ".expand", b.expand, w->v, b.cout, nullptr, nullptr, b.D));
         if (b.has_short) {
             w = e->get(base + ".short.w", {b.cout, b.cin}); if (!w) return DMAD_ERR_STATE;
-            CHK(up3(base + ".short", b.shortc, w->v, b.cout));
+            CHK(up3(base + ".short", b.shortc, w->v, b.cout, nullptr, nullptr, b.cin));
         }
     }
     w = e->get("rx.fc.w", {e->cfg.num_classes, 1024}); if (!w) return DMAD_ERR_STATE;
@@ -582,6 +614,53 @@ int finalize_resnext(dmad_engine* e) {
     CHK(e->alloc(&e->rxS, B * 1024 * 256));
     CHK(e->alloc(&e->rxT1, B * 1024 * 1024));     // stage 2's first reduce: 32x32 pixels x D = 1024
     CHK(e->alloc(&e->rxT2, B * 1024 * 512));
+    if (e->rx_h16) {
+        CHK(e->alloc(&e->rxX16, B * 1024 * 256)); CHK(e->alloc(&e->rxY16, B * 1024 * 256)); CHK(e->alloc(&e->rxS16, B * 1024 * 256));
+        CHK(e->alloc(&e->rxT1h, B * 1024 * 1024)); CHK(e->alloc(&e->rxT2h, B * 1024 * 512));
+        if (int r = gemm_h16_configure()) return fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS, f16 conv GEMM) failed: %d", r);
+    }
+    return 0;
+}
+
+// The same network on its 16-bit tier: f16 maps, every conv through gemm_h16 (BN scale folded into the f16 weights, shift / shortcut /
+// ReLU in the fp32 epilogue); the last bottleneck writes fp32 for the average pool and the fp32 classifier head.
+int classify_resnext_h16(dmad_engine* e, const float* spec, int B, float* logits, hipStream_t s) {
+    h16_t *X = e->rxX16, *Y = e->rxY16;
+    launch_vgg_conv1(spec, e->rxconv1.w, e->rxconv1.scale, e->rxconv1.shift, nullptr, B, s, X);
+    int H = 32;
+    for (int i = 0; i < 9; ++i) {
+        const dmad_engine::RxBlock& b = e->rx[i];
+        const int Ho = (H - 1) / b.stride + 1;
+        const long Nin = (long)B * H * H, Nout = (long)B * Ho * Ho;
+        auto mk = [&](const dmad_engine::RxConv& c, const h16_t* in, h16_t* out16, int M, int K, int taps, long N, int Hin, int ldx, int ldc, int stride) {
+            GemmH16Args g{};
+            g.A = c.wh; g.X = in; g.C16 = out16; g.shift = c.shift; g.M = M; g.K = K; g.taps = taps; g.ldc = ldc; g.N = N; g.H = Hin; g.W = Hin;
+            g.ldx = ldx; g.stride = stride; g.relu = 1;
+            return g;
+        };
+        launch_gemm_h16(mk(b.reduce, X, e->rxT1h, b.D, b.cin, 1, Nin, H, b.cin, b.D, 1), s);                      // conv_reduce + bn + ReLU
+        const int G = b.D / 8, pair = G < 128 ? 2 : 1;
+        GemmH16Args c = mk(b.conv, e->rxT1h, e->rxT2h, G * pair, G * pair, 9, Nout, H, b.D, b.D, b.stride);         // grouped 3x3 (stride) + bn + ReLU
+        c.groups = 8 / pair;
+        launch_gemm_h16(c, s);
+        const h16_t* res = X;
+        if (b.has_short) {
+            GemmH16Args h = mk(b.shortc, X, e->rxS16, b.cout, b.cin, 1, Nout, H, b.cin, b.cout, b.stride);         // shortcut conv + bn (no ReLU)
+            h.relu = 0;
+            launch_gemm_h16(h, s);
+            res = e->rxS16;
+        }
+        GemmH16Args x = mk(b.expand, e->rxT2h, i == 8 ? nullptr : Y, b.cout, b.D, 1, Nout, Ho, b.D, b.cout, 1);   // conv_expand + bn + shortcut, ReLU
+        x.res16 = res;
+        if (i == 8) x.C = e->rxY;
+        launch_gemm_h16(x, s);
+        h16_t* t = X; X = Y; Y = t;
+        H = Ho;
+    }
+    launch_avgpool_nhwc(e->rxY, e->rxT2, B, H * H, 1024, s);
+    launch_gemm_f32(plain_gemm(e->rxfcw, e->rxT2, logits, nullptr, e->rxfcb, e->cfg.num_classes, 1024, B, e->cfg.num_classes, 1024, 0), s,
+                    e->slab, e->slab_floats, (long)e->maxB);
+    LASTCHK();
     return 0;
 }
 
@@ -1088,11 +1167,13 @@ int mel_db(dmad_engine* e, const float* x, int B, float* spec, hipStream_t s, in
     return 0;
 }
 
-int classify(dmad_engine* e, const float* spec, int B, float* logits, hipStream_t s) {
+// h16 = 1: the classifier's 16-bit tier where one is resident (ResNeXt29 on engines with a 16-bit side) — what tier 1 of the vote
+// loops runs; every other caller (dmad_classify, the recheck tiers) gets the fp32 matrix cores
+int classify(dmad_engine* e, const float* spec, int B, float* logits, hipStream_t s, int h16 = 0) {
     if (!e->cfg.with_classifier) return fail(DMAD_ERR_STATE, "engine was created with with_classifier = 0");
     if (!e->cls_final) return fail(DMAD_ERR_STATE, "classifier weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
     if (B < 1 || B > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d]", B, e->maxB);
-    if (e->cls_kind == 1) return classify_resnext(e, spec, B, logits, s);
+    if (e->cls_kind == 1) return (h16 && e->rx_h16) ? classify_resnext_h16(e, spec, B, logits, s) : classify_resnext(e, spec, B, logits, s);
     float *cur = e->act0, *nxt = e->act1;
     launch_vgg_conv1(spec, e->vconv1w, e->vscale[0], e->vshift[0], cur, B, s);
     int H = 32, cin = 64, li = 1;
@@ -1122,6 +1203,9 @@ int classify(dmad_engine* e, const float* spec, int B, float* logits, hipStream_
     LASTCHK();
     return 0;
 }
+
+// the classifier tier of a vote loop's FIRST pass (and of the mode-default paths): 16-bit unless the engine is in DMAD_MODE_FP32
+inline int cls_tier(const dmad_engine* e) { return (e->rx_h16 && e->mode != DMAD_MODE_FP32) ? 1 : 0; }
 
 }  // namespace
 
@@ -1165,6 +1249,7 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     e->tau = cfg->half_type == DMAD_HALF_F16 ? 0.034f : 0.30f;  // measured logit-difference error (against the leader) of the 16-bit path x 1.4 (see dmad.h)
     e->tau2 = 1e-3f;                        // the same for the split-f16 tier (dmad_set_recheck_margin2)
     e->un_h16 = cfg->precision != DMAD_FP32;    // engines with a 16-bit side also get the UNet's f16 tier (once UNet weights are loaded)
+    e->rx_h16 = cfg->precision != DMAD_FP32;    // ... and ResNeXt29's (once its weights are loaded)
     e->tau_spec = 0.4f;                     // spec-domain vote loop: measured logit-difference error of the f16 UNet chain x headroom (see dmad.h)
     const bool wn = cfg->with_wavenet != 0;
     if (e->bf16 && !wn_final_p_supported(cfg->num_res_layers)) {
@@ -1425,6 +1510,28 @@ int dmad_classify(dmad_engine* e, const float* spec, int32_t B, float* logits, d
     return classify(e, spec, B, logits, (hipStream_t)s);
 }
 
+int dmad_classify_tier(dmad_engine* e, const float* spec, int32_t B, int32_t tier, float* logits, dmad_stream s) {
+    if (!e || !spec || !logits) return fail(DMAD_ERR_INVALID, "null argument");
+    if (tier != 0 && tier != 1) return fail(DMAD_ERR_INVALID, "unknown classifier tier %d (0 fp32, 1 16-bit)", tier);
+    return classify(e, spec, B, logits, (hipStream_t)s, tier);
+}
+
+int dmad_conv_h16(const uint16_t* x, const uint16_t* x2, int32_t ksplit, const uint16_t* w, const float* bias, const uint16_t* res16,
+                  int32_t B, int32_t H, int32_t M, int32_t K, int32_t taps, int32_t stride, int32_t groups, int32_t relu,
+                  float* out32, uint16_t* out16, dmad_stream s) {
+    if (!x || !w || (!out32 && !out16)) return fail(DMAD_ERR_INVALID, "null argument");
+    if (B < 1 || H < 1 || M < 1 || K < 1 || groups < 1 || (stride != 1 && stride != 2)) return fail(DMAD_ERR_INVALID, "bad geometry");
+    if (int r = gemm_h16_configure()) return fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS, f16 conv GEMM) failed: %d", r);
+    const int Ho = (H - 1) / stride + 1;
+    GemmH16Args g{};
+    g.A = w; g.X = x; g.C = out32; g.C16 = out16; g.shift = bias; g.res16 = res16; g.M = M; g.K = K; g.taps = taps; g.ldc = groups * M;
+    g.N = (long)B * Ho * Ho; g.H = H; g.W = H; g.ldx = x2 ? ksplit : groups * K; g.stride = stride; g.relu = relu; g.groups = groups;
+    if (x2) { g.X2 = x2; g.ksplit = ksplit; g.ldx2 = K - ksplit; }
+    launch_gemm_h16(g, (hipStream_t)s);
+    LASTCHK();
+    return 0;
+}
+
 int dmad_vote(dmad_engine* e, const float* logits, int32_t B, int64_t* counts, dmad_stream s) {
     if (!e || !logits || !counts || B < 1) return fail(DMAD_ERR_INVALID, "bad argument to dmad_vote");
     launch_vote(logits, B, e->cfg.num_classes, (unsigned long long*)counts, nullptr, (hipStream_t)s);
@@ -1503,7 +1610,7 @@ int dmad_eval_samples(dmad_engine* e, const float* clip, float sigma, float sqrt
         launch_lincomb(0, e->xt, e->eps, nullptr, c_a, c_b, 0.f, x0, (long)B * L, st);
         if (logits_out) {
             CHK(mel_db(e, x0, B, e->spec, st));
-            CHK(classify(e, e->spec, B, logits_out + done * C, st));
+            CHK(classify(e, e->spec, B, logits_out + done * C, st, path == PATH_DEFAULT ? cls_tier(e) : 0));
         }
     }
     LASTCHK();
@@ -1602,7 +1709,7 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
         if (e->cfg.with_classifier) {
             CHK(mel_db(e, x0, B, e->spec, st));
             float* lg = logits_out ? logits_out + done * C : e->logits;
-            CHK(classify(e, e->spec, B, lg, st));
+            CHK(classify(e, e->spec, B, lg, st, cls_tier(e)));
             if (recheck) {
                 launch_vote_margin(lg, B, C, (unsigned long long*)counts, e->tau, (long long)(sample0 + (uint64_t)done), nullptr, e->rc_list,
                                    e->rc_n, e->rc_cap, nullptr, st);
@@ -1649,7 +1756,7 @@ int spec_chain(dmad_engine* e, const SpecJob& j, uint64_t s0, const long long* i
         launch_unet_p_sample(x, e->un_eps, sig != 0.f ? e->znoise : nullptr, j.c_a[t], j.c_b[t], j.c_1[t], j.c_2[t], sig, x, nullptr, (long)B * 1024, st);
     }
     launch_spec_unstandardize(x, j.mel_lo, j.mel_hi, sp, (long)B * 1024, st);
-    CHK(classify(e, sp, B, lg, st));
+    CHK(classify(e, sp, B, lg, st, h16 == 0 ? 0 : cls_tier(e)));
     return 0;
 }
 
@@ -1748,7 +1855,7 @@ int dmad_query_logits(dmad_engine* e, const float* x, int32_t B, int32_t repeats
             pur = e->x0;
         }
         CHK(mel_db(e, pur, nb, e->spec, st));
-        CHK(classify(e, e->spec, nb, logits + r0 * C, st));
+        CHK(classify(e, e->spec, nb, logits + r0 * C, st, cls_tier(e)));
         if (decisions) launch_vote(logits + r0 * C, nb, C, nullptr, decisions + r0, st);
     }
     LASTCHK();

@@ -27,7 +27,8 @@ void launch_mel_pad(const float* x, float* xp, int B, int L, int LPm, hipStream_
 void launch_mel_power(const float* D, float* P, int ldd, int ldp, long rows, hipStream_t s);
 void launch_mel_db(const float* M, float* spec, int B, int to_db, hipStream_t s);
 void launch_power_to_db(const float* x, float* y, long n, hipStream_t s);
-void launch_vgg_conv1(const float* in, const float* w, const float* scale, const float* shift, float* out, int B, hipStream_t s);
+void launch_vgg_conv1(const float* in, const float* w, const float* scale, const float* shift, float* out, int B, hipStream_t s,
+                      h16_t* out16 = nullptr);     // out / out16: fp32 map and / or its f16 twin (either may be null)
 void launch_maxpool2_nhwc(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 void launch_avgpool_nhwc(const float* in, float* out, int B, int HW, int C, hipStream_t s);
 void launch_vote(const float* logits, int B, int C, unsigned long long* counts, int* pred_out, hipStream_t s);

@@ -286,7 +286,7 @@ __global__ void mel_db_kernel(const float* __restrict__ M, float* __restrict__ s
 // ----------------------------------------------------------------------------------------------
 // first conv (Cin = 1) + folded BN + relu: in [B][32][32] -> out NHWC [B][32][32][64]
 __global__ void vgg_conv1_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ scale,
-                                 const float* __restrict__ shift, float* __restrict__ out, long total) {
+                                 const float* __restrict__ shift, float* __restrict__ out, long total, h16_t* __restrict__ out16) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one (b, y, x, co) each
     if (i >= total) return;
     const int co = (int)(i & 63);
@@ -300,7 +300,9 @@ __global__ void vgg_conv1_kernel(const float* __restrict__ in, const float* __re
             const int yy = y + ky - 1, xx = x + kx - 1;
             if ((unsigned)yy < 32u && (unsigned)xx < 32u) s = fmaf(w[co * 9 + ky * 3 + kx], in[(b << 10) + yy * 32 + xx], s);
         }
-    out[i] = relu_nan(s * scale[co] + shift[co]);
+    const float v = relu_nan(s * scale[co] + shift[co]);
+    if (out) out[i] = v;
+    if (out16) { const _Float16 hv = (_Float16)v; out16[i] = __builtin_bit_cast(unsigned short, hv); }     // f16 twin (the classifier's 16-bit tier)
 }
 
 // 2x2 max pool, NHWC
@@ -450,9 +452,9 @@ __global__ void power_to_db_kernel(const float* __restrict__ x, float* __restric
 void launch_power_to_db(const float* x, float* y, long n, hipStream_t s) {
     hipLaunchKernelGGL(power_to_db_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, x, y, n);
 }
-void launch_vgg_conv1(const float* in, const float* w, const float* scale, const float* shift, float* out, int B, hipStream_t s) {
+void launch_vgg_conv1(const float* in, const float* w, const float* scale, const float* shift, float* out, int B, hipStream_t s, h16_t* out16) {
     const long total = (long)B * 1024 * 64;
-    hipLaunchKernelGGL(vgg_conv1_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, in, w, scale, shift, out, total);
+    hipLaunchKernelGGL(vgg_conv1_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, in, w, scale, shift, out, total, out16);
 }
 void launch_maxpool2_nhwc(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
     const long total4 = (long)B * (H / 2) * (W / 2) * (C / 4);

@@ -19,6 +19,9 @@ struct GemmH16Args {
     int stride;           // 0/1 = 1, 2 = output (H-1)/2+1 x (W-1)/2+1
     const h16_t* X2;      // optional: channels [ksplit, K) of every pixel come from X2 (pixel pitch ldx2) — th.cat([h, skip], dim=1)
     int ksplit, ldx2;     //   of the UNet (unet.py:473) read in place; ksplit % 64 == 0
+    int relu;             // 1: max(., 0) after bias and residual (NaN stays NaN, like torch.relu) — ResNeXt's BN-folded convs
+    int groups;           // 0/1 = dense; g > 1: grouped conv (resnext.py:36-37), M and K are PER GROUP: group z reads channels
+                          //   [z K, (z+1) K) of X (pixel pitch ldx), weights A + z * taps * M * K, writes channels [z M, (z+1) M) (pitch ldc)
 };
 
 // 0, or -1 for an argument block the kernel does not serve (nothing is launched; counted for gemm_h16_take_bad_shapes)

@@ -32,10 +32,25 @@ __device__ __attribute__((aligned(128))) unsigned short g_zero_page_h[64];     /
     } while (0)
 
 thread_local int g_bad = 0;
+
+// grouped conv: group z of a launch is an ordinary dense problem on shifted pointers
+__device__ __forceinline__ void select_group(GemmH16Args& a, int z) {
+    if (a.groups > 1) {
+        a.A += (size_t)z * a.taps * a.M * a.K;
+        a.X += z * a.K;
+        const int mo = z * a.M;
+        if (a.C) a.C += mo;
+        if (a.C16) a.C16 += mo;
+        if (a.shift) a.shift += mo;
+        if (a.res) a.res += mo;
+        if (a.res16) a.res16 += mo;
+    }
+}
 }  // namespace
 
 template <int BM, bool TWO>
 __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
+    select_group(a, blockIdx.z);
     constexpr int BN = 384 - BM, WN = BN / 64;          // waves along N (2 or 4); along M: BM / 64
     constexpr int AP = BM / 64, XP = 6 - AP;            // 64-row staging pieces (8 KiB each) holding A rows / X rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -164,7 +179,8 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (!ok[j]) continue;
-            const f32x4 v = acc[i][j];
+            f32x4 v = acc[i][j];
+            if (a.relu) v = f32x4{relu_nan(v[0]), relu_nan(v[1]), relu_nan(v[2]), relu_nan(v[3])};
             if (a.C) *(float4*)(a.C + nn[j] + i * 16) = float4{v[0], v[1], v[2], v[3]};
             if (a.C16) *(f16x4*)(a.C16 + nn[j] + i * 16) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
         }
@@ -184,7 +200,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
 // once per tap); rows outside the image come from a zero page long enough to take the k offset.
 // ----------------------------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int BIG_LDS_256 = 2 * 512 * 128, BIG_LDS_128 = 2 * 640 * 128, BIG_KMAX = 1024;      // 128 KiB / 160 KiB (all of a CU's LDS)
+constexpr int BIG_LDS_256 = 2 * 512 * 128, BIG_LDS_128 = 2 * 640 * 128, BIG_KMAX = 2048;      // 128 KiB / 160 KiB (all of a CU's LDS)
 __device__ __attribute__((aligned(128))) unsigned short g_zero_page_big[BIG_KMAX + 64];
 __device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, unsigned lds) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
@@ -196,6 +212,7 @@ __device__ __forceinline__ void dma16v(const void* vaddr, unsigned lds) {
 
 template <int BM>               // 256: 256 x 256 tile, waves 2 (M) x 4 (N); 128: 128 x 512 tile, waves 1 x 8 (the 128-channel layers)
 __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
+    select_group(a, blockIdx.y);
     constexpr int BN = BM == 256 ? 256 : 512, AP = BM / 64, XP = BN / 64, NP = AP + XP, SLOTB = (BM + BN) * 128, WN = BN / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -361,7 +378,8 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (!ok[j]) continue;
-            const f32x4 v = acc[i][j];
+            f32x4 v = acc[i][j];
+            if (a.relu) v = f32x4{relu_nan(v[0]), relu_nan(v[1]), relu_nan(v[2]), relu_nan(v[3])};
             if (a.C) *(float4*)(a.C + nn[j] + i * 16) = float4{v[0], v[1], v[2], v[3]};
             if (a.C16) *(f16x4*)(a.C16 + nn[j] + i * 16) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
         }
@@ -386,6 +404,8 @@ int gemm_h16_take_bad_shapes() { const int n = g_bad; g_bad = 0; return n; }
 
 int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
     const bool two = a.X2 != nullptr;
+    const int ng = a.groups > 1 ? a.groups : 1;
+    if (ng > 1 && (two || (long)ng * a.K > a.ldx || (long)ng * a.M > a.ldc || ng > 65535)) { ++g_bad; return -1; }
     if ((a.taps != 9 && a.taps != 1) || (a.K % HK) || a.K < HK || (a.M % 128) || (a.ldc & 3) || a.N < 1 || (!a.C && !a.C16) ||
         (a.res && a.res16) || (a.ldx & 7) || (two && ((a.ksplit % HK) || a.ksplit <= 0 || a.ksplit >= a.K || (a.ldx2 & 7)))) {
         ++g_bad;
@@ -396,23 +416,23 @@ int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
     // the 256 x 256 tile where it fills the chip: >= 256 workgroups (DMAD_H16_BIG=0 switches it off: A/B runs)
     static const bool big_on = []() { const char* v = getenv("DMAD_H16_BIG"); return !(v && v[0] == '0'); }();
     if (big_on && !two && a.K <= BIG_KMAX && a.H < 32768 && a.W < 32768 && a.N * (long)a.ldx < (1l << 31)) {
-        if (a.M % 256 == 0 && ((a.N + 255) / 256) * (a.M / 256) >= 256) {
+        if (a.M % 256 == 0 && ((a.N + 255) / 256) * (a.M / 256) * ng >= 256) {
             const long nx = (a.N + 255) / 256;
-            hipLaunchKernelGGL(gemm_h16_big_kernel<256>, dim3((unsigned)(((nx + 7) / 8) * 8 * (a.M / 256))), dim3(512), BIG_LDS_256, s, a);
+            hipLaunchKernelGGL(gemm_h16_big_kernel<256>, dim3((unsigned)(((nx + 7) / 8) * 8 * (a.M / 256)), ng), dim3(512), BIG_LDS_256, s, a);
             return 0;
         }
-        if (a.M == 128 && (a.N + 511) / 512 >= 256) {
+        if (a.M == 128 && (a.N + 511) / 512 * ng >= 256) {
             const long nx = (a.N + 511) / 512;
-            hipLaunchKernelGGL(gemm_h16_big_kernel<128>, dim3((unsigned)(((nx + 7) / 8) * 8)), dim3(512), BIG_LDS_128, s, a);
+            hipLaunchKernelGGL(gemm_h16_big_kernel<128>, dim3((unsigned)(((nx + 7) / 8) * 8), ng), dim3(512), BIG_LDS_128, s, a);
             return 0;
         }
     }
     if (a.M % 256 == 0) {
-        const dim3 grid((unsigned)((a.N + 127) / 128), (unsigned)(a.M / 256));
+        const dim3 grid((unsigned)((a.N + 127) / 128), (unsigned)(a.M / 256), ng);
         if (two) hipLaunchKernelGGL((gemm_h16_kernel<256, true>), grid, dim3(512), H16_LDS, s, a);
         else hipLaunchKernelGGL((gemm_h16_kernel<256, false>), grid, dim3(512), H16_LDS, s, a);
     } else {
-        const dim3 grid((unsigned)((a.N + 255) / 256), (unsigned)(a.M / 128));
+        const dim3 grid((unsigned)((a.N + 255) / 256), (unsigned)(a.M / 128), ng);
         if (two) hipLaunchKernelGGL((gemm_h16_kernel<128, true>), grid, dim3(512), H16_LDS, s, a);
         else hipLaunchKernelGGL((gemm_h16_kernel<128, false>), grid, dim3(512), H16_LDS, s, a);
     }

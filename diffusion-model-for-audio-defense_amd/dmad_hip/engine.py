@@ -507,6 +507,16 @@ class Engine:
             check(self.lib.dmad_classify(self._h, _ptr(sp[s:e]), e - s, _ptr(out[s:e]), _stream()))
         return out
 
+    def classify_tier(self, spec: torch.Tensor, tier: int) -> torch.Tensor:
+        """dmad_classify_tier: the classifier on an explicit tier (0 fp32, 1 the 16-bit tier of ResNeXt29) — test / measurement hook."""
+        if not spec.is_cuda:
+            raise DmadError('input must live on the GPU (the dmad engine has no CPU path)')
+        sp = spec.detach().reshape(spec.shape[0], 32 * 32).contiguous().float()
+        out = torch.empty((sp.shape[0], self.num_classes), device=sp.device, dtype=torch.float32)
+        for s, e in self._chunks(sp.shape[0]):
+            check(self.lib.dmad_classify_tier(self._h, _ptr(sp[s:e]), e - s, int(tier), _ptr(out[s:e]), _stream()))
+        return out
+
     def vote(self, logits: torch.Tensor, counts: torch.Tensor):
         lg = logits.detach().contiguous().float()
         assert lg.is_cuda and counts.is_cuda and counts.dtype == torch.int64 and lg.shape[1] == self.num_classes
@@ -596,6 +606,39 @@ class Engine:
 
     def device_bytes(self) -> int:
         return int(self.lib.dmad_device_bytes(self._h))
+
+
+def conv_h16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, groups: int = 1, relu: bool = False,
+             res: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None, want32: bool = True, want16: bool = True):
+    """dmad_conv_h16 — the f16 conv-GEMM family as a standalone op (test hook).  x: f16 NHWC [B,H,H,Cx] (CUDA), x2: optional second
+    map [B,H,H,C2] whose channels follow x's (dense convs only); w: f16 [groups, taps, M, K] (taps 9 or 1, K per group = (Cx + C2) /
+    groups); bias fp32 [groups*M]; res: optional f16 [B,Ho,Ho,groups*M].  Returns (out32 | None, out16 | None), NHWC."""
+    lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float16 and w.is_cuda and w.dtype == torch.float16 and x.dim() == 4 and w.dim() == 4
+    x, w = x.contiguous(), w.contiguous()
+    B, H, W_, cx = x.shape
+    assert H == W_
+    g_, taps, M, K = w.shape
+    assert g_ == groups and taps in (1, 9)
+    ksplit = 0
+    if x2 is not None:
+        assert groups == 1 and x2.dtype == torch.float16 and x2.shape[:3] == x.shape[:3]
+        x2 = x2.contiguous()
+        ksplit = cx
+        assert cx + x2.shape[3] == K
+    else:
+        assert cx == groups * K
+    Ho = (H - 1) // stride + 1
+    out32 = torch.empty((B, Ho, Ho, groups * M), device=x.device, dtype=torch.float32) if want32 else None
+    out16 = torch.empty((B, Ho, Ho, groups * M), device=x.device, dtype=torch.float16) if want16 else None
+    if bias is not None:
+        bias = bias.detach().contiguous().float()
+    if res is not None:
+        assert res.dtype == torch.float16 and tuple(res.shape) == (B, Ho, Ho, groups * M)
+        res = res.contiguous()
+    check(lib.dmad_conv_h16(_ptr(x), _ptr(x2), int(ksplit), _ptr(w), _ptr(bias), _ptr(res), B, H, M, K, taps, int(stride), int(groups),
+                            1 if relu else 0, _ptr(out32), _ptr(out16), _stream()))
+    return out32, out16
 
 
 def bind_classifier(state_dict, loader_name: str, engine: Optional[Engine] = None) -> Engine:

@@ -166,6 +166,16 @@ int dmad_unet_p_sample(dmad_engine* e, float* x, int32_t t, float c_a, float c_b
  * spec: [B][32][32] fp32, logits: [B][num_classes] fp32. */
 int dmad_classify(dmad_engine* e, const float* spec, int32_t B, float* logits, dmad_stream s);
 
+/* The classifier's tiers.  Engines of precision DMAD_BF16 / DMAD_EXACT that hold ResNeXt29 — the default classifier of the
+ * reference's certification script (certified_robustness_eval.py:57; models/resnext.py:23-142) — also hold a 16-BIT TIER of it:
+ * every conv (1x1 reduce / expand / shortcut, the grouped 3x3) on f16 operands with fp32 accumulation, the eval-mode BatchNorm
+ * scale folded into the f16 weights, shift / shortcut add / ReLU in fp32, maps kept as f16 between the convs; average pool and
+ * the linear head stay fp32.  Tier 1 of dmad_smooth_votes (and the mode-default paths of dmad_eval_samples / dmad_query_logits)
+ * runs it unless the engine is in DMAD_MODE_FP32; the recheck tiers and dmad_classify always use the fp32 matrix cores, so a
+ * re-evaluated sample's logits are the fp32 path's.  dmad_classify_tier evaluates an explicit tier (0: fp32, 1: 16-bit; VGG19_bn
+ * has no 16-bit tier and is served on fp32 either way) — test / measurement hook. */
+int dmad_classify_tier(dmad_engine* e, const float* spec, int32_t B, int32_t tier, float* logits, dmad_stream s);
+
 /* The Monte Carlo loop of RobustCertificate.smooth_predict (+ forward, compute_t_star's result),
  * robustness_eval/certified_robust.py:17-31,33-67:  for samples i in [sample0, sample0 + n):
  *   x_in = sqrt(alpha_bar_star) * (clip + delta_i);  x0 = one_shot(x_in, t);  logits = classifier(mel_db(x0));
@@ -279,6 +289,17 @@ int dmad_profile_read(dmad_engine* e, float* total_ms, int32_t* launches);
 /* The same for the launches of the tail kernel (wn_final: skip GEMM over the gate store + final convs) bracketed since
  * dmad_profile_layers(); call it BEFORE dmad_profile_read (which switches the bracketing off). */
 int dmad_profile_read_final(dmad_engine* e, float* total_ms, int32_t* launches);
+
+/* Test hook of the f16 conv-GEMM family (csrc/gemm_h16.hip: the kernels behind the UNet's and ResNeXt29's 16-bit tiers), standalone —
+ * no engine state is read.  NHWC convolution  out[n][g*M + m] = relu?( sum_tap sum_k w[g][tap][m][k] x[pixel(n, tap)][g*K + k] + bias[g*M + m]
+ * + res[n][g*M + m] )  with f16 operands and fp32 accumulation.  x: device f16 [B][H][H][ldx]; x2 / ksplit: optional second input
+ * map holding channels [ksplit, K) (the UNet's th.cat read in place; x then has ksplit channels per pixel); w: device f16
+ * [groups][taps][M][K] (taps 9 = 3x3 with zero padding 1, or 1); bias: fp32 [groups * M] or NULL; res16: optional f16 residual
+ * [N][groups * M]; out32 / out16: fp32 map and / or f16 twin [N][groups * M], N = B * Ho * Ho, Ho = (H - 1) / stride + 1.
+ * M and K are per group.  Which of the family's kernels serves a shape is the launcher's choice (the product's). */
+int dmad_conv_h16(const uint16_t* x, const uint16_t* x2, int32_t ksplit, const uint16_t* w, const float* bias, const uint16_t* res16,
+                  int32_t B, int32_t H, int32_t M, int32_t K, int32_t taps, int32_t stride, int32_t groups, int32_t relu,
+                  float* out32, uint16_t* out16, dmad_stream s);
 
 /* Bytes of device memory held by the engine. */
 int64_t dmad_device_bytes(const dmad_engine* e);

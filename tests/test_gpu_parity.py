@@ -623,6 +623,120 @@ def test_resnext29_vs_reference_fixture(golden_dir, orc):
     assert int(counts.sum()) == 24 and counts.shape == (10,)
 
 
+
+def test_resnext29_16bit_tier_and_exact_votes(golden_dir, weights, sched):
+    """The reference script's DEFAULT classifier (certified_robustness_eval.py:57; models/resnext.py:23-142) on its 16-bit tier:
+    (1) dmad_classify_tier(1) — every conv on f16 operands through gemm_h16 (grouped 3x3, stride 2, 1x1 with the BN scale folded
+    into the weights) — within the f16 tolerance of the logits of the imported reference class, batch invariant, and really another
+    arithmetic than the fp32 tier; dmad_classify itself stays the fp32 tier; (2) the exact-vote loop with the f16 classifier in
+    tier 1 and the fp32 classifier in the recheck tiers: counts == the all-fp32 counts, bit for bit, on 3 clips x 3 sigmas x 512
+    = 4 608 samples, re-evaluated rows of logits_out bit-identical to the fp32 path's."""
+    from dmad_hip import engine as E
+    z = G(golden_dir, 'resnext29.npz')
+    sd = synth.resnext29_state_dict(int(z['seed']))
+    eng = E.Engine(max_batch=64, precision=E.EXACT, recheck_batch=32)
+    eng.load_wavenet(weights[0])
+    eng.load_resnext29(sd)
+    spec = torch.from_numpy(z['spec_in']).cuda()
+    l32, l16 = eng.classify_tier(spec, 0), eng.classify_tier(spec, 1)
+    assert torch.equal(l32, eng.classify(spec))                                   # dmad_classify = the fp32 tier
+    assert relmax(l32.cpu().numpy(), z['logits']) < 2e-4
+    e16 = relmax(l16.cpu().numpy(), z['logits'])
+    assert 1e-6 < e16 < F16_MAX_TOL, e16
+    assert torch.equal(eng.classify_tier(spec[1:2], 1), l16[1:2])                 # a sample's logits do not depend on its batch
+    big = eng.classify_tier(spec.repeat(40, 1, 1, 1), 1)                          # 160 > max_batch: chunked; other tile shapes
+    assert torch.equal(big[:4], l16) and torch.equal(big[156:], l16)
+    hp, coef = sched
+    ab = hp['Alpha_bar']
+    N, worst = 512, 0.0
+    for ci in (0, 1, 2):
+        clip = torch.from_numpy(synth.synthetic_clip(ci)).cuda()
+        for sigma in (0.25, 0.5, 1.0):
+            t = int(torch.abs(ab - 1 / (1 + sigma ** 2)).min(0, keepdim=True)[1].item())
+            sc = float(torch.tensor((1 / (1 + sigma ** 2)) ** 0.5, dtype=torch.float32))
+            out = {}
+            for mode in (E.MODE_FAST, E.MODE_FP32, E.MODE_EXACT_VOTES):
+                eng.set_mode(mode)
+                eng.recheck_stats(reset=True)
+                c, l, _ = eng.smooth_votes(clip, sigma, sc, t, *coef(t), N, seed=700 + ci, sample0=9000, want_logits=True)
+                out[mode] = (c.cpu().tolist(), l.cpu().numpy().astype(np.float64), eng.recheck_stats())
+            fast, f32, ex = out[E.MODE_FAST], out[E.MODE_FP32], out[E.MODE_EXACT_VOTES]
+            assert sum(fast[0]) == sum(f32[0]) == sum(ex[0]) == N
+            assert ex[0] == f32[0], (ci, sigma, ex[0], f32[0])
+            assert (ex[1].argmax(1) == f32[1].argmax(1)).all()
+            e = fast[1] - f32[1]
+            lead = np.abs(e - e[np.arange(N), f32[1].argmax(1)][:, None]).max()
+            worst = max(worst, float(lead))
+            srt = np.sort(fast[1].astype(np.float32), 1)
+            low = ~((srt[:, -1] - srt[:, -2]) >= np.float32(eng.recheck_margin))
+            assert ex[2] == (N, int(low.sum()))
+            # a rechecked row carries the logits of a higher tier; the rows that reached fp32 are the fp32 path's bit for bit
+            same = (ex[1] == f32[1]).all(1)
+            assert int(same.sum()) >= eng.recheck_stats(detail=True)[2]
+    assert worst < eng.recheck_margin, (worst, eng.recheck_margin)                # the bound covers tier 1's error WITH the f16 classifier
+    eng.close()
+
+
+def _conv_ref(x, x2, w, bias, res, stride, groups, relu):
+    """torch fp32 NCHW convolution of the same f16-rounded operands (the fp32 reference of the f16 conv-GEMM family)."""
+    xin = x if x2 is None else torch.cat([x, x2], dim=3)
+    g_, taps, M, K = w.shape
+    k = 3 if taps == 9 else 1
+    wt = w.float().reshape(g_, k, k, M, K).permute(0, 3, 4, 1, 2).reshape(g_ * M, K, k, k)       # [groups*M, K, kh, kw]
+    y = torch.nn.functional.conv2d(xin.float().permute(0, 3, 1, 2), wt, bias=None if bias is None else bias.float(), stride=stride,
+                                   padding=k // 2, groups=g_)
+    y = y.permute(0, 2, 3, 1)
+    if res is not None:
+        y = y + res.float()
+    return torch.relu(y) if relu else y
+
+
+H16_CASES = [   # B, H, cin, cout, taps, stride, c1 (two-part input: first map's channels), residual, groups, relu
+    (2, 8, 64, 128, 9, 1, 0, False, 1, False), (3, 8, 128, 256, 9, 1, 0, True, 1, False), (2, 16, 128, 128, 9, 2, 0, False, 1, False),
+    (5, 4, 256, 256, 9, 1, 0, True, 1, False), (2, 8, 256, 384, 1, 1, 0, False, 1, False), (2, 8, 384, 128, 1, 1, 256, False, 1, False),
+    (3, 16, 256, 768, 1, 1, 0, False, 1, False), (2, 8, 512, 256, 1, 1, 256, True, 1, False), (1, 32, 128, 128, 9, 1, 0, True, 1, False),
+    # the 256 x 256 register-prefetched tile (>= 256 workgroups): 3x3 with residual, N tail, stride 2, 1x1 with three row blocks
+    (256, 16, 256, 256, 9, 1, 0, True, 1, False), (257, 16, 256, 256, 9, 1, 0, True, 1, False), (256, 32, 128, 256, 9, 2, 0, False, 1, False),
+    (128, 16, 256, 768, 1, 1, 0, False, 1, False),
+    # the 128 x 512 tile (M = 128): 3x3 with residual, N tail, stride 2, K = 384
+    (128, 32, 128, 128, 9, 1, 0, True, 1, False), (129, 32, 128, 128, 9, 1, 0, False, 1, False), (512, 32, 128, 128, 9, 2, 0, False, 1, False),
+    (128, 32, 384, 128, 9, 1, 0, True, 1, False),
+    # ResNeXt29's forms: K = 64, ReLU, 1x1 with stride 2, grouped 3x3 (4 paired / 8 groups; stride 2; small and chip-filling launches)
+    (3, 32, 64, 512, 1, 1, 0, False, 1, True), (2, 32, 256, 512, 1, 2, 0, False, 1, False), (2, 16, 512, 512, 9, 1, 0, False, 4, True),
+    (3, 16, 1024, 1024, 9, 2, 0, False, 8, True), (64, 32, 512, 512, 9, 1, 0, False, 4, True), (128, 16, 2048, 2048, 9, 2, 0, False, 8, True),
+    (256, 8, 2048, 1024, 1, 1, 0, True, 1, True),
+]
+
+
+@pytest.mark.parametrize('case', H16_CASES, ids=lambda c: 'B%d_H%d_%dto%d_t%d_s%d_c1%d_r%d_g%d_relu%d' % tuple(int(v) for v in c))
+def test_gemm_h16_family_vs_torch_conv(case):
+    """Every form of the f16 conv-GEMM family (csrc/gemm_h16.hip: the 384-row kernel in both splits, the 256 x 256 and 128 x 512
+    register-prefetched tiles, two-part input, stride 2, N tails, grouped convs, ReLU) through dmad_conv_h16 against a torch fp32
+    convolution of the same f16-rounded operands (improved_diffusion/unet.py:107-252, models/resnext.py:23-62 are the callers' ops):
+    the fp32 output within 2e-3 absolute (fp32 accumulation order only), the f16 twin within one f16 rounding of it."""
+    from dmad_hip import engine as E
+    B, H, cin, cout, taps, stride, c1, with_res, groups, relu = case
+    g = torch.Generator().manual_seed(1000 + B + H + cin)
+    Kg, Mg = cin // groups, cout // groups
+    x = (torch.rand(B, H, H, cin, generator=g) * 2 - 1).half().cuda()
+    w = ((torch.rand(groups, taps, Mg, Kg, generator=g) * 2 - 1) * 0.1).half().cuda()
+    bias = (torch.rand(cout, generator=g) * 2 - 1).cuda()
+    Ho = (H - 1) // stride + 1
+    res = (torch.rand(B, Ho, Ho, cout, generator=g) * 2 - 1).half().cuda() if with_res else None
+    xa, xb = (x[..., :c1].contiguous(), x[..., c1:].contiguous()) if c1 else (x, None)
+    o32, o16 = E.conv_h16(xa, w, bias, stride=stride, groups=groups, relu=bool(relu), res=res, x2=xb)
+    # reference in chunks of the batch (fp32 conv of 512 x 32 x 32 x 128 fits, but keep the test's footprint small)
+    worst32 = worst16 = 0.0
+    for b0 in range(0, B, 64):
+        sl = slice(b0, min(B, b0 + 64))
+        ref = _conv_ref(xa[sl], None if xb is None else xb[sl], w, bias, None if res is None else res[sl], stride, groups, bool(relu))
+        worst32 = max(worst32, float((o32[sl] - ref).abs().max()))
+        worst16 = max(worst16, float((o16[sl].float() - ref).abs().max()))
+    assert worst32 < 2e-3, worst32
+    assert worst16 < 2e-2, worst16
+    assert torch.equal(o16, o32.half())                     # the f16 twin IS the rounded fp32 output
+
+
 # ------------------------------------------------------------------------------------------ Improved-Diffusion UNet (N1)
 def test_unet_purifier_vs_reference_fixture(golden_dir):
     """UNetModel.forward, GaussianDiffusion.q_sample / p_sample and the ImprovedDiffusion wrapper on the HIP engine vs
@@ -867,12 +981,16 @@ def test_bench_contract():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--samples-per-step', '8',
                         '--max-batch', '8', '--cpu-samples', '2', '--full-n', '64', '--c5-n', '16', '--c2-iters', '1', '--c2-batch', '8', '--c3-clips', '1',
-                        '--check-steps', '1', '--grid-steps', '1'], capture_output=True, text=True, timeout=600, cwd=root)
+                        '--check-steps', '1', '--grid-steps', '1', '--resnext-steps', '1'], capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
     j = json.loads(lines[0])
     base = json.load(open(os.path.join(root, 'BASELINE.json')))
+    # the reference script's default classifier (ResNeXt29) on its 16-bit tier, exact votes checked on its own keys
+    rx = j['resnext29_mode']
+    assert rx['clips_per_s'] > 0 and rx['fast_mode_clips_per_s'] > 0 and sum(rx['votes']) == 8 * rx['steps'] and rx['vs_vgg_headline'] > 0
+    assert rx['exact_equals_fp32'] is True and rx['votes_exact_first_step'] == rx['votes_fp32_first_step'] and rx['check_samples'] == 8
     # BASELINE C4's whole sigma grid rides in the line: 0.25 and 1.0 beside the headline's 0.5, each with its own exactness check
     sg = {round(g['sigma'], 2): g for g in j['sigma_grid']}
     assert sorted(sg) == [0.25, 1.0] and sg[0.25]['t_star'] == 34 and sg[1.0]['t_star'] == 117
