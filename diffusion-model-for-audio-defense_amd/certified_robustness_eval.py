@@ -117,8 +117,11 @@ def run(args, classifier=None, denoiser=None, log=print):
         y_certified, r_certified = RC.certify(x=waveforms, y=targets, sigma=args.sigma, n_0=100, n=args.num_sampling,
                                               batch_size=args.batch_size, audit=getattr(args, 'audit', 0))
         audits = RC.audit_log[n_audits:]
-        records.append_batch(targets.tolist(), y_certified.tolist(), r_certified.tolist(),
-                             extra=[{'audit': a} for a in audits] if len(audits) == len(targets) else None)
+        extra = None
+        if getattr(args, 'audit', 0) > 0:       # an audit that was asked for leaves a trace in every record, also when it could not run
+            extra = ([{'audit': a} for a in audits] if len(audits) == len(targets) else
+                     [{'audit': None, 'audit_unavailable': 'needs the fused loop with device noise on an exact-vote engine'}] * len(targets))
+        records.append_batch(targets.tolist(), y_certified.tolist(), r_certified.tolist(), extra=extra)
         if rank == 0:
             records.flush()
             msg = 'certified %d / %d examples' % (len(records), len(test_dataset))

@@ -24,6 +24,10 @@ namespace {
 
 thread_local std::string g_err, g_warn;
 
+// WaveNet paths of an engine (dmad_wavenet_eps_path / dmad_set_waveform_tier): the mode's default (16-bit where resident), exact fp32,
+// the fp32 pipeline on split-f16 operands
+enum { PATH_DEFAULT = 0, PATH_FP32 = 1, PATH_X3 = 2 };
+
 int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -164,6 +168,7 @@ struct dmad_engine {
     bool bf16 = true, f32 = false, wn_final = false, cls_final = false;   // bf16 / f32: which WaveNet paths are resident
     int maxB32 = 0;                        // clips per exact-fp32 WaveNet pass (== maxB for DMAD_FP32, recheck_batch for DMAD_EXACT)
     int mode = DMAD_MODE_FAST;             // enum dmad_mode (DMAD_EXACT engines switch at run time)
+    int wave_tier = 2;                     // dmad_set_waveform_tier: WaveNet path of the waveform-returning entry points in DMAD_MODE_EXACT_VOTES
     float tau = 0.f;                       // recheck bound on the bf16 top-2 logit margin
     long long* rc_list = nullptr;          // global indices of the samples queued for the fp32 re-evaluation
     unsigned long long* rc_n = nullptr;    // their number (device) ...
@@ -992,13 +997,15 @@ bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, 
 }
 
 // eps = UNetModel.forward(x, t * ones)  (unet.py:453-477): x, eps [B][32][32]
-// h16 < 0: the mode's default (the 16-bit tier where it is resident, unless the engine is in DMAD_MODE_FP32); 0 / 1: explicit
+// h16 < 0: the tier of the map-returning entry points (dmad_unet_eps / dmad_unet_p_sample): the 16-bit tier in DMAD_MODE_FAST (and in
+// DMAD_MODE_EXACT_VOTES when dmad_set_waveform_tier chose the 16-bit tier), the exact-fp32 UNet otherwise — only the spec-domain vote
+// loop has a recheck, so it alone runs the 16-bit tier by default (it passes h16 = 1); 0 / 1: explicit
 int unet_eps(dmad_engine* e, const float* x, int t, int B, float* eps, hipStream_t s, int h16 = -1) {
     if (!e->un_final) return fail(DMAD_ERR_STATE, "UNet weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
     if (B < 1 || B > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d]", B, e->maxB);
     if (t < 0) return fail(DMAD_ERR_INVALID, "diffusion step %d < 0", t);
     CHK(unet_prepare_step(e, t, s));
-    if (h16 < 0) h16 = (e->un_h16 && e->mode != DMAD_MODE_FP32) ? 1 : 0;
+    if (h16 < 0) h16 = (e->un_h16 && (e->mode == DMAD_MODE_FAST || (e->mode == DMAD_MODE_EXACT_VOTES && e->wave_tier == PATH_DEFAULT))) ? 1 : 0;
     if (h16 && !e->un_h16) return fail(DMAD_ERR_STATE, "this engine has no 16-bit UNet tier (DMAD_FP32 precision)");
     if (h16) {
         int H = 32, rot = 0;
@@ -1066,7 +1073,6 @@ GemmF32Args plain_gemm(const float* A, const float* X, float* C, const float* sc
 
 // exact32: evaluate on the exact-fp32 path (the only one of a DMAD_FP32 engine; DMAD_MODE_FP32 and the recheck pass of a
 // DMAD_EXACT engine); batches larger than the fp32 workspace are walked in chunks of maxB32 clips
-enum { PATH_DEFAULT = 0, PATH_FP32 = 1, PATH_X3 = 2 };
 int wavenet_eps(dmad_engine* e, const float* x_t, int t, int B, float* eps, hipStream_t s, int path = PATH_DEFAULT) {
     if (!e->wn_final) return fail(DMAD_ERR_STATE, "WaveNet weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
     if (B < 1 || B > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d]", B, e->maxB);
@@ -1202,6 +1208,14 @@ int classify(dmad_engine* e, const float* spec, int B, float* logits, hipStream_
     }
     LASTCHK();
     return 0;
+}
+
+// WaveNet path of the entry points that hand waveforms (or logits of purified waveforms) back — dmad_wavenet_eps, dmad_one_shot,
+// dmad_ddpm_step / _purify, dmad_query_logits: the mode's own path, except that an exact-vote engine in DMAD_MODE_EXACT_VOTES serves
+// them on the tier dmad_set_waveform_tier selected (default: the split-f16 tier, fp32-grade) — only the vote loop has a recheck
+inline int wave_path(const dmad_engine* e) {
+    if (!(e->bf16 && e->f32) || e->mode != DMAD_MODE_EXACT_VOTES) return PATH_DEFAULT;
+    return e->wave_tier;
 }
 
 // the classifier tier of a vote loop's FIRST pass (and of the mode-default paths): 16-bit unless the engine is in DMAD_MODE_FP32
@@ -1414,12 +1428,12 @@ int dmad_finalize_weights(dmad_engine* e) {
 
 int dmad_wavenet_eps(dmad_engine* e, const float* x_t, int32_t t, int32_t B, float* eps, dmad_stream s) {
     if (!e || !x_t || !eps) return fail(DMAD_ERR_INVALID, "null argument");
-    return wavenet_eps(e, x_t, t, B, eps, (hipStream_t)s);
+    return wavenet_eps(e, x_t, t, B, eps, (hipStream_t)s, wave_path(e));
 }
 
 int dmad_one_shot(dmad_engine* e, const float* x_t, int32_t t, float c_a, float c_b, int32_t B, float* x0, dmad_stream s) {
     if (!e || !x_t || !x0) return fail(DMAD_ERR_INVALID, "null argument");
-    CHK(wavenet_eps(e, x_t, t, B, e->eps, (hipStream_t)s));
+    CHK(wavenet_eps(e, x_t, t, B, e->eps, (hipStream_t)s, wave_path(e)));
     launch_lincomb(0, x_t, e->eps, nullptr, c_a, c_b, 0.f, x0, (long)B * e->L, (hipStream_t)s);
     LASTCHK();
     return 0;
@@ -1428,7 +1442,7 @@ int dmad_one_shot(dmad_engine* e, const float* x_t, int32_t t, float c_a, float 
 int dmad_ddpm_step(dmad_engine* e, float* x, int32_t t, float c_eps, float c_div, float c_sig, const float* z, uint64_t seed,
                    uint64_t sample0, int32_t B, dmad_stream s) {
     if (!e || !x) return fail(DMAD_ERR_INVALID, "null argument");
-    CHK(wavenet_eps(e, x, t, B, e->eps, (hipStream_t)s));
+    CHK(wavenet_eps(e, x, t, B, e->eps, (hipStream_t)s, wave_path(e)));
     const float* zz = nullptr;
     if (c_sig != 0.f) {
         zz = z;
@@ -1548,6 +1562,17 @@ int dmad_set_mode(dmad_engine* e, int32_t mode) {
     }
     if (mode != DMAD_MODE_FAST && mode != DMAD_MODE_EXACT_VOTES && mode != DMAD_MODE_FP32) return fail(DMAD_ERR_INVALID, "unknown mode %d", mode);
     e->mode = mode;
+    return 0;
+}
+
+int dmad_set_waveform_tier(dmad_engine* e, int32_t tier) {
+    if (!e) return fail(DMAD_ERR_INVALID, "null engine");
+    if (tier != PATH_DEFAULT && tier != PATH_FP32 && tier != PATH_X3) return fail(DMAD_ERR_INVALID, "unknown waveform tier %d (0 16-bit, 1 fp32, 2 split-f16)", tier);
+    if (!(e->bf16 && e->f32)) {
+        if (tier == PATH_DEFAULT) return 0;
+        return fail(DMAD_ERR_STATE, "waveform tiers need a DMAD_EXACT engine (this one has only its %s path)", e->bf16 ? "16-bit" : "fp32");
+    }
+    e->wave_tier = tier;
     return 0;
 }
 
@@ -1801,7 +1826,7 @@ int dmad_spec_smooth_votes(dmad_engine* e, const float* clip, float sigma, int32
         const uint64_t s0 = sample0 + (uint64_t)done;
         float* sp = spec_out ? spec_out + done * 1024 : e->spec;
         float* lg = logits_out ? logits_out + done * C : e->logits;
-        CHK(spec_chain(e, job, s0, nullptr, B, -1, sp, lg, st));
+        CHK(spec_chain(e, job, s0, nullptr, B, (e->un_h16 && e->mode != DMAD_MODE_FP32) ? 1 : 0, sp, lg, st));     // first pass: the 16-bit tier
         if (recheck) {
             launch_vote_margin(lg, B, C, (unsigned long long*)counts, e->tau_spec, (long long)s0, nullptr, e->rc_list, e->rc_n, e->rc_cap, nullptr, st);
             if (done + B - queued_from + batch > e->rc_cap && done + B < n) { CHK(drain()); queued_from = done + B; }
@@ -1811,6 +1836,28 @@ int dmad_spec_smooth_votes(dmad_engine* e, const float* clip, float sigma, int32
     }
     if (recheck && n > 0) CHK(drain());
     e->st_spec_samples += n;
+    LASTCHK();
+    return 0;
+}
+
+int dmad_spec_eval_samples(dmad_engine* e, const float* clip, float sigma, int32_t t_star, float q_a, float q_b, const float* c_a,
+                           const float* c_b, const float* c_1, const float* c_2, const float* c_sig, float mel_lo, float mel_hi, uint64_t seed,
+                           const int64_t* idx, int64_t n, int32_t tier, float* logits_out, float* spec_out, dmad_stream s) {
+    if (!e || !clip || !idx || !c_a || !c_b || !c_1 || !c_2 || !c_sig || (!logits_out && !spec_out)) return fail(DMAD_ERR_INVALID, "null argument");
+    if (!e->cfg.with_classifier || !e->cls_final) return fail(DMAD_ERR_STATE, "the spec-domain chain needs the mel front-end and a finalised classifier");
+    if (!e->un_final) return fail(DMAD_ERR_STATE, "UNet weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
+    if (n < 0 || t_star < 0 || !(mel_hi > mel_lo)) return fail(DMAD_ERR_INVALID, "bad argument");
+    if (tier != 0 && tier != 1) return fail(DMAD_ERR_INVALID, "unknown UNet tier %d (0 exact fp32, 1 16-bit)", tier);
+    if (tier == 1 && !e->un_h16) return fail(DMAD_ERR_STATE, "this engine has no 16-bit UNet tier (DMAD_FP32 precision)");
+    hipStream_t st = (hipStream_t)s;
+    const int C = e->cfg.num_classes;
+    const SpecJob job{clip, sigma, t_star, q_a, q_b, c_a, c_b, c_1, c_2, c_sig, mel_lo, mel_hi, seed};
+    for (int64_t done = 0; done < n; done += e->maxB) {
+        const int B = (int)(n - done < e->maxB ? n - done : e->maxB);
+        float* sp = spec_out ? spec_out + done * 1024 : e->spec;
+        float* lg = logits_out ? logits_out + done * C : e->logits;
+        CHK(spec_chain(e, job, 0, (const long long*)idx + done, B, tier, sp, lg, st));
+    }
     LASTCHK();
     return 0;
 }
@@ -1850,12 +1897,12 @@ int dmad_query_logits(dmad_engine* e, const float* x, int32_t B, int32_t repeats
             CHK(dmad_ddpm_purify(e, e->xt, t_star, c_a, c_b, c_eps, c_div, c_sig, seed, sample0 + (uint64_t)r0, nb, e->x0, s));
             pur = e->x0;
         } else if (sampler == 2) {
-            CHK(wavenet_eps(e, e->xt, t_star - 1, nb, e->eps, st));
+            CHK(wavenet_eps(e, e->xt, t_star - 1, nb, e->eps, st, wave_path(e)));
             launch_lincomb(0, e->xt, e->eps, nullptr, c_a, c_b, 0.f, e->x0, (long)nb * L, st);
             pur = e->x0;
         }
         CHK(mel_db(e, pur, nb, e->spec, st));
-        CHK(classify(e, e->spec, nb, logits + r0 * C, st, cls_tier(e)));
+        CHK(classify(e, e->spec, nb, logits + r0 * C, st));       // the fp32 classifier, like AcousticSystem.forward's own call
         if (decisions) launch_vote(logits + r0 * C, nb, C, nullptr, decisions + r0, st);
     }
     LASTCHK();

@@ -19,6 +19,7 @@ from ._lib import DmadConfig, DmadError, check
 BF16, FP32, EXACT = 0, 1, 2                       # enum dmad_precision
 MODE_FAST, MODE_EXACT_VOTES, MODE_FP32 = 0, 1, 2  # enum dmad_mode (EXACT engines)
 HALF_BF16, HALF_F16 = 0, 1                        # enum dmad_half_type: operand format of the 16-bit MFMA path
+WAVE_16BIT, WAVE_FP32, WAVE_SPLIT = 0, 1, 2       # dmad_set_waveform_tier: WaveNet tier of the waveform-returning surfaces (EXACT engines)
 # Recheck bound of the exact-vote mode: a Monte Carlo sample whose 16-bit-path top-2 logit margin is below it is
 # re-evaluated on the higher tiers.  Let i be the exact path's arg-max and e = (16-bit logits) - (exact logits).  If the 16-bit
 # margin is >= tau and the 16-bit leader were some j != i, then l~_j - l~_i >= tau with l_j - l_i <= 0, i.e. e_j - e_i >= tau:
@@ -195,7 +196,15 @@ class Engine:
         self.classifier_kind = None
         self.mode = {BF16: MODE_FAST, FP32: MODE_FP32, EXACT: MODE_EXACT_VOTES}[precision]
         self.calibration = None                # what the last calibrate_recheck() observed
+        self.waveform_tier = WAVE_SPLIT if precision == EXACT else WAVE_16BIT
+        # what calibrations may never go below: the committed defaults, or a wider bound the caller chose (constructor / environment /
+        # a direct set_recheck_margin call)
+        self.floor1, self.floor2, self.floor_spec = DEFAULT_RECHECK_MARGIN[half_type], DEFAULT_RECHECK_MARGIN2, DEFAULT_SPEC_RECHECK_MARGIN
+        self.spec_calibration = None
         if precision == EXACT:
+            wt = os.environ.get('DMAD_WAVEFORM_TIER')
+            if wt:
+                self.set_waveform_tier({'16bit': WAVE_16BIT, 'fp32': WAVE_FP32, 'split': WAVE_SPLIT}[wt.lower()])
             if recheck_margin is None:
                 recheck_margin = float(os.environ.get('DMAD_RECHECK_MARGIN', DEFAULT_RECHECK_MARGIN[half_type]))
             self.set_recheck_margin(recheck_margin)
@@ -257,19 +266,33 @@ class Engine:
         check(self.lib.dmad_set_mode(self._h, int(mode)))
         self.mode = int(mode)
 
-    def set_recheck_margin(self, tau: float):
+    def set_waveform_tier(self, tier: int):
+        """dmad_set_waveform_tier: WaveNet tier of the waveform-returning surfaces (wavenet_eps, one_shot, ddpm_step / purify, the purifier
+        inside query_logits) of an exact-vote engine: WAVE_SPLIT (default: fp32-grade, 8e-5), WAVE_FP32, WAVE_16BIT (4e-3)."""
+        check(self.lib.dmad_set_waveform_tier(self._h, int(tier)))
+        self.waveform_tier = int(tier)
+
+    def set_recheck_margin(self, tau: float, calibrated: bool = False):
+        """bound of the 16-bit tier.  A value the CALLER sets (calibrated = False) also becomes the floor of later calibrations when it
+        is wider than the committed default: a calibration may only widen what is in force."""
         check(self.lib.dmad_set_recheck_margin(self._h, float(tau)))
         self.recheck_margin = float(tau)
+        if not calibrated:
+            self.floor1 = max(DEFAULT_RECHECK_MARGIN[self.half_type], float(tau))
 
-    def set_recheck_margin2(self, tau2: float):
+    def set_recheck_margin2(self, tau2: float, calibrated: bool = False):
         """bound of the split-f16 middle tier (< 0: tier off, queued samples go straight to the fp32 path)."""
         check(self.lib.dmad_set_recheck_margin2(self._h, float(tau2)))
         self.recheck_margin2 = float(tau2)
+        if not calibrated:
+            self.floor2 = max(DEFAULT_RECHECK_MARGIN2, float(tau2))
 
-    def set_spec_recheck_margin(self, tau: float):
+    def set_spec_recheck_margin(self, tau: float, calibrated: bool = False):
         """bound of the spec-domain vote loop's 16-bit UNet tier (dmad_set_spec_recheck_margin)."""
         check(self.lib.dmad_set_spec_recheck_margin(self._h, float(tau)))
         self.spec_recheck_margin = float(tau)
+        if not calibrated:
+            self.floor_spec = max(DEFAULT_SPEC_RECHECK_MARGIN, float(tau))
 
     def spec_recheck_stats(self, reset: bool = False):
         """-> (samples voted by spec_smooth_votes, samples whose chain was re-run on the exact-fp32 UNet) since the last reset."""
@@ -331,14 +354,60 @@ class Engine:
                 e2 = max(e2, pair_err(mid[:n_fp32].double(), ref.double()))
         finally:
             self.set_mode(mode)
-        floor1 = DEFAULT_RECHECK_MARGIN[self.half_type]
-        new2 = max(DEFAULT_RECHECK_MARGIN2, headroom * e2)
+        floor1, floor2 = self.floor1, self.floor2         # the committed defaults, or a wider bound the caller put in force
+        new2 = max(floor2, headroom * e2)
         new1 = max(floor1, headroom * e1 + new2, TAIL_Z * s1 + new2)
-        self.set_recheck_margin(new1); self.set_recheck_margin2(new2)
+        self.set_recheck_margin(new1, calibrated=True); self.set_recheck_margin2(new2, calibrated=True)
         self.calibration = {'e1': e1, 'e2': e2, 's1': s1, 'tau1': new1, 'tau2': new2, 'n': n, 'n_fp32': n_fp32, 'clips': len(clips),
-                            'headroom': headroom, 'floor1': floor1, 'floor2': DEFAULT_RECHECK_MARGIN2,
+                            'headroom': headroom, 'floor1': floor1, 'floor2': floor2,
                             'previous': (tau1, tau2)}
         return new1, new2, e1, e2
+
+    def spec_eval_samples(self, clip: torch.Tensor, sigma: float, t_star: int, q_a: float, q_b: float, c_a, c_b, c_1, c_2, c_sig,
+                          mel_lo: float, mel_hi: float, idx: torch.Tensor, tier: int, seed: int = 0, want_spec: bool = False):
+        """dmad_spec_eval_samples: logits [len(idx), C] (and the purified dB spectrograms when asked) of the spec-domain chain for
+        the Monte Carlo samples with GLOBAL indices `idx` on UNet tier 0 (exact fp32) / 1 (16-bit).  Nothing votes."""
+        clip = clip.detach().reshape(-1).contiguous().float()
+        assert clip.is_cuda and clip.numel() == self.L
+        idx = idx.detach().to(device=clip.device, dtype=torch.int64).contiguous()
+        n = idx.numel()
+        logits = torch.empty((n, self.num_classes), device=clip.device)
+        spec = torch.empty((n, 1, 32, 32), device=clip.device) if want_spec else None
+        arrs = [(C.c_float * (t_star + 1))(*[float(v) for v in a]) for a in (c_a, c_b, c_1, c_2, c_sig)]
+        check(self.lib.dmad_spec_eval_samples(self._h, _ptr(clip), float(sigma), int(t_star), float(q_a), float(q_b), arrs[0], arrs[1], arrs[2],
+                                              arrs[3], arrs[4], float(mel_lo), float(mel_hi), int(seed), _ptr(idx), int(n), int(tier),
+                                              _ptr(logits), _ptr(spec), _stream()))
+        return (logits, spec) if want_spec else logits
+
+    def calibrate_spec_recheck(self, clip, sigma: float, chain_args: tuple, n: int = 256, headroom: float = 1.5, seed: int = 0x5BECCA1):
+        """The spec-domain counterpart of calibrate_recheck: for THE RESIDENT WEIGHTS and this (sigma, t*), run n Monte Carlo samples'
+        whole chains per clip on the UNet's 16-bit tier and on its exact-fp32 tier from the same Philox keys, take the leader-difference
+        error statistic (see DEFAULT_RECHECK_MARGIN) and set
+            tau_spec = max(floor, headroom * e, TAIL_Z * s)
+        with e its largest value and s its Gaussian scale (q90 / q99 points), floor = the committed default (or a wider bound the
+        caller put in force): widen-only.  chain_args = (t_star, q_a, q_b, c_a, c_b, c_1, c_2, c_sig, mel_lo, mel_hi) as for
+        spec_smooth_votes.  Returns (tau_spec, e, s); the record is kept in self.spec_calibration."""
+        if self.precision != EXACT:
+            raise DmadError('calibrate_spec_recheck needs an EXACT engine')
+        clips = list(clip) if isinstance(clip, (list, tuple)) else [clip]
+        e = s = 0.0
+        zs = {0.9: 2.5392, 0.99: 3.2608}                  # 18 Q(z) = 1 - q (the maximum of 9 |normal differences|)
+        for ci, x in enumerate(clips):
+            idx = torch.arange(n, dtype=torch.int64, device=self.device)
+            lo = self.spec_eval_samples(x, sigma, *chain_args, idx, tier=1, seed=seed + ci).double()
+            ref = self.spec_eval_samples(x, sigma, *chain_args, idx, tier=0, seed=seed + ci).double()
+            if not (bool(torch.isfinite(lo).all()) and bool(torch.isfinite(ref).all())):
+                raise DmadError('calibrate_spec_recheck: non-finite logits')
+            d = lo - ref
+            le = (d - d.gather(1, ref.argmax(1, keepdim=True))).abs().max(1).values
+            e = max(e, float(le.max()))
+            s = max(s, max(float(torch.quantile(le, q)) / z for q, z in zs.items()))
+        previous, floor = self.spec_recheck_margin, self.floor_spec
+        new = max(floor, headroom * e, TAIL_Z * s)
+        self.set_spec_recheck_margin(new, calibrated=True)
+        self.spec_calibration = {'e': e, 's': s, 'tau_spec': new, 'n': n, 'clips': len(clips), 'headroom': headroom, 'floor': floor,
+                                 'previous': previous, 'sigma': sigma, 't_star': int(chain_args[0])}
+        return new, e, s
 
     def eval_samples(self, clip: torch.Tensor, sigma: float, sqrt_abar_star: float, t: int, c_a: float, c_b: float,
                      idx: torch.Tensor, path: int = 0, seed: int = 0, sample0: int = 0, delta: Optional[torch.Tensor] = None,

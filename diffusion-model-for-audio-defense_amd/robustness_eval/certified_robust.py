@@ -54,7 +54,7 @@ class RobustCertificate():
         self.calibrate = int(calibrate)
         self.calibrate_clips = max(1, int(calibrate_clips))
         self._calibrated = {}                   # t -> (tau1, tau2, e1, e2): the widest bounds / largest errors seen so far
-        self._calibrated_clips = {}             # t -> clips measured
+        self._calibrated_clips = {}             # t -> fingerprints of the clips measured (certify() calls smooth_predict twice per clip)
         self.log = log
         self._last = None                       # (seed, sigma, coeffs, n) of the last fused smooth_predict, for audit()
         self.audit_log = []                     # one dict per audited smooth_predict
@@ -148,20 +148,48 @@ class RobustCertificate():
         if fused and self.calibrate > 0:
             eng = self.denoiser.engine
             tk = coeffs[0]
-            if getattr(eng, 'precision', None) == 2 and self._calibrated_clips.get(tk, 0) < self.calibrate_clips:    # EXACT engines
+            seen = self._calibrated_clips.setdefault(tk, [])
+            fp = self._clip_fingerprint(x)
+            if getattr(eng, 'precision', None) == 2 and fp not in seen and len(seen) < self.calibrate_clips:    # EXACT engines, once per CLIP
                 new = eng.calibrate_recheck(x, sigma, coeffs[3], tk, coeffs[1], coeffs[2], n=self.calibrate, n_fp32=max(16, self.calibrate // 2))
                 old = self._calibrated.get(tk)
                 if old is not None:             # the bounds of a sigma only widen from clip to clip
                     new = (max(new[0], old[0]), max(new[1], old[1]), max(new[2], old[2]), max(new[3], old[3]))
-                    eng.set_recheck_margin(new[0]); eng.set_recheck_margin2(new[1])
+                    eng.set_recheck_margin(new[0], calibrated=True); eng.set_recheck_margin2(new[1], calibrated=True)
                 self._calibrated[tk] = new
-                self._calibrated_clips[tk] = self._calibrated_clips.get(tk, 0) + 1
+                seen.append(fp)
                 if self.log is not None:
                     self.log('recheck bounds at sigma=%g (t*=%d), clip %d of %d: observed 16-bit error %.4g, split-f16 error %.3g -> tau1 %.4g, tau2 %.3g'
-                             % (sigma, tk + 1, self._calibrated_clips[tk], self.calibrate_clips, new[2], new[3], new[0], new[1]))
+                             % (sigma, tk + 1, len(seen), self.calibrate_clips, new[2], new[3], new[0], new[1]))
             elif getattr(eng, 'precision', None) == 2 and tk in self._calibrated:
-                eng.set_recheck_margin(self._calibrated[tk][0]); eng.set_recheck_margin2(self._calibrated[tk][1])    # another sigma ran in between
+                eng.set_recheck_margin(self._calibrated[tk][0], calibrated=True)      # another sigma ran in between
+                eng.set_recheck_margin2(self._calibrated[tk][1], calibrated=True)
         self._last = (seed, sigma, coeffs, num_sampling) if (fused and self.noise_source == 'device') else None
+        spec_eng = self._fused_spec() if not fused else None
+        spec_args = None
+        if spec_eng is not None:
+            from diffusion_models.Improved_Diffusion_Unconditional.improved_diffusion.sc09_spectrogram_dataset import MEL_LOWER_BOUND, MEL_UPPER_BOUND
+            spec_args = tuple(self.transform.purifier.purify_coefficients()) + (MEL_LOWER_BOUND, MEL_UPPER_BOUND)
+            exact = getattr(spec_eng, 'precision', None) == 2 and spec_eng.mode == 1           # DMAD_EXACT engine in DMAD_MODE_EXACT_VOTES
+            if exact and self.calibrate > 0:        # the spec tier's bound for the resident weights at this (sigma, t*): widen-only, per clip
+                key = ('spec', spec_args[0], round(float(sigma), 6))
+                seen = self._calibrated_clips.setdefault(key, [])
+                fp = self._clip_fingerprint(x)
+                if fp not in seen and len(seen) < self.calibrate_clips:
+                    tau, e_, s_ = spec_eng.calibrate_spec_recheck(x, sigma, spec_args, n=max(64, min(self.calibrate, 512)))
+                    old = self._calibrated.get(key)
+                    if old is not None and old[0] > tau:
+                        tau = old[0]
+                        spec_eng.set_spec_recheck_margin(tau, calibrated=True)
+                    self._calibrated[key] = (tau, max(e_, old[1]) if old else e_, max(s_, old[2]) if old else s_)
+                    seen.append(fp)
+                    if self.log is not None:
+                        self.log('spec-tier recheck bound at sigma=%g (t*=%d), clip %d of %d: observed 16-bit chain error %.4g (scale %.3g) -> tau_spec %.4g'
+                                 % (sigma, spec_args[0], len(seen), self.calibrate_clips, e_, s_, tau))
+                elif key in self._calibrated:
+                    spec_eng.set_spec_recheck_margin(self._calibrated[key][0], calibrated=True)
+            if exact and self.noise_source == 'device':
+                self._last = ('spec', seed, sigma, spec_args, num_sampling)
         if self.noise_source == 'torch_cpu':
             # The reference's stream: one CPU torch.normal draw per batch (ref l.47).  The stream is batch-split invariant,
             # so every rank draws the whole stream, keeps its own slice of each batch and feeds it to the engine batch by
@@ -182,12 +210,8 @@ class RobustCertificate():
                 done += b
             if counts is None:
                 counts = torch.zeros(self.num_classes, dtype=torch.int64, device=x.device)
-        elif self._fused_spec() is not None and hi > lo:
-            from diffusion_models.Improved_Diffusion_Unconditional.improved_diffusion.sc09_spectrogram_dataset import MEL_LOWER_BOUND, MEL_UPPER_BOUND
-            pur = self.transform.purifier
-            ts, q_a, q_b, c_a, c_b, c_1, c_2, c_sig = pur.purify_coefficients()
-            counts, _, _ = self._fused_spec().spec_smooth_votes(x, sigma, ts, q_a, q_b, c_a, c_b, c_1, c_2, c_sig, MEL_LOWER_BOUND, MEL_UPPER_BOUND,
-                                                                hi - lo, batch=batch_size, seed=seed, sample0=lo)
+        elif spec_eng is not None and hi > lo:
+            counts, _, _ = spec_eng.spec_smooth_votes(x, sigma, *spec_args, hi - lo, batch=batch_size, seed=seed, sample0=lo)
         elif fused and hi > lo:
             counts, _, _ = self.denoiser.engine.smooth_votes(x, sigma, coeffs[3], coeffs[0], coeffs[1], coeffs[2], hi - lo,
                                                              seed=seed, sample0=lo)
@@ -234,6 +258,39 @@ class RobustCertificate():
             counts = torch.zeros(self.num_classes, dtype=torch.int64, device=device)
         return counts
 
+    @staticmethod
+    def _clip_fingerprint(x: torch.Tensor) -> str:
+        import hashlib
+        return hashlib.sha1(x.detach().float().cpu().contiguous().numpy().tobytes()).hexdigest()
+
+    def _audit_spec(self, x: torch.Tensor, k: int):
+        """audit() for the spec-domain loop: k samples' chains on the UNet's 16-bit tier; those that VOTED there (margin >= tau_spec)
+        re-run on the exact-fp32 UNet from the same keys."""
+        _, seed, sigma, spec_args, n = self._last
+        eng = self._fused_spec()
+        k = min(int(k), n)
+        g = torch.Generator().manual_seed(seed & 0x7FFFFFFFFFFFFFFF)
+        idx = torch.randperm(n, generator=g)[:k].sort()[0].to(x.device)
+        fast = eng.spec_eval_samples(x, sigma, *spec_args, idx, tier=1, seed=seed)
+        top2 = fast.topk(2, dim=1)
+        margin = top2.values[:, 0] - top2.values[:, 1]
+        voted = (margin >= eng.spec_recheck_margin) & torch.isfinite(fast).all(1)
+        vidx = idx[voted]
+        rec = {'audited': int(k), 'voted_on_tier1': int(vidx.numel()), 'disagreements': [], 'max_leader_diff_error': 0.0,
+               'tau_spec': eng.spec_recheck_margin, 'sigma': sigma, 'loop': 'spec'}
+        if vidx.numel():
+            ref = eng.spec_eval_samples(x, sigma, *spec_args, vidx, tier=0, seed=seed)
+            f = fast[voted]
+            e = (f - ref).double()
+            rec['max_leader_diff_error'] = float((e - e.gather(1, ref.argmax(1, keepdim=True))).abs().max())
+            bad = (f.argmax(1) != ref.argmax(1)).nonzero().reshape(-1)
+            rec['disagreements'] = [(int(vidx[j]), int(f[j].argmax()), int(ref[j].argmax()), float(margin[voted][j])) for j in bad.tolist()]
+        self.audit_log.append(rec)
+        if self.log is not None:
+            self.log('audit (spec loop): %d samples, %d voted on the 16-bit UNet tier, %d disagree with the exact-fp32 UNet, largest leader-difference '
+                     'error %.4g (tau_spec %.4g)' % (rec['audited'], rec['voted_on_tier1'], len(rec['disagreements']), rec['max_leader_diff_error'], rec['tau_spec']))
+        return rec
+
     @torch.no_grad()
     def audit(self, x: torch.Tensor, k: int):
         """Opt-in check of the exact-vote mode on the LAST fused smooth_predict(x, ...): k of its Monte Carlo samples (drawn
@@ -243,6 +300,8 @@ class RobustCertificate():
         disagreements [(sample index, tier-1 class, tier-2 class, tier-1 margin)], largest leader-difference error seen, tau1."""
         if self._last is None:
             raise RuntimeError('audit() follows a fused smooth_predict with device noise on an exact-vote engine')
+        if self._last[0] == 'spec':
+            return self._audit_spec(x, k)
         seed, sigma, coeffs, n = self._last
         eng = self.denoiser.engine
         if getattr(eng, 'precision', None) != 2:
@@ -285,8 +344,12 @@ class RobustCertificate():
             counts_0 = self.smooth_predict(x_in, num_sampling=n_0, sigma=sigma, batch_size=batch_size)
             c_A = counts_0.max(0, keepdim=True)[1].item()
             counts = self.smooth_predict(x_in, num_sampling=n, sigma=sigma, batch_size=batch_size)
-            if audit > 0 and self._last is not None:       # opt-in: re-evaluate `audit` tier-1 voters of this example on tier 2
+            if audit > 0 and self._last is not None:       # opt-in: re-evaluate `audit` tier-1 voters of this example on a higher tier
                 self.audit(x_in, audit)
+            elif audit > 0 and not getattr(self, '_audit_warned', False):
+                self._audit_warned = True
+                (self.log or print)('audit requested but unavailable for this configuration (it needs the fused loop with device noise on an '
+                                    'exact-vote engine: noise_source=%r, fused=%r): no "audit" entry will be written' % (self.noise_source, self._fused()))
             pa = self.lower_conf_bound(k=counts[c_A], n=n, alpha=alpha)
             if pa > 0.5:
                 y_pred[i] = c_A

@@ -52,7 +52,8 @@ enum dmad_half_type {
 enum dmad_mode {
     DMAD_MODE_FAST = 0,         /* 16-bit WaveNet, no recheck (what a DMAD_BF16 engine does) */
     DMAD_MODE_EXACT_VOTES = 1,  /* 16-bit WaveNet + margin-triggered recheck (split-f16 tier, then exact fp32) inside
-                                 * dmad_smooth_votes; every other entry point runs the 16-bit WaveNet */
+                                 * dmad_smooth_votes; the waveform-returning entry points run the tier dmad_set_waveform_tier
+                                 * selects (default: split-f16, fp32-grade) */
     DMAD_MODE_FP32 = 2          /* every WaveNet evaluation on the exact-fp32 path (what a DMAD_FP32 engine does) */
 };
 
@@ -170,8 +171,8 @@ int dmad_classify(dmad_engine* e, const float* spec, int32_t B, float* logits, d
  * reference's certification script (certified_robustness_eval.py:57; models/resnext.py:23-142) — also hold a 16-BIT TIER of it:
  * every conv (1x1 reduce / expand / shortcut, the grouped 3x3) on f16 operands with fp32 accumulation, the eval-mode BatchNorm
  * scale folded into the f16 weights, shift / shortcut add / ReLU in fp32, maps kept as f16 between the convs; average pool and
- * the linear head stay fp32.  Tier 1 of dmad_smooth_votes (and the mode-default paths of dmad_eval_samples / dmad_query_logits)
- * runs it unless the engine is in DMAD_MODE_FP32; the recheck tiers and dmad_classify always use the fp32 matrix cores, so a
+ * the linear head stay fp32.  Tier 1 of dmad_smooth_votes (and the mode-default path of dmad_eval_samples)
+ * runs it unless the engine is in DMAD_MODE_FP32; the recheck tiers, dmad_query_logits and dmad_classify always use the fp32 matrix cores, so a
  * re-evaluated sample's logits are the fp32 path's.  dmad_classify_tier evaluates an explicit tier (0: fp32, 1: 16-bit; VGG19_bn
  * has no 16-bit tier and is served on fp32 either way) — test / measurement hook. */
 int dmad_classify_tier(dmad_engine* e, const float* spec, int32_t B, int32_t tier, float* logits, dmad_stream s);
@@ -206,6 +207,15 @@ int dmad_smooth_votes(dmad_engine* e, const float* clip, float sigma, float sqrt
  * left the 16-bit pass, samples that reached the fp32 path.  dmad_wavenet_eps_path evaluates the eps-network on an
  * explicit path (0: the mode's default, 1: exact fp32, 2: split-f16) — test / measurement hook for the tiers. */
 int dmad_set_mode(dmad_engine* e, int32_t mode);
+/* Which WaveNet tier the WAVEFORM-returning entry points of a DMAD_EXACT engine run in DMAD_MODE_EXACT_VOTES — dmad_wavenet_eps,
+ * dmad_one_shot, dmad_ddpm_step, dmad_ddpm_purify and the purifier inside dmad_query_logits (DiffWave.forward / one_shot_denoise /
+ * compute_eps_t and AcousticSystem's query path, diffusion_models/diffwave_ddpm.py:36-47,166-182): 2 = the split-f16 tier (the DEFAULT:
+ * eps within 8e-5 of the reference's, the fp32 tolerance class, at ~3.6 x the cost of the 16-bit path), 1 = exact fp32, 0 = the 16-bit
+ * path (4e-3 with f16 operands).  Only the vote loop has a margin-triggered recheck, so these surfaces get their accuracy from the tier
+ * itself.  DMAD_MODE_FAST / DMAD_MODE_FP32 keep their meaning (16-bit / fp32 everywhere); DMAD_BF16 / DMAD_FP32 engines have one path.
+ * Tolerance delivered per surface: the vote counts of dmad_smooth_votes — exact (see below); its x0_out / logits_out rows — the tier the
+ * row voted on; the entry points above — this setting. */
+int dmad_set_waveform_tier(dmad_engine* e, int32_t tier);
 int dmad_set_recheck_margin(dmad_engine* e, float tau);
 int dmad_set_recheck_margin2(dmad_engine* e, float tau2);
 int dmad_recheck_stats(dmad_engine* e, int64_t* samples, int64_t* rechecked, int64_t* rechecked_fp32, int32_t reset);
@@ -246,14 +256,23 @@ int dmad_spec_smooth_votes(dmad_engine* e, const float* clip, float sigma, int32
 
 /* The UNet's tiers.  Engines of precision DMAD_BF16 / DMAD_EXACT hold, beside the exact-fp32 UNet, a 16-BIT TIER of it: every
  * conv / 1x1 (unet.py:107-252) on f16 operands with fp32 accumulation (v_mfma_f32_16x16x32_f16), GroupNorm, softmax, bias and
- * residual sums and the maps themselves in fp32.  dmad_unet_eps / dmad_unet_p_sample evaluate the tier the mode selects
- * (DMAD_MODE_FP32: exact fp32, otherwise the 16-bit tier; DMAD_FP32 engines have only the fp32 one).  In DMAD_MODE_EXACT_VOTES
+ * residual sums and the maps themselves in fp32.  dmad_unet_eps / dmad_unet_p_sample — map-returning surfaces without a recheck —
+ * evaluate the exact-fp32 UNet unless the engine is in DMAD_MODE_FAST (or dmad_set_waveform_tier chose the 16-bit tier): the 16-bit
+ * tier is opt-in there (DMAD_FP32 engines have only the fp32 one).  In DMAD_MODE_EXACT_VOTES
  * dmad_spec_smooth_votes runs every sample's chain on the 16-bit tier, queues the samples whose top-2 logit margin is below
  * tau_spec (dmad_set_spec_recheck_margin; default 0.4 = 1.45 x the largest leader-difference error (0.276) of the 16-bit chain measured on 6 144 samples) and re-runs their WHOLE chain on the exact-fp32
  * UNet from the same Philox keys — the same empirical guarantee as the waveform loop's (dmad_set_mode).
  * dmad_spec_recheck_stats: samples voted by dmad_spec_smooth_votes, samples whose chain was re-run in fp32. */
 int dmad_set_spec_recheck_margin(dmad_engine* e, float tau);
 int dmad_spec_recheck_stats(dmad_engine* e, int64_t* samples, int64_t* rechecked, int32_t reset);
+/* The chain of dmad_spec_smooth_votes for an explicit LIST of Monte Carlo samples on an explicit UNet tier (0: exact fp32, 1: 16-bit;
+ * the classifier is the fp32 one on tier 0): row i of logits_out [n][num_classes] / spec_out [n][32][32] (either optional) is sample
+ * idx[i] (device int64, GLOBAL indices: every draw of the row is Philox-keyed by it).  Nothing votes, no queue is touched — the hook
+ * behind the calibration of tau_spec for the resident weights (Engine.calibrate_spec_recheck) and RobustCertificate.certify(audit=k)
+ * on the spec-domain loop. */
+int dmad_spec_eval_samples(dmad_engine* e, const float* clip, float sigma, int32_t t_star, float q_a, float q_b, const float* c_a,
+                           const float* c_b, const float* c_1, const float* c_2, const float* c_sig, float mel_lo, float mel_hi, uint64_t seed,
+                           const int64_t* idx, int64_t n, int32_t tier, float* logits_out, float* spec_out, dmad_stream s);
 
 /* Batched query of the whole system for the gradient-free attack drivers: EOT.forward evaluates
  * model(x_batch.repeat(EOT_batch_size, 1, 1)) EOT_num_batches times (robustness_eval/_EOT.py:30-64; callers

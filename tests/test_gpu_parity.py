@@ -22,6 +22,7 @@ pytestmark = pytest.mark.gpu
 FP32_TOL = 2e-5
 BF16_MAX_TOL, BF16_RMS_TOL = 3e-2, 2.5e-2
 F16_MAX_TOL = 4e-3
+SPLIT_TOL = 8e-5            # the split-f16 tier (three f16 MFMAs per product): what an exact-vote engine's waveform surfaces deliver
 
 
 def relmax(got, ref):
@@ -181,13 +182,24 @@ def test_wavenet_eps_vs_reference_fixture(engines, golden_dir):
     assert relmax(got, ref) < FP32_TOL
     got = engines['bf16'].wavenet_eps(x_t, int(z['t'])).cpu().numpy()
     assert relmax(got, ref) < BF16_MAX_TOL and relrms(got, ref) < BF16_RMS_TOL
-    ex = engines['exact']                                     # the same kernels instantiated on f16 operands
-    assert ex.half_type == 1
+    from dmad_hip import engine as E
+    ex = engines['exact']                                     # the exact-vote engine: f16 operands on its 16-bit path
+    assert ex.half_type == 1 and ex.waveform_tier == E.WAVE_SPLIT
+    got = ex.wavenet_eps(x_t, int(z['t'])).cpu().numpy()      # waveform surfaces default to the split-f16 tier: fp32-grade
+    assert relmax(got, ref) < SPLIT_TOL, relmax(got, ref)
+    ex.set_waveform_tier(E.WAVE_16BIT)                        # the same kernels as the bf16 engine's, instantiated on f16 operands
     got = ex.wavenet_eps(x_t, int(z['t'])).cpu().numpy()
-    assert relmax(got, ref) < F16_MAX_TOL and relrms(got, ref) < F16_MAX_TOL
-    ex.set_mode(2)                                            # DMAD_MODE_FP32: the engine's exact-fp32 path (chunks of 4)
+    assert 1e-5 < relmax(got, ref) < F16_MAX_TOL and relrms(got, ref) < F16_MAX_TOL
+    ex.set_waveform_tier(E.WAVE_FP32)
     got = ex.wavenet_eps(x_t, int(z['t'])).cpu().numpy()
-    ex.set_mode(1)
+    assert relmax(got, ref) < FP32_TOL
+    ex.set_waveform_tier(E.WAVE_SPLIT)
+    ex.set_mode(E.MODE_FAST)                                  # DMAD_MODE_FAST: 16-bit everywhere, whatever the waveform tier says
+    got = ex.wavenet_eps(x_t, int(z['t'])).cpu().numpy()
+    assert 1e-5 < relmax(got, ref) < F16_MAX_TOL
+    ex.set_mode(E.MODE_FP32)                                  # DMAD_MODE_FP32: the engine's exact-fp32 path (chunks of 4)
+    got = ex.wavenet_eps(x_t, int(z['t'])).cpu().numpy()
+    ex.set_mode(E.MODE_EXACT_VOTES)
     assert relmax(got, ref) < FP32_TOL
 
 
@@ -207,9 +219,33 @@ def test_samplers_vs_reference_fixture(engines, sched, golden_dir):
     z = G(golden_dir, 'samplers.npz')
     hp, coef = sched
     x_t = torch.from_numpy(z['x_t']).cuda()
-    for name, tol in (('fp32', FP32_TOL), ('bf16', BF16_MAX_TOL)):
+    for name, tol in (('fp32', FP32_TOL), ('bf16', BF16_MAX_TOL), ('exact', 1e-4)):      # 'exact': the DEFAULT engine's waveform tier
         got = engines[name].one_shot(x_t, 65, *coef(65)).cpu().numpy()
         assert relmax(got, z['one_shot_t66'][:, 0]) < tol, name
+
+
+def test_default_engine_waveform_surfaces_are_fp32_grade(engines, golden_dir):
+    """north_star: "purified waveforms match within a stated fp32 tolerance".  On the DEFAULT (exact-vote) engine the mirrors'
+    waveform-returning surfaces — DiffWave.forward, one_shot_denoise, two_shot_denoise, compute_eps_t (diffwave_ddpm.py:36-47,
+    166-182,184-226) — run the split-f16 tier: within 1e-4 of the reference fixtures (the fp32 engine holds 2e-5 / 5e-5, the 16-bit
+    tier 4e-3)."""
+    from diffusion_models.diffwave_ddpm import DiffWave, WaveNetHIP
+    from diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    z, z2 = G(golden_dir, 'samplers.npz'), G(golden_dir, 'samplers2.npz')
+    hp = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    eng = engines['exact']
+    den = DiffWave(WaveNetHIP(eng), hp, reverse_timestep=66)
+    x_t = torch.from_numpy(z['x_t']).cuda()
+    assert relmax(den.one_shot_denoise(x_t).cpu().numpy(), z['one_shot_t66']) < 1e-4
+    assert relmax(den.two_shot_denoise(x_t).cpu().numpy(), z['two_shot_t66']) < 1e-4
+    for tstar in (3, 5):
+        d = DiffWave(WaveNetHIP(eng), hp, reverse_timestep=tstar, noise_source='torch_cpu')
+        torch.manual_seed(100 + tstar)
+        assert relmax(d(torch.from_numpy(z['x0']).cuda()).cpu().numpy(), z['ddpm_t%d' % tstar]) < 1e-4, tstar
+    d9 = DiffWave(WaveNetHIP(eng), hp, reverse_timestep=9, noise_source='torch_cpu')
+    torch.manual_seed(501)
+    x9 = d9._diffusion(torch.from_numpy(z2['x0']).cuda())
+    assert relmax(d9.compute_eps_t(x9, 8).cpu().numpy(), z2['eps_t9']) < 1e-4
 
 
 @pytest.mark.parametrize('tstar', [3, 5])
@@ -1409,6 +1445,68 @@ def test_config5_exact_votes_on_the_16bit_unet_tier():
     assert bool(torch.isnan(ln).all()) and cn.tolist() == [5, 0, 0, 0, 0, 0, 0, 0, 0, 0] and eng.spec_recheck_stats() == (5, 5)
     eng.set_mode(E.MODE_FP32)
     assert eng.spec_smooth_votes(*bargs, 5, batch=4, seed=1)[0].tolist() == cn.tolist()
+    eng.close()
+
+
+def test_spec_tier_calibration_and_audit(tmp_path):
+    """the spec-domain loop's bound is calibrated and auditable like the waveform loop's.  dmad_spec_eval_samples evaluates
+    listed samples' chains on an explicit UNet tier (rows equal the vote loop's logits_out rows on the same keys);
+    Engine.calibrate_spec_recheck measures the 16-bit chain's leader-difference error for the resident weights at this (sigma, t*) and
+    only WIDENS tau_spec (never below the committed default, never below a wider bound the caller put in force);
+    RobustCertificate(calibrate=n) runs it once per clip, certify(audit=k) re-runs k tier-1 voters on the exact-fp32 UNet and records
+    the outcome; the map-returning UNet surfaces of an exact-vote engine default to the fp32 tier."""
+    from audio_models.ConvNets_SpeechCommands.models.vgg import vgg19_bn
+    from diffusion_models.improved_diffusion_ddpm import create_improved_diffusion, SpecDefense
+    from dmad_hip import engine as E
+    from dmad_hip.transforms import MelSpectrogramDB
+    from robustness_eval.certified_robust import RobustCertificate
+    eng = E.Engine(max_batch=32, precision=E.EXACT, with_wavenet=False)
+    csd = synth.vgg19_bn_state_dict(4321)
+    eng.load_vgg19_bn(csd)
+    pur = create_improved_diffusion(None, reverse_timestep=4, state_dict=synth.unet_state_dict(31), engine=eng)
+    chain = tuple(pur.purify_coefficients()) + (-100.0, 38.22)
+    clip = torch.from_numpy(synth.synthetic_clip(2)).cuda()
+    # the hook reproduces the loop's rows, tier by tier
+    eng.set_mode(E.MODE_FP32)
+    _, l32, _ = eng.spec_smooth_votes(clip, 0.5, *chain, 40, seed=5, want_logits=True)
+    eng.set_mode(E.MODE_FAST)
+    _, l16, _ = eng.spec_smooth_votes(clip, 0.5, *chain, 40, seed=5, want_logits=True)
+    eng.set_mode(E.MODE_EXACT_VOTES)
+    idx = torch.tensor([3, 17, 39, 0], device='cuda')
+    assert torch.equal(eng.spec_eval_samples(clip, 0.5, *chain, idx, tier=0, seed=5), l32[idx.cpu()])
+    assert torch.equal(eng.spec_eval_samples(clip, 0.5, *chain, idx, tier=1, seed=5), l16[idx.cpu()])
+    # map-returning surfaces: fp32 tier by default on an exact-vote engine, the 16-bit tier is opt-in
+    x = torch.randn(2, 32, 32, generator=torch.Generator().manual_seed(1)).cuda()
+    e_def = eng.unet_eps(x, 3)
+    eng.set_mode(E.MODE_FP32); e_32 = eng.unet_eps(x, 3)
+    eng.set_mode(E.MODE_FAST); e_16 = eng.unet_eps(x, 3)
+    eng.set_mode(E.MODE_EXACT_VOTES)
+    assert torch.equal(e_def, e_32) and not torch.equal(e_def, e_16)
+    eng.set_waveform_tier(E.WAVE_16BIT)
+    assert torch.equal(eng.unet_eps(x, 3), e_16)
+    eng.set_waveform_tier(E.WAVE_SPLIT)
+    # calibration: widen-only
+    tau, e, s_ = eng.calibrate_spec_recheck(clip, 0.5, chain, n=96)
+    assert tau >= E.DEFAULT_SPEC_RECHECK_MARGIN and 0 < e < tau and s_ > 0 and eng.spec_recheck_margin == tau
+    assert eng.spec_calibration['floor'] == E.DEFAULT_SPEC_RECHECK_MARGIN and eng.spec_calibration['t_star'] == 4
+    eng.set_spec_recheck_margin(1.25)                        # a wider bound the caller chose is a floor, too
+    assert eng.calibrate_spec_recheck(clip, 0.5, chain, n=32)[0] >= 1.25
+    eng.set_spec_recheck_margin(E.DEFAULT_SPEC_RECHECK_MARGIN)
+    # through the mirror: one calibration per clip (certify calls smooth_predict twice per clip), an audit entry per example
+    net = vgg19_bn(num_classes=10, in_channels=1).eval()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in csd.items()})
+    net.bind_engine(eng)
+    lines = []
+    rc = RobustCertificate(classifier=net, transform=SpecDefense(MelSpectrogramDB(eng), pur), seed=3, calibrate=64, calibrate_clips=2, log=lines.append)
+    assert rc._fused_spec() is eng
+    xb = torch.stack([clip.reshape(1, -1), torch.from_numpy(synth.synthetic_clip(3)).cuda().reshape(1, -1)])
+    y, r = rc.certify(xb, torch.tensor([0, 0]).cuda(), sigma=0.5, n_0=16, n=64, batch_size=32, audit=24)
+    cal = [l for l in lines if l.startswith('spec-tier recheck bound')]
+    aud = [l for l in lines if l.startswith('audit (spec loop)')]
+    assert len(cal) == 2 and 'clip 2 of 2' in cal[1] and len(aud) == 2 and len(rc.audit_log) == 2
+    for rec in rc.audit_log:
+        assert rec['loop'] == 'spec' and rec['audited'] == 24 and 0 <= rec['voted_on_tier1'] <= 24 and rec['disagreements'] == []
+        assert rec['max_leader_diff_error'] < rec['tau_spec']
     eng.close()
 
 

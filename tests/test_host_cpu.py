@@ -479,8 +479,8 @@ def test_certificate_calibration_and_audit_host_logic():
             self.cal = [(0.040, 1.0e-3, 0.020, 1e-4), (0.036, 2.0e-3, 0.018, 9e-4), (0.9, 0.9, 0.5, 0.5)]
             self.cal_calls, self.eval_calls, self.modes = [], [], []
 
-        def set_recheck_margin(self, v): self.recheck_margin = v
-        def set_recheck_margin2(self, v): self.recheck_margin2 = v
+        def set_recheck_margin(self, v, calibrated=False): self.recheck_margin = v
+        def set_recheck_margin2(self, v, calibrated=False): self.recheck_margin2 = v
         def set_mode(self, m): self.modes.append(m); self.mode = m
 
         def calibrate_recheck(self, x, sigma, sc, t, c_a, c_b, n, n_fp32):
@@ -510,10 +510,12 @@ def test_certificate_calibration_and_audit_host_logic():
     lines = []
     rc = RobustCertificate(classifier=cls, transform=MelSpectrogramDB(eng), denoiser=den, seed=4, calibrate=16, calibrate_clips=2, log=lines.append)
     assert rc._fused()
-    x = torch.zeros(1, 16000)
+    x, x_b = torch.zeros(1, 16000), torch.full((1, 16000), 0.25)
     assert rc.smooth_predict(x, num_sampling=20, sigma=0.5, batch_size=8).tolist()[3] == 20
     assert eng.cal_calls == [(65, 16, 16)] and rc._calibrated[65] == (0.040, 1.0e-3, 0.020, 1e-4)
-    rc.smooth_predict(x, num_sampling=20, sigma=0.5, batch_size=8)                 # second clip: narrower tau1, wider tau2 -> elementwise max
+    rc.smooth_predict(x, num_sampling=20, sigma=0.5, batch_size=8)                 # the SAME clip again (certify's n pass after its n_0 pass):
+    assert eng.cal_calls == [(65, 16, 16)] and len(lines) == 1                     # measured once per clip, not once per call
+    rc.smooth_predict(x_b, num_sampling=20, sigma=0.5, batch_size=8)               # second clip: narrower tau1, wider tau2 -> elementwise max
     assert rc._calibrated[65] == (0.040, 2.0e-3, 0.020, 9e-4) and (eng.recheck_margin, eng.recheck_margin2) == (0.040, 2.0e-3)
     rc.smooth_predict(x, num_sampling=20, sigma=1.0, batch_size=8)                 # another sigma: its own calibration (third script row)
     assert eng.cal_calls[-1][0] == 116 and eng.recheck_margin == 0.9
