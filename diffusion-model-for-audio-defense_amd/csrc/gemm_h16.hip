@@ -32,6 +32,7 @@ __device__ __attribute__((aligned(128))) unsigned short g_zero_page_h[64];     /
     } while (0)
 
 thread_local int g_bad = 0;
+int g_h16_cus = 256;                            // workgroups of a persistent launch (one per CU, a multiple of 8: the XCD-aware tile walk)
 
 // grouped conv: group z of a launch is an ordinary dense problem on shifted pointers
 __device__ __forceinline__ void select_group(GemmH16Args& a, int z) {
@@ -386,6 +387,226 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------------------
+// Persistent form of the register-prefetched tile (round 4).  One workgroup per CU walks over output tiles; the 2-slot k-step ring
+// NEVER drains between them: the staging cursor runs two k-steps ahead of the compute cursor through the concatenated k-steps of
+// the workgroup's tiles, so a tile's first k-steps land while the previous tile's last ones are contracted and its epilogue
+// stores run.  What this removes is everything a tile pays around its k-loop as a workgroup of its own — dispatch of a 128-160 KiB-LDS
+// workgroup behind the previous one's store tail, the per-lane pixel arithmetic, two cold k-steps — which is most of the time of
+// the short-K launches (K = 256 1x1 / qkv convs: 4 k-steps per tile, 166-189 TFLOP/s as separate workgroups).
+// Tile walk: XCD x (blockIdx % 8) owns a contiguous range of tile ids (id = pixel tile * ny + row block, so the row blocks of one
+// pixel tile stay on one XCD: their pixel rows are L2 hits), its workgroups take the ids of that range round-robin.
+// Residual reads of the epilogue are issued right behind the k-step barrier (nothing else in flight) and retired by an explicit
+// count that leaves the next k-step's DMA pieces flying.
+// ----------------------------------------------------------------------------------------------------------------------------
+template <int BM>
+__global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, int nx) {
+    constexpr int BN = BM == 256 ? 256 : 512, AP = BM / 64, XP = BN / 64, NP = AP + XP, SLOTB = (BM + BN) * 128, WN = BN / 64;
+    constexpr int MT = BM == 256 ? 8 : 8;            // accumulator row tiles per wave (wave tile 128 x 64 in both forms)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv / WN, wn = wv % WN, q = lane >> 4, r16 = lane & 15;
+    const int ny = a.M / BM;
+    const long T = (long)nx * ny;
+    const int G8 = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7), jw = (int)(blockIdx.x >> 3);
+    const long chunk = (((T + 7) / 8 + ny - 1) / ny) * ny;          // whole pixel tiles per XCD
+    const long lo = xcd * chunk, hi = lo + chunk < T ? lo + chunk : T;
+    long ctile = lo + jw;                                            // compute cursor (tile id)
+    if (ctile >= hi) return;
+    const int my_tiles = (int)((hi - ctile + G8 - 1) / G8);
+    const int steps_per_tap = a.K / HK, nsteps = a.taps * steps_per_tap;
+    const int rloc = wv * 8 + (lane >> 3), ch8 = ((lane & 7) ^ ((rloc >> 1) & 7)) * 8;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    const unsigned voffA = (unsigned)((rloc * a.K + ch8) * 2);
+    const size_t a_piece = (size_t)64 * a.K * 2, a_tap = (size_t)a.M * a.K * 2;
+    const int st = a.stride > 1 ? a.stride : 1;
+    const int Wo = (a.W - 1) / st + 1, Ho = (a.H - 1) / st + 1, hw = Ho * Wo;
+    // ---- staging cursor: tile, tap, k-step inside the tap; per-lane pixel rows of the staging tile --------------------------
+    long stile = ctile;
+    int st_tap = 0, st_kq = 0, st_left = my_tiles * nsteps;         // k-steps not staged yet
+    int xpix[XP], xyx[XP];                                           // image base pixel (or -1: row past N), (y << 16) | x per staged row
+    int st_dy = a.taps == 9 ? -1 : 0, st_dx = st_dy;                 // the staging tap's offsets
+    const char* Ab = nullptr;
+    const char* st_a = nullptr;
+    auto tile_rows = [&](long id) {
+        const long tx = id / ny;
+        const int mb = (int)(id - tx * ny);
+        Ab = (const char*)(a.A + (size_t)mb * BM * a.K);
+        const unsigned n0 = (unsigned)tx * BN;                       // N < 2^31 (launcher): 32-bit pixel arithmetic
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+            const unsigned n = n0 + p * 64 + rloc;
+            xpix[p] = -1; xyx[p] = 0;
+            if (n < (unsigned)a.N) {
+                const unsigned b = n / (unsigned)hw, pix = n - b * (unsigned)hw, py = pix / (unsigned)Wo;
+                xpix[p] = (int)(b * (unsigned)(a.H * a.W));
+                xyx[p] = (int)(((py * st) << 16) | ((pix - py * Wo) * st));
+            }
+        }
+    };
+    auto st_advance = [&]() {                                        // after a k-step's pieces have been issued
+        --st_left;
+        if (++st_kq == steps_per_tap) {
+            st_kq = 0;
+            if (++st_tap == a.taps) {
+                st_tap = 0;
+                stile += G8;
+                if (st_left > 0) tile_rows(stile);
+            }
+            st_dy = a.taps == 9 ? st_tap / 3 - 1 : 0;
+            st_dx = a.taps == 9 ? st_tap % 3 - 1 : 0;
+        }
+        st_a = Ab + (size_t)st_tap * a_tap + (size_t)st_kq * 128;
+    };
+    const h16_t* zrow = g_zero_page_big + (lane & 7) * 8;
+    auto piece = [&](int k, unsigned slot_lds) {                     // k < XP: pixel rows (address formed here: 16 registers of state), then the AP weight pieces
+        if (k < XP) {
+            const int yy = (xyx[k] >> 16) + st_dy, xq = (xyx[k] & 0xffff) + st_dx;
+            const bool ok = xpix[k] >= 0 && (unsigned)yy < (unsigned)a.H && (unsigned)xq < (unsigned)a.W;
+            const h16_t* src = ok ? a.X + ((long)xpix[k] + yy * a.W + xq) * a.ldx + ch8 + st_kq * HK : zrow;
+            dma16v(src, slot_lds + BM * 128 + k * 8192 + wv * 1024);
+        } else {
+            dma16s(st_a + (size_t)(k - XP) * a_piece, voffA, slot_lds + (k - XP) * 8192 + wv * 1024);
+        }
+    };
+    tile_rows(stile);
+    st_a = Ab;
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int sw = (r16 >> 1) & 7;
+    const int fk[2] = {r16 * 128 + ((q ^ sw) * 16), r16 * 128 + (((4 + q) ^ sw) * 16)};
+    const int aoff = wm * 16384, boff = BM * 128 + wn * 8192;
+    f16x8 AX[4], AY[4], BP[4], BQ[4];
+    auto ldA = [&](f16x8 (&U)[4], const char* slot, int half, int kh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) U[i] = *(const f16x8*)(slot + aoff + half * 8192 + i * 2048 + fk[kh]);
+    };
+    auto ldB = [&](f16x8 (&U)[4], const char* slot, int kh) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) U[j] = *(const f16x8*)(slot + boff + j * 2048 + fk[kh]);
+    };
+#define PERS_MFMA4(AU, BU, i0, ii)                                                                                   \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                             \
+            acc[(i0) + (ii)][j_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AU[ii], BU[j_], acc[(i0) + (ii)][j_], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+    // prologue: the first two k-steps of the stream staged, the first one landed, its first units in registers
+#pragma unroll
+    for (int k = 0; k < NP; ++k) piece(k, lds0);
+    st_advance();
+    if (st_left > 0) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) piece(k, lds0 + SLOTB);
+        st_advance();
+        if (NP == 8) { GH_WAIT_BARRIER(8); } else { GH_WAIT_BARRIER(10); }
+    } else {
+        GH_WAIT_BARRIER(0);
+    }
+    ldA(AX, smem, 0, 0);
+    ldB(BP, smem, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int total = my_tiles * nsteps;
+    int s = 0;                                                       // k-step inside the compute tile
+    for (int g = 0; g < total; ++g) {
+        const char* cur = smem + (g & 1) * SLOTB;
+        const char* nxt = smem + ((g & 1) ^ 1) * SLOTB;
+        const unsigned cur_lds = lds0 + (g & 1) * SLOTB;
+        const bool last = s == nsteps - 1;
+        // phase 1: (A0, B) k0; read A1 k0
+        ldA(AY, cur, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        PERS_MFMA4(AX, BP, 0, 0); PERS_MFMA4(AX, BP, 0, 1); PERS_MFMA4(AX, BP, 0, 2); PERS_MFMA4(AX, BP, 0, 3);
+        // phase 2: (A1, B) k0; read A0 k1, B k1
+        ldA(AX, cur, 0, 1);
+        ldB(BQ, cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        PERS_MFMA4(AY, BP, 4, 0); PERS_MFMA4(AY, BP, 4, 1); PERS_MFMA4(AY, BP, 4, 2); PERS_MFMA4(AY, BP, 4, 3);
+        // phase 3: (A0, B) k1; read A1 k1
+        ldA(AY, cur, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        PERS_MFMA4(AX, BQ, 0, 0); PERS_MFMA4(AX, BQ, 0, 1); PERS_MFMA4(AX, BQ, 0, 2); PERS_MFMA4(AX, BQ, 0, 3);
+        // the next k-step of the stream has landed, every wave holds its last fragments of this slot
+        GH_WAIT_BARRIER(0);
+        // phase 4: (A1, B) k1; unless the tile ends here, read A0 k0, B k0 of the next k-step; stage the k-step after it into this slot
+        if (!last) {
+            ldA(AX, nxt, 0, 0);
+            ldB(BP, nxt, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = st_left > 0;
+        if (more) { piece(0, cur_lds); piece(1, cur_lds); if (NP == 10) piece(8, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        PERS_MFMA4(AY, BQ, 4, 0);
+        if (more) { piece(2, cur_lds); piece(3, cur_lds); if (NP == 10) piece(9, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        PERS_MFMA4(AY, BQ, 4, 1);
+        if (more) { piece(4, cur_lds); piece(5, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        PERS_MFMA4(AY, BQ, 4, 2);
+        if (more) { piece(6, cur_lds); piece(7, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        PERS_MFMA4(AY, BQ, 4, 3);
+        if (more) st_advance();
+        if (!last) { ++s; continue; }
+        // ---- the tile is complete: epilogue straight from the accumulators (the fragment registers are free here) ---------------
+        {
+            const long tx = ctile / ny;
+            const int m0 = (int)(ctile - tx * ny) * BM;
+            const long n0 = tx * BN;
+            unsigned nn[4];                                          // element offsets of the lane's four pixel rows (N * ldc < 2^31: launcher)
+            bool ok[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long n = n0 + wn * 64 + j * 16 + r16;
+                ok[j] = n < a.N;
+                nn[j] = (unsigned)((ok[j] ? n : a.N - 1) * a.ldc + m0 + wm * 128 + q * 4);
+            }
+#pragma unroll
+            for (int h2 = 0; h2 < 4; ++h2) {                         // four quarters of the wave's rows: 8 residual chunks in flight each
+                f16x4 rh[2][4];
+                if (a.res16) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) rh[i][j] = *(const f16x4*)(a.res16 + nn[j] + (h2 * 2 + i) * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ii = h2 * 2 + i;
+                    const float4 b4 = a.shift ? *(const float4*)(a.shift + m0 + wm * 128 + ii * 16 + q * 4) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 v = acc[ii][j];
+                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                        if (a.res) { const float4 rr = *(const float4*)(a.res + nn[j] + ii * 16); v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+                        if (a.res16) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (float)rh[i][j][r];
+                        }
+                        if (a.relu) v = f32x4{relu_nan(v[0]), relu_nan(v[1]), relu_nan(v[2]), relu_nan(v[3])};
+                        if (ok[j]) {
+                            if (a.C) *(float4*)(a.C + nn[j] + ii * 16) = float4{v[0], v[1], v[2], v[3]};
+                            if (a.C16) *(f16x4*)(a.C16 + nn[j] + ii * 16) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                        }
+                        acc[ii][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+        }
+        ctile += G8;
+        s = 0;
+        if (g + 1 < total) {                                         // first units of the next tile (its k-step 0 landed before the barrier above)
+            ldA(AX, nxt, 0, 0);
+            ldB(BP, nxt, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef PERS_MFMA4
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+}
+
 int gemm_h16_configure() {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_h16_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, H16_LDS);
     if (e != hipSuccess) return (int)e;
@@ -397,7 +618,15 @@ int gemm_h16_configure() {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_h16_big_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
     if (e != hipSuccess) return (int)e;
-    return (int)hipFuncSetAttribute((const void*)gemm_h16_big_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
+    e = hipFuncSetAttribute((const void*)gemm_h16_big_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
+        g_h16_cus = prop.multiProcessorCount & ~7;
+    return (int)hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
 }
 
 int gemm_h16_take_bad_shapes() { const int n = g_bad; g_bad = 0; return n; }
@@ -415,6 +644,19 @@ int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
     // whichever divides M)
     // the 256 x 256 tile where it fills the chip: >= 256 workgroups (DMAD_H16_BIG=0 switches it off: A/B runs)
     static const bool big_on = []() { const char* v = getenv("DMAD_H16_BIG"); return !(v && v[0] == '0'); }();
+    // the persistent form (DMAD_H16_PERS=0 switches it off: A/B runs): dense convs whose tiles fill the chip at least once
+    static const bool pers_on = []() { const char* v = getenv("DMAD_H16_PERS"); return !(v && v[0] == '0'); }();
+    if (pers_on && big_on && ng == 1 && !two && a.K <= BIG_KMAX && a.H < 32768 && a.W < 32768 && a.N * (long)a.ldx < (1l << 31)) {
+        const int bm = a.M % 256 == 0 ? 256 : (a.M == 128 ? 128 : 0);
+        if (bm) {
+            const long nxp = (a.N + (bm == 256 ? 255 : 511)) / (bm == 256 ? 256 : 512), tiles = nxp * (a.M / bm);
+            if (tiles >= g_h16_cus && nxp < (1l << 31) && a.N * (long)a.ldc < (1l << 31)) {
+                if (bm == 256) hipLaunchKernelGGL(gemm_h16_pers_kernel<256>, dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
+                else hipLaunchKernelGGL(gemm_h16_pers_kernel<128>, dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp);
+                return 0;
+            }
+        }
+    }
     if (big_on && !two && a.K <= BIG_KMAX && a.H < 32768 && a.W < 32768 && a.N * (long)a.ldx < (1l << 31)) {
         if (a.M % 256 == 0 && ((a.N + 255) / 256) * (a.M / 256) * ng >= 256) {
             const long nx = (a.N + 255) / 256;

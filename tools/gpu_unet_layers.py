@@ -40,7 +40,8 @@ def launches():
 
 if len(sys.argv) > 2 and sys.argv[1] == '--analyse':
     path = glob.glob(os.path.join(sys.argv[2], '**', '*kernel_trace.csv'), recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(path)) if 'gemm_f32_kernel' in r['Kernel_Name']]
+    pat = os.environ.get('KERNEL', 'gemm_f32_kernel')          # KERNEL=gemm_h16: the 16-bit tier's launches (same launch order)
+    rows = [r for r in csv.DictReader(open(path)) if pat in r['Kernel_Name']]
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     L = launches()
     rows = rows[-len(L):]
@@ -49,6 +50,11 @@ if len(sys.argv) > 2 and sys.argv[1] == '--analyse':
         us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         tot += us
         worst.append((us, fl / us / 1e6, name))
+    if os.environ.get('ALL'):                                  # every launch in launch order, with the kernel that served it
+        for (name, fl), r in zip(L, rows):
+            us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+            kn = r['Kernel_Name'].split('(')[0].replace('void dmad::', '')
+            print('%-52s %9.1f us  %6.1f TFLOP/s  %s grid %s' % (name, us, fl / us / 1e6, kn, r.get('Grid_Size', '?')))
     for us, tf, name in sorted(worst, reverse=True)[:25]:
         print('%-52s %9.1f us  %6.1f TFLOP/s' % (name, us, tf))
     print('total gemm %.1f us over %d launches; flops %.2f T -> %.1f TFLOP/s' % (tot, len(L), sum(f for _, f in L) / 1e12, sum(f for _, f in L) / tot / 1e6))
