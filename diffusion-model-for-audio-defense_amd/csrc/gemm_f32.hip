@@ -18,6 +18,7 @@
 // problem (conv zero padding, M / N tails) are fetched from a zero page.  3-slot LDS ring, counted vmcnt, one barrier
 // per k-step, no register staging.
 #include "gemm_f32.h"
+#include "gemm_x3_ablate.h"
 
 namespace dmad {
 
@@ -308,10 +309,7 @@ constexpr int X3_BM = 256, X3_PAIR = 384 * 128, X3_LDS = 3 * X3_PAIR;
 // instruction fetch one whole cache line (64-byte rows asked L2 for every line twice); the eight 16-byte chunks of a row are
 // XOR-swizzled by (row >> 1) & 7 (conflict-free ds_read_b128 under the hardware's lane groups, tools/lds_bank_check.py); lane
 // (row, q) reads chunks q and q + 4: 8 hi and 8 lo halves = one K = 32 fragment of each part, as before.
-// Compile-time switches, ablation builds only (tools/x3_ablation.sh builds them into libdmad_hip.so.<variant>; the product library
-// defines none): X3_NO_DMA / X3_ONLY_A / X3_ONLY_X (steady-state LDS-DMA off / weight pieces only / activation pieces only),
-// X3_NO_LDS (no fragment reads), X3_NO_FIX (no hi / lo register exchange), X3_NO_BARRIER, X3_NO_VMWAIT (barrier without the counted
-// vmcnt wait), X3_STAMPS (s_memtime per phase group, printed for the K = 9216 skip GEMM).  Results of such builds are meaningless.
+// The X3A_* hooks are the identity in the product build: gemm_x3_ablate.h (ablation / stamp builds of tools/x3_ablation.sh only).
 template <bool DIAG>
 __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
     constexpr int MT = 4;
@@ -346,7 +344,7 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
         voffX[p] = (unsigned)((rowoff(n) - off0 + chunk4) * 4);
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
-    bool x3_steady = false;            // (ablation builds X3_ONLY_A / X3_ONLY_X: the prologue always stages both operands)
+    bool x3_steady = false;            // false during the prologue (ablation builds that drop one operand's pieces still stage both there)
     (void)x3_steady;
     int st_tap = 0, st_kq = 0;               // staging cursor: the next pair to stage is (tap st_tap, k-pair st_kq)
     const char *st_a = Ab, *st_x = Xb;
@@ -356,12 +354,7 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
         st_x = Xb + ((long)st_tap * a.tap_stride + (long)st_kq * 32) * 4;
     };
     auto piece = [&](int k, unsigned slot_lds) {          // one of the six 8 KiB DMA pieces of the cursor's pair
-#ifdef X3_ONLY_A
-        if (k >= 4 && x3_steady) return;
-#endif
-#ifdef X3_ONLY_X
-        if (k < 4 && x3_steady) return;
-#endif
+        if (X3A_SKIP_PIECE(k, x3_steady)) return;
         if (k < 4) x3_dma16(st_a + (size_t)k * a_piece, voffA, slot_lds + k * 8192 + wv * 1024);
         else x3_dma16(st_x, voffX[k - 4], slot_lds + 32768 + (k - 4) * 8192 + wv * 1024);
     };
@@ -378,16 +371,8 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
     // 16-row tiles x (hi, lo) = 16 registers.  A tile's two chunks c0 = [hi0-3 | lo0-3], c1 = [hi4-7 | lo4-7] are read straight
     // into (H, L) and turned into H = 8 hi, L = 8 lo by exchanging two registers (`fix`), one phase after the read.
     u32x4_t AH[2][2], AL[2][2], BH[2][2], BL[2][2];
-#ifdef X3_NO_LDS
-    auto ld = [&](u32x4_t& H, u32x4_t& L, const char* tile) { asm volatile("" : "+v"(H), "+v"(L)); };
-#else
-    auto ld = [&](u32x4_t& H, u32x4_t& L, const char* tile) { H = *(const u32x4_t*)(tile + f0); L = *(const u32x4_t*)(tile + f1); };
-#endif
-#ifdef X3_NO_FIX
-    auto fix = [&](u32x4_t& H, u32x4_t& L) {};
-#else
-    auto fix = [&](u32x4_t& H, u32x4_t& L) { const unsigned x = H[2], y = H[3]; H[2] = L[0]; H[3] = L[1]; L[0] = x; L[1] = y; };
-#endif
+    auto ld = [&](u32x4_t& H, u32x4_t& L, const char* tile) { X3A_LD(H, L, tile, f0, f1); };
+    auto fix = [&](u32x4_t& H, u32x4_t& L) { X3A_FIX(H, L); };
     auto hv = [](const u32x4_t& v) { return __builtin_bit_cast(f16x8, v); };
 #define X3_MFMA(k, ah, bh)                                                                                                        \
     do {                                                                                                                           \
@@ -440,12 +425,7 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
     // p+3 go into that slot under the MFMAs of phases 3, 4.  Even and odd pairs walk the quadrants in mirrored order, so that
     // every phase replaces exactly one operand half — the one no later phase of the pair reads:
     //   even: (A0,B0) (A0,B1) | (A1,B1) (A1,B0)      odd: (A0,B1) (A0,B0) | (A1,B0) (A1,B1)
-#ifdef X3_STAMPS
-    unsigned long long x3_t[4] = {0, 0, 0, 0}, x3_prev = __builtin_amdgcn_s_memtime();
-#define X3_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); x3_t[k] += now_ - x3_prev; x3_prev = now_; } while (0)
-#else
-#define X3_STAMP(k) do {} while (0)
-#endif
+    X3A_STAMP_DECL;
     x3_steady = true;
     int slot = 0;
     for (int p = 0; p < npairs; p += 2) {
@@ -454,53 +434,34 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
         const char* L1 = smem + s1 * X3_PAIR;
         const char* L2 = smem + s2 * X3_PAIR;
         bool do_dma = false;
-        X3_STAMP(0);
+        X3A_STAMP(0);
         // ---- even pair p (slot `slot`)
         X3_PHASE(0, 0, 1, 0, 1, 1, L0, -1, 0u);                  // fix B0;  (A0,B0);  read B1(p)
         X3_PHASE(0, 1, 1, 1, 0, 1, L0, -1, 0u);                  // fix B1;  (A0,B1);  read A1(p)
-        X3_STAMP(1);
-#ifdef X3_NO_VMWAIT
-        __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier();
-#elif !defined(X3_NO_BARRIER)
-        if (p + 2 < npairs) { GF_WAIT_BARRIER(6); } else { GF_WAIT_BARRIER(0); }
-#endif
-        X3_STAMP(2);
-        do_dma = p + 3 < npairs;
-#ifdef X3_NO_DMA
-        do_dma = false;
-#endif
+        X3A_STAMP(1);
+        X3A_PAIR_BARRIER(p + 2 < npairs);
+        X3A_STAMP(2);
+        do_dma = X3A_DO_DMA(p + 3 < npairs);
         X3_PHASE(1, 1, 0, 1, 0, 0, L1, 0, lds0 + slot * X3_PAIR);    // fix A1;  (A1,B1);  read A0(p+1);  pieces 0-2 of pair p+3
         X3_PHASE(1, 0, 0, 0, 1, 1, L1, 3, lds0 + slot * X3_PAIR);    // fix A0;  (A1,B0);  read B1(p+1);  pieces 3-5
         if (do_dma) st_advance();
-        X3_STAMP(3);
+        X3A_STAMP(3);
         if (p + 1 >= npairs) break;
         // ---- odd pair p+1 (slot s1)
         do_dma = false;
         X3_PHASE(0, 1, 1, 1, 1, 0, L1, -1, 0u);                  // fix B1;  (A0,B1);  read B0(p+1)
         X3_PHASE(0, 0, 1, 0, 0, 1, L1, -1, 0u);                  // fix B0;  (A0,B0);  read A1(p+1)
-        X3_STAMP(1);
-#ifdef X3_NO_VMWAIT
-        __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier();
-#elif !defined(X3_NO_BARRIER)
-        if (p + 3 < npairs) { GF_WAIT_BARRIER(6); } else { GF_WAIT_BARRIER(0); }
-#endif
-        X3_STAMP(2);
-        do_dma = p + 4 < npairs;
-#ifdef X3_NO_DMA
-        do_dma = false;
-#endif
+        X3A_STAMP(1);
+        X3A_PAIR_BARRIER(p + 3 < npairs);
+        X3A_STAMP(2);
+        do_dma = X3A_DO_DMA(p + 4 < npairs);
         X3_PHASE(1, 0, 0, 1, 0, 0, L2, 0, lds0 + s1 * X3_PAIR);      // fix A1;  (A1,B0);  read A0(p+2);  pieces 0-2 of pair p+4
         X3_PHASE(1, 1, 0, 0, 1, 0, L2, 3, lds0 + s1 * X3_PAIR);      // fix A0;  (A1,B1);  read B0(p+2);  pieces 3-5
         if (do_dma) st_advance();
-        X3_STAMP(3);
+        X3A_STAMP(3);
         slot = s2;
     }
-#ifdef X3_STAMPS
-    if (npairs == 288 && (blockIdx.x == 100 || blockIdx.x == 1501) && lane == 0 && (wv == 0 || wv == 4 || wv == 3))
-        printf("x3 stamps block %d wave %d: loop-top %llu  ph1+2 %llu  barrier %llu  ph3+4 %llu cycles per pair\n", (int)blockIdx.x, wv,
-               x3_t[0] / 288, x3_t[1] / 288, x3_t[2] / 288, x3_t[3] / 288);
-#endif
-#undef X3_STAMP
+    X3A_STAMP_PRINT(npairs, wv, lane);
 #undef X3_PHASE
 #undef X3_MFMA
     __builtin_amdgcn_s_waitcnt(0xC07F);          // the reads past the last pair (never used) are retired before the epilogue
