@@ -22,6 +22,7 @@ pytestmark = pytest.mark.gpu
 FP32_TOL = 2e-5
 BF16_MAX_TOL, BF16_RMS_TOL = 3e-2, 2.5e-2
 F16_MAX_TOL = 4e-3
+UNET_FP32_TOL = 1e-5        # the exact-fp32 UNet tier vs the reference fixture: measured 2.6e-6 / 1.7e-6 at t = 3 / 40 (tools/gpu_unet_tolerance.py)
 SPLIT_TOL = 8e-5            # the split-f16 tier (three f16 MFMAs per product): what an exact-vote engine's waveform surfaces deliver
 
 
@@ -795,15 +796,15 @@ def test_unet_purifier_vs_reference_fixture(golden_dir):
         assert relmax(x_t.cpu().numpy(), z['x_t%d' % t]) < 1e-6
         eps = model(torch.from_numpy(z['x_t%d' % t]).cuda(), tt)
         assert eps.shape == (2, 1, 32, 32)
-        assert relmax(eps.cpu().numpy(), z['eps_t%d' % t]) < 5e-4, t
+        assert relmax(eps.cpu().numpy(), z['eps_t%d' % t]) < UNET_FP32_TOL, t
     solo = model(torch.from_numpy(z['x_t3'][1:]).cuda(), torch.tensor([3]))
     assert torch.equal(solo, model(torch.from_numpy(z['x_t3']).cuda(), torch.tensor([3, 3]))[1:])      # batch invariance
     big = model(torch.from_numpy(z['x_t3']).cuda().repeat(3, 1, 1, 1), torch.full((6,), 3))         # 6 > max_batch: chunked
     assert torch.equal(big[4:], big[:2])
     for t in (3, 0):
         r = gd.p_sample(model, torch.from_numpy(z['x_t3']).cuda(), torch.full((2,), t), noise=torch.from_numpy(z['p_noise_t%d' % t]).cuda())
-        assert float((r['pred_xstart'].cpu() - torch.from_numpy(z['p_xstart_t%d' % t])).abs().max()) < 1e-3
-        assert float((r['sample'].cpu() - torch.from_numpy(z['p_sample_t%d' % t])).abs().max()) < 1e-3
+        assert float((r['pred_xstart'].cpu() - torch.from_numpy(z['p_xstart_t%d' % t])).abs().max()) < 1e-6    # measured 1.2e-7 (values up to 0.79)
+        assert float((r['sample'].cpu() - torch.from_numpy(z['p_sample_t%d' % t])).abs().max()) < 1e-6
     out = pur(x0)                                              # diffuse to t* = 3, four reverse steps, back to dB
     again = pur(x0)
     assert out.shape == spec.shape and bool(torch.isfinite(out).all())
@@ -823,7 +824,7 @@ def test_unet_purifier_vs_reference_fixture(golden_dir):
     eng.close()
     f32 = E.Engine(max_batch=2, precision=E.FP32, with_classifier=False, with_wavenet=False)
     create_improved_diffusion(None, reverse_timestep=3, state_dict=synth.unet_state_dict(int(z['seed'])), engine=f32)
-    assert relmax(f32.unet_eps(torch.from_numpy(z['x_t3']).cuda(), 3).cpu().numpy(), z['eps_t3'][:, 0]) < 5e-4      # FP32 engines: the fp32 tier only
+    assert relmax(f32.unet_eps(torch.from_numpy(z['x_t3']).cuda(), 3).cpu().numpy(), z['eps_t3'][:, 0]) < UNET_FP32_TOL      # FP32 engines: the fp32 tier only
     f32.close()
 
 
