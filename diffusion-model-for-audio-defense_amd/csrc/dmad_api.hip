@@ -264,6 +264,10 @@ struct dmad_engine {
     h16_t* un_buf16[3] = {nullptr};
     std::vector<h16_t*> un_hs16;
     h16_t *un_t1h = nullptr, *un_t2h = nullptr, *un_uph = nullptr, *un_atth = nullptr, *un_qkvh = nullptr;
+    // GroupNorm statistics of the f16 maps, written by the GEMM that produces the map (GemmH16Args::stats): one slab per map buffer
+    float* un_st_buf[3] = {nullptr};
+    float* un_st_t2 = nullptr;
+    std::vector<float*> un_st_hs;
     float tau_spec = 0.f;                  // recheck bound of the spec-domain vote loop's 16-bit tier (dmad_set_spec_recheck_margin)
     int64_t st_spec_samples = 0, st_spec_rechecked = 0;
 
@@ -833,6 +837,14 @@ int finalize_unet(dmad_engine* e) {
             e->un_hs16.push_back(p);
         }
         for (int i = 0; i < 3; ++i) CHK(e->alloc(&e->un_buf16[i], B * 1024 * 384));
+        // statistics slabs: [pixels / 64][channels / 4][2] floats = 1 / 32 float per map value
+        for (int i = 0; i < 3; ++i) CHK(e->alloc(&e->un_st_buf[i], B * 1024 * 384 / 32));
+        CHK(e->alloc(&e->un_st_t2, B * 1024 * 256 / 32));
+        for (size_t i = 0; i < e->un_hs_ch.size(); ++i) {
+            float* p = nullptr;
+            CHK(e->alloc(&p, B * e->un_hs_hw[i] * e->un_hs_ch[i] / 32 + 64));
+            e->un_st_hs.push_back(p);
+        }
         CHK(e->alloc(&e->un_t1h, B * 1024 * 384));
         CHK(e->alloc(&e->un_t2h, B * 1024 * 256));
         CHK(e->alloc(&e->un_uph, B * 1024 * 256));
@@ -939,34 +951,49 @@ const float* unet_apply(dmad_engine* e, const dmad_engine::UnOp& o, const float*
 // softmax and the bias / residual sums in fp32; the hidden state itself exists as f16 maps ONLY (a block output costs 2 bytes per
 // value to write and 2 to read back as the next residual, against 4 + 2 and 4 with an fp32 copy beside it).  UMap::f of a block
 // output is only the identity of its buffer slot on this tier (never written or read); the network input has f alone.
-struct UMap { const float* f; const h16_t* h; };
+struct UMap { const float* f; const h16_t* h; const float* st; };      // st: the map's GroupNorm statistics slab (nullptr: none, e.g. maps of fewer than 64 pixels)
 
 GemmH16Args un_h16_args(const h16_t* A, const float* bias, const h16_t* X, float* C, h16_t* C16, int cout, int cin, int taps, int B, int H,
-                        int stride, const h16_t* res16) {
+                        int stride, const h16_t* res16, float* stats = nullptr) {
     GemmH16Args g{};
     const int Ho = (H - 1) / (stride > 1 ? stride : 1) + 1;
     g.A = A; g.X = X; g.C = C; g.C16 = C16; g.shift = bias; g.res16 = res16; g.M = cout; g.K = cin; g.taps = taps; g.ldc = cout;
     g.N = (long)B * Ho * Ho; g.H = H; g.W = H; g.ldx = cin; g.stride = stride;
+    g.stats = Ho * Ho >= 64 ? stats : nullptr;          // a 64-pixel block of the slab must lie inside one sample
     return g;
 }
 
-bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, int& H, float* dstf, h16_t* dsth, int& rot, hipStream_t s,
-                    UMap* result, UMap in2 = UMap{nullptr, nullptr}, int c1 = 0) {
+// GroupNorm of the 16-bit tier: the one-pass kernel when every part of the input carries its statistics slab, the two-pass ones otherwise
+int un_groupnorm16(UMap in, UMap in2, int c1, const float* gw, const float* gb, const float* ss, int silu, h16_t* y16, float* y32, int B, int HW,
+                   int C, hipStream_t s) {
+    static const bool fused = []() { const char* v = getenv("DMAD_GN_FUSED"); return !(v && v[0] == '0'); }();     // A/B switch
+    if (fused && in.h && in.st && (!in2.h || in2.st) && HW >= 64 &&
+        launch_groupnorm16_apply(in.h, in.st, in2.h, in2.st, c1, gw, gb, ss, silu, y16, y32, B, HW, C, s) == 0)
+        return 0;
+    return launch_groupnorm_nhwc(in.f, gw, gb, ss, silu, y32, B, HW, C, s, in2.f, c1, y16, in.h, in2.h);
+}
+
+bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, int& H, float* dstf, h16_t* dsth, float* dstst, int& rot, hipStream_t s,
+                    UMap* result, UMap in2 = UMap{nullptr, nullptr, nullptr}, int c1 = 0) {
     h16_t* SK16 = (h16_t*)e->un_buf[5];        // the skip conv's output, f16 (the fp32 tier's buffer, reused)
     h16_t *T1h = e->un_t1h, *T2h = e->un_t2h, *ATTh = e->un_atth;
     float* outf = dstf;
     h16_t* outh = dsth;
+    float* outst = dstst;
     if (!outf) {
         int r = rot; rot = (rot + 1) % 3;
         if (e->un_buf[r] == in.f) { r = rot; rot = (rot + 1) % 3; }
-        outf = e->un_buf[r]; outh = e->un_buf16[r];
+        outf = e->un_buf[r]; outh = e->un_buf16[r]; outst = e->un_st_buf[r];
     }
+    int Hout = H;
+    const UMap none{nullptr, nullptr, nullptr};
     if (o.kind == 1) {                      // ResBlock._forward, unet.py:186-199
         if (in2.f && o.cin == o.cout) { fail(DMAD_ERR_STATE, "a concatenated input needs the ResBlock's skip conv"); return false; }
-        // GroupNorm reads the f16 twins (the network input of the first block excepted: it has none); the in_layers conv writes f16 only
-        if (launch_groupnorm_nhwc(in.f, o.gn1w, o.gn1b, nullptr, 1, nullptr, B, H * H, o.cin, s, in2.f, c1, T1h, in.h, in2.h)) { gn_fail(H * H, o.cin); return false; }
-        launch_gemm_h16(un_h16_args(o.w1h, o.b1, T1h, nullptr, T2h, o.cout, o.cin, 9, B, H, 1, nullptr), s);
-        if (launch_groupnorm_nhwc(nullptr, o.gn2w, o.gn2b, e->un_ss_cur + o.ss_off, 1, nullptr, B, H * H, o.cout, s, nullptr, 0, T1h, T2h)) { gn_fail(H * H, o.cout); return false; }
+        // GroupNorm reads the f16 maps (statistics from the producing GEMM's epilogue where there is one); the in_layers conv writes f16 only
+        if (un_groupnorm16(in, in2, c1, o.gn1w, o.gn1b, nullptr, 1, T1h, nullptr, B, H * H, o.cin, s)) { gn_fail(H * H, o.cin); return false; }
+        launch_gemm_h16(un_h16_args(o.w1h, o.b1, T1h, nullptr, T2h, o.cout, o.cin, 9, B, H, 1, nullptr, e->un_st_t2), s);
+        const UMap t2{nullptr, T2h, H * H >= 64 ? e->un_st_t2 : nullptr};
+        if (un_groupnorm16(t2, none, 0, o.gn2w, o.gn2b, e->un_ss_cur + o.ss_off, 1, T1h, nullptr, B, H * H, o.cout, s)) { gn_fail(H * H, o.cout); return false; }
         const h16_t* skip = in.h;
         if (o.cin != o.cout) {
             GemmH16Args g = un_h16_args(o.skwh, o.skb, in.h, nullptr, SK16, o.cout, o.cin, 1, B, H, 1, nullptr);
@@ -974,25 +1001,28 @@ bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, 
             launch_gemm_h16(g, s);
             skip = SK16;
         }
-        launch_gemm_h16(un_h16_args(o.w2h, o.b2, T1h, nullptr, outh, o.cout, o.cout, 9, B, H, 1, skip), s);
+        launch_gemm_h16(un_h16_args(o.w2h, o.b2, T1h, nullptr, outh, o.cout, o.cout, 9, B, H, 1, skip, outst), s);
     } else if (o.kind == 2) {               // AttentionBlock._forward + QKVAttention, unet.py:225-258
         const int C = o.cin, T = H * H;
-        if (launch_groupnorm_nhwc(in.f, o.gn1w, o.gn1b, nullptr, 0, nullptr, B, T, C, s, nullptr, 0, T1h, in.h)) { gn_fail(T, C); return false; }
+        if (un_groupnorm16(in, none, 0, o.gn1w, o.gn1b, nullptr, 0, T1h, nullptr, B, T, C, s)) { gn_fail(T, C); return false; }
         if ((long)T * C > 256l * 256) { fail(DMAD_ERR_STATE, "UNet attention: %d tokens x %d channels exceed the f16 qkv buffer", T, C); return false; }
         launch_gemm_h16(un_h16_args(o.w1h, o.b1, T1h, nullptr, e->un_qkvh, 3 * C, C, 1, B, H, 1, nullptr), s);      // qkv straight to f16
         if (int rc = launch_qkv_attention_h16(e->un_qkvh, ATTh, B, T, kUnHeads, s)) { fail(rc > 0 ? DMAD_ERR_HIP : DMAD_ERR_STATE, "UNet attention (T = %d): %s", T, rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported map size"); return false; }
-        launch_gemm_h16(un_h16_args(o.w2h, o.b2, ATTh, nullptr, outh, C, C, 1, B, H, 1, in.h), s);
+        launch_gemm_h16(un_h16_args(o.w2h, o.b2, ATTh, nullptr, outh, C, C, 1, B, H, 1, in.h, outst), s);
     } else if (o.kind == 3) {               // Downsample: conv 3x3 stride 2, unet.py:82-111
-        launch_gemm_h16(un_h16_args(o.w1h, o.b1, in.h, nullptr, outh, o.cout, o.cin, 9, B, H, 2, nullptr), s);
+        launch_gemm_h16(un_h16_args(o.w1h, o.b1, in.h, nullptr, outh, o.cout, o.cin, 9, B, H, 2, nullptr, outst), s);
         H /= 2;
+        Hout = H;
     } else if (o.kind == 4) {               // Upsample: nearest x2 + conv 3x3, unet.py:49-79
         launch_upsample2x_nhwc_h16(in.h, e->un_uph, B, H, H, o.cin, s);
         H *= 2;
-        launch_gemm_h16(un_h16_args(o.w1h, o.b1, e->un_uph, nullptr, outh, o.cout, o.cin, 9, B, H, 1, nullptr), s);
-    } else {                                // input conv 1 -> 128 (direct kernel, fp32 arithmetic)
+        Hout = H;
+        launch_gemm_h16(un_h16_args(o.w1h, o.b1, e->un_uph, nullptr, outh, o.cout, o.cin, 9, B, H, 1, nullptr, outst), s);
+    } else {                                // input conv 1 -> 128 (direct kernel, fp32 arithmetic): no statistics slab
         if (launch_conv1ch_3x3(in.f, o.w1, o.b1, outf, B, o.cout, s, outh)) { fail(DMAD_ERR_STATE, "input conv: %d output channels > 128", o.cout); return false; }
+        outst = nullptr;
     }
-    *result = UMap{outf, outh};
+    *result = UMap{outf, outh, Hout * Hout >= 64 ? outst : nullptr};
     return true;
 }
 
@@ -1009,24 +1039,26 @@ int unet_eps(dmad_engine* e, const float* x, int t, int B, float* eps, hipStream
     if (h16 && !e->un_h16) return fail(DMAD_ERR_STATE, "this engine has no 16-bit UNet tier (DMAD_FP32 precision)");
     if (h16) {
         int H = 32, rot = 0;
-        UMap h{x, nullptr};
+        UMap h{x, nullptr, nullptr};
+        std::vector<const float*> hs_st(e->un_hs.size(), nullptr);      // the statistics slab each saved map ended up with (none for conv_in's / the 4x4 maps)
         for (size_t i = 0; i < e->un_in.size(); ++i)
             for (size_t j = 0; j < e->un_in[i].size(); ++j) {
                 const bool save = j + 1 == e->un_in[i].size();
-                if (!unet_apply_h16(e, e->un_in[i][j], h, B, H, save ? e->un_hs[i] : nullptr, save ? e->un_hs16[i] : nullptr, rot, s, &h)) return DMAD_ERR_STATE;
+                if (!unet_apply_h16(e, e->un_in[i][j], h, B, H, save ? e->un_hs[i] : nullptr, save ? e->un_hs16[i] : nullptr, save ? e->un_st_hs[i] : nullptr, rot, s, &h)) return DMAD_ERR_STATE;
+                if (save) hs_st[i] = h.st;
             }
-        for (auto& o : e->un_mid) if (!unet_apply_h16(e, o, h, B, H, nullptr, nullptr, rot, s, &h)) return DMAD_ERR_STATE;
+        for (auto& o : e->un_mid) if (!unet_apply_h16(e, o, h, B, H, nullptr, nullptr, nullptr, rot, s, &h)) return DMAD_ERR_STATE;
         size_t top = e->un_hs.size();
         for (auto& blk : e->un_out) {
             --top;
             const int c1 = blk[0].cin - e->un_hs_ch[top];
-            const UMap hs{e->un_hs[top], e->un_hs16[top]};
+            const UMap hs{e->un_hs[top], e->un_hs16[top], hs_st[top]};
             for (size_t j = 0; j < blk.size(); ++j) {
-                const bool ok = j == 0 ? unet_apply_h16(e, blk[0], h, B, H, nullptr, nullptr, rot, s, &h, hs, c1) : unet_apply_h16(e, blk[j], h, B, H, nullptr, nullptr, rot, s, &h);
+                const bool ok = j == 0 ? unet_apply_h16(e, blk[0], h, B, H, nullptr, nullptr, nullptr, rot, s, &h, hs, c1) : unet_apply_h16(e, blk[j], h, B, H, nullptr, nullptr, nullptr, rot, s, &h);
                 if (!ok) return DMAD_ERR_STATE;
             }
         }
-        if (launch_groupnorm_nhwc(h.f, e->un_outgw, e->un_outgb, nullptr, 1, e->un_buf[3], B, 1024, kUnMC, s, nullptr, 0, nullptr, h.h)) { gn_fail(1024, kUnMC); return DMAD_ERR_STATE; }
+        if (un_groupnorm16(h, UMap{nullptr, nullptr, nullptr}, 0, e->un_outgw, e->un_outgb, nullptr, 1, nullptr, e->un_buf[3], B, 1024, kUnMC, s)) { gn_fail(1024, kUnMC); return DMAD_ERR_STATE; }
         launch_conv3x3_c128_to1(e->un_buf[3], e->un_outw, e->un_outb, eps, B, s);
         LASTCHK();
         return 0;

@@ -19,6 +19,8 @@ struct GemmH16Args {
     int stride;           // 0/1 = 1, 2 = output (H-1)/2+1 x (W-1)/2+1
     const h16_t* X2;      // optional: channels [ksplit, K) of every pixel come from X2 (pixel pitch ldx2) — th.cat([h, skip], dim=1)
     int ksplit, ldx2;     //   of the UNet (unet.py:473) read in place; ksplit % 64 == 0
+    float* stats;         // optional [ceil(N / 64)][ldc / 4][2]: (sum, sum of squares) of the f16-ROUNDED outputs of every (64-pixel block,
+                          //   4-channel quad) — the GroupNorm statistics of the consumer, accumulated in the epilogue (groupnorm16_apply_kernel)
     int relu;             // 1: max(., 0) after bias and residual (NaN stays NaN, like torch.relu) — ResNeXt's BN-folded convs
     int groups;           // 0/1 = dense; g > 1: grouped conv (resnext.py:36-37), M and K are PER GROUP: group z reads channels
                           //   [z K, (z+1) K) of X (pixel pitch ldx), weights A + z * taps * M * K, writes channels [z M, (z+1) M) (pitch ldc)

@@ -34,6 +34,23 @@ __device__ __attribute__((aligned(128))) unsigned short g_zero_page_h[64];     /
 thread_local int g_bad = 0;
 int g_h16_cus = 256;                            // workgroups of a persistent launch (one per CU, a multiple of 8: the XCD-aware tile walk)
 
+// GroupNorm statistics in the epilogue (GemmH16Args::stats): a lane adds the four channels of its pixel of a 16 x 16 accumulator tile,
+// as the f16 values the consumer will read; stats_store reduces over the 16 pixel lanes of the quad's row group (fixed xor tree) and
+// lane 0 of the group writes the (sum, sum of squares) of the wave's 64 pixels x 4 channels.
+__device__ __forceinline__ void stats_add(float& s1, float& s2, const f32x4& v) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float t = (float)(_Float16)v[r];
+        s1 += t;
+        s2 = __builtin_fmaf(t, t, s2);
+    }
+}
+__device__ __forceinline__ void stats_store(float s1, float s2, float* stats, long blk, int quads, int quad, int r16) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (r16 == 0) *(float2*)(stats + ((size_t)blk * quads + quad) * 2) = float2{s1, s2};
+}
+
 // grouped conv: group z of a launch is an ordinary dense problem on shifted pointers
 __device__ __forceinline__ void select_group(GemmH16Args& a, int z) {
     if (a.groups > 1) {
@@ -45,6 +62,7 @@ __device__ __forceinline__ void select_group(GemmH16Args& a, int z) {
         if (a.shift) a.shift += mo;
         if (a.res) a.res += mo;
         if (a.res16) a.res16 += mo;
+        if (a.stats) a.stats += (mo >> 2) * 2;
     }
 }
 }  // namespace
@@ -176,7 +194,8 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)rh[i][j][r];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (!ok[j]) continue;
@@ -184,7 +203,10 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
             if (a.relu) v = f32x4{relu_nan(v[0]), relu_nan(v[1]), relu_nan(v[2]), relu_nan(v[3])};
             if (a.C) *(float4*)(a.C + nn[j] + i * 16) = float4{v[0], v[1], v[2], v[3]};
             if (a.C16) *(f16x4*)(a.C16 + nn[j] + i * 16) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            stats_add(s1, s2, v);
         }
+        if (a.stats) stats_store(s1, s2, a.stats, (n0 + wn * 64) >> 6, a.ldc >> 2, (m0 + wm * 64 + i * 16 + q * 4) >> 2, r16);
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------------------------
@@ -376,6 +398,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)rh[j][r];
         }
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (!ok[j]) continue;
@@ -383,7 +406,9 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
             if (a.relu) v = f32x4{relu_nan(v[0]), relu_nan(v[1]), relu_nan(v[2]), relu_nan(v[3])};
             if (a.C) *(float4*)(a.C + nn[j] + i * 16) = float4{v[0], v[1], v[2], v[3]};
             if (a.C16) *(f16x4*)(a.C16 + nn[j] + i * 16) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            stats_add(s1, s2, v);
         }
+        if (a.stats) stats_store(s1, s2, a.stats, (n0 + wn * 64) >> 6, a.ldc >> 2, (m0 + wm * 128 + i * 16 + q * 4) >> 2, r16);
     }
 }
 
@@ -576,6 +601,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
                 for (int i = 0; i < 2; ++i) {
                     const int ii = h2 * 2 + i;
                     const float4 b4 = a.shift ? *(const float4*)(a.shift + m0 + wm * 128 + ii * 16 + q * 4) : float4{0.f, 0.f, 0.f, 0.f};
+                    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         f32x4 v = acc[ii][j];
@@ -589,9 +615,11 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
                         if (ok[j]) {
                             if (a.C) *(float4*)(a.C + nn[j] + ii * 16) = float4{v[0], v[1], v[2], v[3]};
                             if (a.C16) *(f16x4*)(a.C16 + nn[j] + ii * 16) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                            stats_add(s1, s2, v);
                         }
                         acc[ii][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
+                    if (a.stats) stats_store(s1, s2, a.stats, (n0 + wn * 64) >> 6, a.ldc >> 2, (m0 + wm * 128 + ii * 16 + q * 4) >> 2, r16);
                 }
             }
         }

@@ -19,6 +19,12 @@ void launch_conv3x3_c128_to1(const float* in, const float* w, const float* bias,
 int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* ss, int silu, float* y, int B, int HW,
                           int C, hipStream_t s, const float* x2 = nullptr, int c1 = 0, h16_t* y16 = nullptr,      // y16 != nullptr: the result is written as f16 there (y unused)
                           const h16_t* x16 = nullptr, const h16_t* x2_16 = nullptr);   // x16 != nullptr: the input is read from f16 map(s) x16 (/ x2_16) instead of x (/ x2)
+// The 16-bit tier's GroupNorm as one streaming pass over an f16 map (or the two parts x [c1 channels] | x2 of a concatenated input)
+// whose statistics the producing GEMMs left in st / st2 (GemmH16Args::stats: [B * HW / 64][channels / 4][2] floats per map):
+// y = SiLU?((x - mean) * rstd * gamma + beta [* (1 + ss[c]) + ss[C + c]]) as f16 (y16) or fp32 (y32).  HW a multiple of 64.
+// Returns -1 for a map it does not serve (the caller then takes launch_groupnorm_nhwc).
+int launch_groupnorm16_apply(const h16_t* x, const float* st, const h16_t* x2, const float* st2, int c1, const float* gamma, const float* beta,
+                             const float* ss, int silu, h16_t* y16, float* y32, int B, int HW, int C, hipStream_t s);
 void launch_silu(const float* x, float* y, long n, hipStream_t s);
 // nearest-neighbour x2 (F.interpolate(scale_factor=2, mode="nearest"), unet.py:72)
 void launch_upsample2x_nhwc(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);

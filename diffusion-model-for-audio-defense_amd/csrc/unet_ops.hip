@@ -227,6 +227,80 @@ __global__ void __launch_bounds__(256) groupnorm16_stream_kernel(const h16_t* __
     }
 }
 
+// GroupNorm + SiLU (+ scale-shift) of the 16-bit tier as ONE streaming pass (round 4): the statistics come from the producing GEMMs'
+// epilogues (GemmH16Args::stats: (sum, sum of squares) per 64-pixel block and 4-channel quad of the f16 map), so this kernel only
+// sums a sample's partials (fixed order: a sample's result does not depend on the batch), folds mean / rstd / gamma / beta /
+// scale-shift into one multiplier and one addend per channel, and applies them: 16-byte loads and stores of whole pixel rows (every
+// 128-byte line touched once), where the two-pass forms above re-read their slab and move 8 bytes per lane.
+// x / x2: the map, or the two parts [c1 | C - c1 channels] of a concatenated input, each with the slab of the GEMM that wrote it;
+// workgroup = (sample, one of `wps` pixel ranges), 256 threads (192 for C = 384: a multiple of the C / 8 octets per pixel).
+__global__ void __launch_bounds__(256) groupnorm16_apply_kernel(const h16_t* __restrict__ x, const h16_t* __restrict__ x2, int c1,
+                                                                const float* __restrict__ st1, const float* __restrict__ st2,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ ss, int silu, h16_t* __restrict__ y16,
+                                                                float* __restrict__ y32, int HW, int C, int wps) {
+    __shared__ float mulc[512], addc[512], gsum[2][32];
+    const int NT = blockDim.x, t = threadIdx.x;
+    const int b = blockIdx.x / wps, part = blockIdx.x - b * wps;
+    const int cpg = C >> 5, qpg = cpg >> 2, nblk = HW >> 6;
+    const int ca = x2 ? c1 : C, cb = C - ca;                         // channels of the first / second part
+    {   // group sums: 8 threads per group, entry e = (pixel block, quad of the group), fixed xor tree over the 8
+        const int k = t & 7, entries = nblk * qpg;
+        for (int g = t >> 3; g < 32; g += NT >> 3) {                 // (a wave's 8 groups are all below 32 or all above: uniform trip count)
+            float s1 = 0.f, s2 = 0.f;
+            for (int e = k; e < entries; e += 8) {
+                const int blk = e / qpg, quad = g * qpg + (e - blk * qpg);
+                const float2 v = (4 * quad < ca) ? *(const float2*)(st1 + ((size_t)(b * nblk + blk) * (ca >> 2) + quad) * 2)
+                                                 : *(const float2*)(st2 + ((size_t)(b * nblk + blk) * (cb >> 2) + (quad - (ca >> 2))) * 2);
+                s1 += v.x; s2 += v.y;
+            }
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            if (k == 0) { gsum[0][g] = s1; gsum[1][g] = s2; }
+        }
+    }
+    __syncthreads();
+    const float n = (float)(cpg * HW);
+    for (int c = t; c < C; c += NT) {
+        const int g = c / cpg;
+        const float mean = gsum[0][g] / n;
+        const float var = fmaxf(gsum[1][g] / n - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        float m = rstd * gamma[c], a = beta[c] - mean * m;
+        if (ss) { const float sc = 1.f + ss[c]; m *= sc; a = a * sc + ss[C + c]; }
+        mulc[c] = m; addc[c] = a;
+    }
+    __syncthreads();
+    const int opp = C >> 3, o = t % opp, ppp = NT / opp;             // octets per pixel, this thread's octet, pixels per pass
+    const int c0 = o * 8;
+    const bool second = x2 && c0 >= ca;
+    const h16_t* src = second ? x2 + (size_t)b * HW * cb + (c0 - ca) : x + (size_t)b * HW * ca + c0;
+    const int pitch = second ? cb : ca;
+    float mu[8], ad[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { mu[r] = mulc[c0 + r]; ad[r] = addc[c0 + r]; }
+    const int per = HW / wps, p_lo = part * per, p_hi = p_lo + per;
+    const size_t obase = (size_t)b * HW * C + c0;
+#pragma unroll 4
+    for (int pix = p_lo + t / opp; pix < p_hi; pix += ppp) {
+        const f16x8 hv = *(const f16x8*)(src + (size_t)pix * pitch);
+        float u[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float w = __builtin_fmaf((float)hv[r], mu[r], ad[r]);
+            if (silu) w = w * fast_rcp(1.f + fast_exp2(w * -1.4426950408889634f));
+            u[r] = w;
+        }
+        if (y16) {
+            *(f16x8*)(y16 + obase + (size_t)pix * C) = f16x8{(_Float16)u[0], (_Float16)u[1], (_Float16)u[2], (_Float16)u[3],
+                                                             (_Float16)u[4], (_Float16)u[5], (_Float16)u[6], (_Float16)u[7]};
+        } else {
+            *(float4*)(y32 + obase + (size_t)pix * C) = float4{u[0], u[1], u[2], u[3]};
+            *(float4*)(y32 + obase + (size_t)pix * C + 4) = float4{u[4], u[5], u[6], u[7]};
+        }
+    }
+}
+
 __global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const float v = x[i]; y[i] = v / (1.f + expf(-v)); }
@@ -518,6 +592,15 @@ int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta,
     else if (per <= 16) GN_LAUNCH(16);
     else return -1;                                 // larger than any map of this network (32x32 x 384 channels)
 #undef GN_LAUNCH
+    return 0;
+}
+int launch_groupnorm16_apply(const h16_t* x, const float* st, const h16_t* x2, const float* st2, int c1, const float* gamma, const float* beta,
+                             const float* ss, int silu, h16_t* y16, float* y32, int B, int HW, int C, hipStream_t s) {
+    if (C % 128 || C < 128 || C > 512 || B < 1 || HW < 64 || (HW & 63) || !x || !st || (!y16 && !y32)) return -1;
+    if (x2 && (!st2 || c1 < 8 || c1 >= C || (c1 & 7))) return -1;
+    const int wps = HW >= 1024 ? HW / 256 : 1;                      // 256 pixels per workgroup on the large maps, a whole sample otherwise
+    const int nt = C == 384 ? 192 : 256;
+    hipLaunchKernelGGL(groupnorm16_apply_kernel, dim3((unsigned)(B * wps)), dim3(nt), 0, s, x, x2, c1, st, st2, gamma, beta, ss, silu, y16, y32, HW, C, wps);
     return 0;
 }
 void launch_silu(const float* x, float* y, long n, hipStream_t s) {
