@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
 // Residual reads of the epilogue are issued right behind the k-step barrier (nothing else in flight) and retired by an explicit
 // count that leaves the next k-step's DMA pieces flying.
 // ----------------------------------------------------------------------------------------------------------------------------
-template <int BM>
+template <int BM, bool WIDE>      // WIDE: f16 map out, no fp32 output / residual (the epilogue with 16-byte stores); else the plain epilogue
 __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, int nx) {
     constexpr int BN = BM == 256 ? 256 : 512, AP = BM / 64, XP = BN / 64, NP = AP + XP, SLOTB = (BM + BN) * 128, WN = BN / 64;
     constexpr int MT = BM == 256 ? 8 : 8;            // accumulator row tiles per wave (wave tile 128 x 64 in both forms)
@@ -580,47 +580,96 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
             const long tx = ctile / ny;
             const int m0 = (int)(ctile - tx * ny) * BM;
             const long n0 = tx * BN;
-            unsigned nn[4];                                          // element offsets of the lane's four pixel rows (N * ldc < 2^31: launcher)
+            unsigned nrow[4];                                        // element offset of the lane's four pixel rows (N * ldc < 2^31: launcher)
             bool ok[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const long n = n0 + wn * 64 + j * 16 + r16;
                 ok[j] = n < a.N;
-                nn[j] = (unsigned)((ok[j] ? n : a.N - 1) * a.ldc + m0 + wm * 128 + q * 4);
+                nrow[j] = (unsigned)((ok[j] ? n : a.N - 1) * a.ldc);
             }
+            const int mw = m0 + wm * 128;                            // first output channel of this wave
+            if constexpr (WIDE) {
+                // f16 map out (the common case): 16-BYTE stores.  A lane holds 4 channels x 1 pixel per accumulator tile (8 bytes as f16);
+                // lanes q / q ^ 1 exchange halves (one v_permlane16_swap per dword) so that every lane ends up with 8 consecutive
+                // channels — even q: of row tile 2p, odd q: of row tile 2p + 1 — and a row tile pair costs one 16-byte store per pixel
+                // block instead of two 8-byte ones (the epilogue of a short-K tile is bound by the NUMBER of its store instructions:
+                // 32 per lane were ~9 us of a 17 us K = 256 tile).  The f16 residual is fetched in the same chunks and un-swapped.
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #pragma unroll
-            for (int h2 = 0; h2 < 4; ++h2) {                         // four quarters of the wave's rows: 8 residual chunks in flight each
-                f16x4 rh[2][4];
-                if (a.res16) {
+                for (int p = 0; p < 4; ++p) {                        // row tile pairs (2p, 2p + 1)
+                    const int t0 = 2 * p, t1 = t0 + 1;
+                    const unsigned coff = (unsigned)(mw + (t0 + (q & 1)) * 16 + (q >> 1) * 8);
+                    constexpr int JB = BM == 256 ? 4 : 2;              // residual chunks in flight (the 128 x 512 form has 16 more registers of staging state)
+                    u32x4 rc[JB];
+                    const float4 z4 = float4{0.f, 0.f, 0.f, 0.f};
+                    const float4 b0 = a.shift ? *(const float4*)(a.shift + mw + t0 * 16 + q * 4) : z4;
+                    const float4 b1 = a.shift ? *(const float4*)(a.shift + mw + t1 * 16 + q * 4) : z4;
+                    float s10 = 0.f, s20 = 0.f, s11 = 0.f, s21 = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int j = 0; j < 4; ++j) {
+                        if (a.res16 && j % JB == 0) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) rh[i][j] = *(const f16x4*)(a.res16 + nn[j] + (h2 * 2 + i) * 16);
+                            for (int jj = 0; jj < JB; ++jj) rc[jj] = *(const u32x4*)(a.res16 + nrow[j + jj] + coff);
+                        }
+                        f32x4 v0 = acc[t0][j], v1 = acc[t1][j];
+                        v0[0] += b0.x; v0[1] += b0.y; v0[2] += b0.z; v0[3] += b0.w;
+                        v1[0] += b1.x; v1[1] += b1.y; v1[2] += b1.z; v1[3] += b1.w;
+                        if (a.res16) {
+                            const auto h0 = __builtin_amdgcn_permlane16_swap(rc[j % JB][0], rc[j % JB][2], false, false);
+                            const auto h1 = __builtin_amdgcn_permlane16_swap(rc[j % JB][1], rc[j % JB][3], false, false);
+                            const f16x4 hx = __builtin_bit_cast(f16x4, u32x2{h0[0], h1[0]}), hy = __builtin_bit_cast(f16x4, u32x2{h0[1], h1[1]});
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { v0[r] += (float)hx[r]; v1[r] += (float)hy[r]; }
+                        }
+                        if (a.relu) {
+                            v0 = f32x4{relu_nan(v0[0]), relu_nan(v0[1]), relu_nan(v0[2]), relu_nan(v0[3])};
+                            v1 = f32x4{relu_nan(v1[0]), relu_nan(v1[1]), relu_nan(v1[2]), relu_nan(v1[3])};
+                        }
+                        if (ok[j]) { stats_add(s10, s20, v0); stats_add(s11, s21, v1); }
+                        const u32x2 ox = __builtin_bit_cast(u32x2, f16x4{(_Float16)v0[0], (_Float16)v0[1], (_Float16)v0[2], (_Float16)v0[3]});
+                        const u32x2 oy = __builtin_bit_cast(u32x2, f16x4{(_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]});
+                        const auto x0 = __builtin_amdgcn_permlane16_swap(ox[0], oy[0], false, false);
+                        const auto x1 = __builtin_amdgcn_permlane16_swap(ox[1], oy[1], false, false);
+                        if (ok[j]) *(u32x4*)(a.C16 + nrow[j] + coff) = u32x4{x0[0], x1[0], x0[1], x1[1]};
+                        acc[t0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc[t1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    if (a.stats) {
+                        stats_store(s10, s20, a.stats, (n0 + wn * 64) >> 6, a.ldc >> 2, (mw + t0 * 16 + q * 4) >> 2, r16);
+                        stats_store(s11, s21, a.stats, (n0 + wn * 64) >> 6, a.ldc >> 2, (mw + t1 * 16 + q * 4) >> 2, r16);
+                    }
                 }
+            } else {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int ii = h2 * 2 + i;
-                    const float4 b4 = a.shift ? *(const float4*)(a.shift + m0 + wm * 128 + ii * 16 + q * 4) : float4{0.f, 0.f, 0.f, 0.f};
+                for (int ii = 0; ii < MT; ++ii) {                    // fp32 map out and / or fp32 residual (rare: a classifier's last block): plain form
+                    const float4 b4 = a.shift ? *(const float4*)(a.shift + mw + ii * 16 + q * 4) : float4{0.f, 0.f, 0.f, 0.f};
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
+                        const unsigned off = nrow[j] + mw + ii * 16 + q * 4;
                         f32x4 v = acc[ii][j];
                         v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-                        if (a.res) { const float4 rr = *(const float4*)(a.res + nn[j] + ii * 16); v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+                        if (a.res) { const float4 rr = *(const float4*)(a.res + off); v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
                         if (a.res16) {
+                            const f16x4 rh = *(const f16x4*)(a.res16 + off);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += (float)rh[i][j][r];
+                            for (int r = 0; r < 4; ++r) v[r] += (float)rh[r];
                         }
                         if (a.relu) v = f32x4{relu_nan(v[0]), relu_nan(v[1]), relu_nan(v[2]), relu_nan(v[3])};
                         if (ok[j]) {
-                            if (a.C) *(float4*)(a.C + nn[j] + ii * 16) = float4{v[0], v[1], v[2], v[3]};
-                            if (a.C16) *(f16x4*)(a.C16 + nn[j] + ii * 16) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                            if (a.C) *(float4*)(a.C + off) = float4{v[0], v[1], v[2], v[3]};
+                            if (a.C16) *(f16x4*)(a.C16 + off) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                             stats_add(s1, s2, v);
                         }
-                        acc[ii][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
-                    if (a.stats) stats_store(s1, s2, a.stats, (n0 + wn * 64) >> 6, a.ldc >> 2, (m0 + wm * 128 + ii * 16 + q * 4) >> 2, r16);
+                    if (a.stats) stats_store(s1, s2, a.stats, (n0 + wn * 64) >> 6, a.ldc >> 2, (mw + ii * 16 + q * 4) >> 2, r16);
                 }
+#pragma unroll
+                for (int ii = 0; ii < MT; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ii][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
         ctile += G8;
@@ -648,13 +697,17 @@ int gemm_h16_configure() {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_h16_big_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
+    e = hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
     if (e != hipSuccess) return (int)e;
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
         g_h16_cus = prop.multiProcessorCount & ~7;
-    return (int)hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
+    return (int)hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
 }
 
 int gemm_h16_take_bad_shapes() { const int n = g_bad; g_bad = 0; return n; }
@@ -679,8 +732,11 @@ int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
         if (bm) {
             const long nxp = (a.N + (bm == 256 ? 255 : 511)) / (bm == 256 ? 256 : 512), tiles = nxp * (a.M / bm);
             if (tiles >= g_h16_cus && nxp < (1l << 31) && a.N * (long)a.ldc < (1l << 31)) {
-                if (bm == 256) hipLaunchKernelGGL(gemm_h16_pers_kernel<256>, dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
-                else hipLaunchKernelGGL(gemm_h16_pers_kernel<128>, dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp);
+                const bool wide = a.C16 && !a.C && !a.res && !(a.ldc & 7);
+                if (bm == 256 && wide) hipLaunchKernelGGL((gemm_h16_pers_kernel<256, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
+                else if (bm == 256) hipLaunchKernelGGL((gemm_h16_pers_kernel<256, false>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
+                else if (wide) hipLaunchKernelGGL((gemm_h16_pers_kernel<128, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp);
+                else hipLaunchKernelGGL((gemm_h16_pers_kernel<128, false>), dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp);
                 return 0;
             }
         }
