@@ -174,6 +174,7 @@ def main():
     ap.add_argument('--grid-steps', type=int, default=4)
     ap.add_argument('--resnext-steps', type=int, default=6, help='timed steps of the ResNeXt29 leg (the reference script\'s default classifier on an '
                                                                  'exact-vote engine of its own, ~30 s incl. the engine build); 0 = skip')
+    ap.add_argument('--c5-batch', type=int, default=2048, help='engine batch of the C5 leg (spectrograms per UNet evaluation; ~45 GB of HBM at 2048)')
     ap.add_argument('--classifier', choices=['vgg19_bn', 'resnext29'], default='vgg19_bn',
                     help='vgg19_bn = the configuration BASELINE.json names; resnext29 = the reference script\'s default classifier')
     args = ap.parse_args()
@@ -439,7 +440,7 @@ def main():
         # mel-dB -> standardise -> q_sample(t*) -> 26 UNet evaluations -> classifier) on an engine of its own without WaveNet workspace,
         # in the exact-vote mode (UNet chain on the 16-bit tier, low-margin samples re-run on the exact-fp32 UNet)
         from diffusion_models.improved_diffusion_ddpm import create_improved_diffusion
-        c5_b, c5_t = 512, 25                    # engine batch 512 like the headline
+        c5_b, c5_t = args.c5_batch, 25          # engine batch 2048: the 8x8 / 4x4 maps of the UNet fill the chip (512 -> 2048: + 11 %, same votes)
         eng5 = E.Engine(max_batch=c5_b, precision=E.EXACT, recheck_batch=0, with_wavenet=False)
         eng5.load_vgg19_bn(csd)
         pur = create_improved_diffusion(None, reverse_timestep=c5_t, state_dict=synth.unet_state_dict(31), engine=eng5)
@@ -465,7 +466,7 @@ def main():
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 dt5 = float(tmax.item())
             return dt5, cnt.cpu().tolist(), eng5.spec_recheck_stats()
-        n32 = max(1, min(args.c5_n, 512))                                    # the exact-fp32 leg: the same first keys, fewer of them
+        n32 = max(1, min(args.c5_n, 1024))                                   # the exact-fp32 leg: the same first keys, fewer of them
         c5_dt, c5_counts, (c5_voted, c5_re) = c5_run(E.MODE_EXACT_VOTES, args.c5_n)
         f_dt, f_counts, _ = c5_run(E.MODE_FAST, n32)
         x_dt, x_counts, _ = c5_run(E.MODE_EXACT_VOTES, n32)

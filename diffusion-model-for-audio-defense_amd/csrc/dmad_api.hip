@@ -959,7 +959,8 @@ GemmH16Args un_h16_args(const h16_t* A, const float* bias, const h16_t* X, float
     const int Ho = (H - 1) / (stride > 1 ? stride : 1) + 1;
     g.A = A; g.X = X; g.C = C; g.C16 = C16; g.shift = bias; g.res16 = res16; g.M = cout; g.K = cin; g.taps = taps; g.ldc = cout;
     g.N = (long)B * Ho * Ho; g.H = H; g.W = H; g.ldx = cin; g.stride = stride;
-    g.stats = Ho * Ho >= 64 ? stats : nullptr;          // a 64-pixel block of the slab must lie inside one sample
+    g.stats = Ho * Ho >= 16 ? stats : nullptr;          // a statistics block must lie inside one sample: 64 pixels, or 16 on the 4 x 4 maps
+    g.stats_px = Ho * Ho >= 64 ? 64 : 16;
     return g;
 }
 
@@ -967,7 +968,7 @@ GemmH16Args un_h16_args(const h16_t* A, const float* bias, const h16_t* X, float
 int un_groupnorm16(UMap in, UMap in2, int c1, const float* gw, const float* gb, const float* ss, int silu, h16_t* y16, float* y32, int B, int HW,
                    int C, hipStream_t s) {
     static const bool fused = []() { const char* v = getenv("DMAD_GN_FUSED"); return !(v && v[0] == '0'); }();     // A/B switch
-    if (fused && in.h && in.st && (!in2.h || in2.st) && HW >= 64 &&
+    if (fused && in.h && in.st && (!in2.h || in2.st) && HW >= 16 &&
         launch_groupnorm16_apply(in.h, in.st, in2.h, in2.st, c1, gw, gb, ss, silu, y16, y32, B, HW, C, s) == 0)
         return 0;
     return launch_groupnorm_nhwc(in.f, gw, gb, ss, silu, y32, B, HW, C, s, in2.f, c1, y16, in.h, in2.h);
@@ -992,7 +993,7 @@ bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, 
         // GroupNorm reads the f16 maps (statistics from the producing GEMM's epilogue where there is one); the in_layers conv writes f16 only
         if (un_groupnorm16(in, in2, c1, o.gn1w, o.gn1b, nullptr, 1, T1h, nullptr, B, H * H, o.cin, s)) { gn_fail(H * H, o.cin); return false; }
         launch_gemm_h16(un_h16_args(o.w1h, o.b1, T1h, nullptr, T2h, o.cout, o.cin, 9, B, H, 1, nullptr, e->un_st_t2), s);
-        const UMap t2{nullptr, T2h, H * H >= 64 ? e->un_st_t2 : nullptr};
+        const UMap t2{nullptr, T2h, H * H >= 16 ? e->un_st_t2 : nullptr};
         if (un_groupnorm16(t2, none, 0, o.gn2w, o.gn2b, e->un_ss_cur + o.ss_off, 1, T1h, nullptr, B, H * H, o.cout, s)) { gn_fail(H * H, o.cout); return false; }
         const h16_t* skip = in.h;
         if (o.cin != o.cout) {
@@ -1022,7 +1023,7 @@ bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, 
         if (launch_conv1ch_3x3(in.f, o.w1, o.b1, outf, B, o.cout, s, outh)) { fail(DMAD_ERR_STATE, "input conv: %d output channels > 128", o.cout); return false; }
         outst = nullptr;
     }
-    *result = UMap{outf, outh, Hout * Hout >= 64 ? outst : nullptr};
+    *result = UMap{outf, outh, Hout * Hout >= 16 ? outst : nullptr};
     return true;
 }
 
@@ -1058,8 +1059,8 @@ int unet_eps(dmad_engine* e, const float* x, int t, int B, float* eps, hipStream
                 if (!ok) return DMAD_ERR_STATE;
             }
         }
-        if (un_groupnorm16(h, UMap{nullptr, nullptr, nullptr}, 0, e->un_outgw, e->un_outgb, nullptr, 1, nullptr, e->un_buf[3], B, 1024, kUnMC, s)) { gn_fail(1024, kUnMC); return DMAD_ERR_STATE; }
-        launch_conv3x3_c128_to1(e->un_buf[3], e->un_outw, e->un_outb, eps, B, s);
+        if (un_groupnorm16(h, UMap{nullptr, nullptr, nullptr}, 0, e->un_outgw, e->un_outgb, nullptr, 1, e->un_t1h, nullptr, B, 1024, kUnMC, s)) { gn_fail(1024, kUnMC); return DMAD_ERR_STATE; }
+        launch_conv3x3_c128_to1_h16(e->un_t1h, e->un_outw, e->un_outb, eps, B, s);       // (operands f16, fp32 accumulate, like the tier's GEMMs)
         LASTCHK();
         return 0;
     }

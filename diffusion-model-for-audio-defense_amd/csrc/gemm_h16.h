@@ -21,6 +21,8 @@ struct GemmH16Args {
     int ksplit, ldx2;     //   of the UNet (unet.py:473) read in place; ksplit % 64 == 0
     float* stats;         // optional [ceil(N / 64)][ldc / 4][2]: (sum, sum of squares) of the f16-ROUNDED outputs of every (64-pixel block,
                           //   4-channel quad) — the GroupNorm statistics of the consumer, accumulated in the epilogue (groupnorm16_apply_kernel)
+    int stats_px;         // pixels per statistics block: 0 / 64 (a wave's 64 pixel rows) or 16 (maps of 16 pixels per sample: 4 x 4; served by
+                          //   the 384-row kernel only) — the slab is then [ceil(N / 16)][ldc / 4][2]
     int relu;             // 1: max(., 0) after bias and residual (NaN stays NaN, like torch.relu) — ResNeXt's BN-folded convs
     int groups;           // 0/1 = dense; g > 1: grouped conv (resnext.py:36-37), M and K are PER GROUP: group z reads channels
                           //   [z K, (z+1) K) of X (pixel pitch ldx), weights A + z * taps * M * K, writes channels [z M, (z+1) M) (pitch ldc)

@@ -205,7 +205,19 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
             if (a.C16) *(f16x4*)(a.C16 + nn[j] + i * 16) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             stats_add(s1, s2, v);
         }
-        if (a.stats) stats_store(s1, s2, a.stats, (n0 + wn * 64) >> 6, a.ldc >> 2, (m0 + wm * 64 + i * 16 + q * 4) >> 2, r16);
+        if (a.stats && a.stats_px != 16) stats_store(s1, s2, a.stats, (n0 + wn * 64) >> 6, a.ldc >> 2, (m0 + wm * 64 + i * 16 + q * 4) >> 2, r16);
+    }
+    if (a.stats && a.stats_px == 16) {          // 16-pixel samples (4 x 4 maps): one statistics block per 16 x 16 accumulator tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s1 = 0.f, s2 = 0.f;
+                f32x4 v = acc[i][j];
+                if (a.relu) v = f32x4{relu_nan(v[0]), relu_nan(v[1]), relu_nan(v[2]), relu_nan(v[3])};
+                if (ok[j]) stats_add(s1, s2, v);
+                stats_store(s1, s2, a.stats, (n0 + wn * 64 + j * 16) >> 4, a.ldc >> 2, (m0 + wm * 64 + i * 16 + q * 4) >> 2, r16);
+            }
     }
 }
 
@@ -727,7 +739,9 @@ int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
     static const bool big_on = []() { const char* v = getenv("DMAD_H16_BIG"); return !(v && v[0] == '0'); }();
     // the persistent form (DMAD_H16_PERS=0 switches it off: A/B runs): dense convs whose tiles fill the chip at least once
     static const bool pers_on = []() { const char* v = getenv("DMAD_H16_PERS"); return !(v && v[0] == '0'); }();
-    if (pers_on && big_on && ng == 1 && !two && a.K <= BIG_KMAX && a.H < 32768 && a.W < 32768 && a.N * (long)a.ldx < (1l << 31)) {
+    const bool st16 = a.stats && a.stats_px == 16;           // 16-pixel statistics blocks: the 384-row kernel only
+    if (a.stats && a.stats_px != 0 && a.stats_px != 16 && a.stats_px != 64) { ++g_bad; return -1; }
+    if (pers_on && big_on && ng == 1 && !two && !st16 && a.K <= BIG_KMAX && a.H < 32768 && a.W < 32768 && a.N * (long)a.ldx < (1l << 31)) {
         const int bm = a.M % 256 == 0 ? 256 : (a.M == 128 ? 128 : 0);
         if (bm) {
             const long nxp = (a.N + (bm == 256 ? 255 : 511)) / (bm == 256 ? 256 : 512), tiles = nxp * (a.M / bm);
@@ -741,7 +755,7 @@ int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
             }
         }
     }
-    if (big_on && !two && a.K <= BIG_KMAX && a.H < 32768 && a.W < 32768 && a.N * (long)a.ldx < (1l << 31)) {
+    if (big_on && !two && !st16 && a.K <= BIG_KMAX && a.H < 32768 && a.W < 32768 && a.N * (long)a.ldx < (1l << 31)) {
         if (a.M % 256 == 0 && ((a.N + 255) / 256) * (a.M / 256) * ng >= 256) {
             const long nx = (a.N + 255) / 256;
             hipLaunchKernelGGL(gemm_h16_big_kernel<256>, dim3((unsigned)(((nx + 7) / 8) * 8 * (a.M / 256)), ng), dim3(512), BIG_LDS_256, s, a);

@@ -11,6 +11,7 @@ namespace dmad {
 int launch_conv1ch_3x3(const float* in, const float* w, const float* bias, float* out, int B, int Cout, hipStream_t s, h16_t* out16 = nullptr);
 // conv 3x3, 128 -> 1 channel, padding 1, bias: in [B][1024][128] (NHWC), w [9][128] (tap-major), out [B][1024]   (out.2)
 void launch_conv3x3_c128_to1(const float* in, const float* w, const float* bias, float* out, int B, hipStream_t s);
+void launch_conv3x3_c128_to1_h16(const h16_t* in, const float* w, const float* bias, float* out, int B, hipStream_t s);   // the same on an f16 map
 // GroupNorm32(32, C) in fp32 (nn.py:15-17,92-100) over [B][HW][C], then optionally y * (1 + ss[c]) + ss[C + c]
 // (scale-shift norm, unet.py:190-194; ss = one row of 2C floats shared by the batch) and optionally SiLU.
 // Returns -1 for a map it is not built for (C not a multiple of 128, or more than 12288 values per group).
@@ -21,7 +22,8 @@ int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta,
                           const h16_t* x16 = nullptr, const h16_t* x2_16 = nullptr);   // x16 != nullptr: the input is read from f16 map(s) x16 (/ x2_16) instead of x (/ x2)
 // The 16-bit tier's GroupNorm as one streaming pass over an f16 map (or the two parts x [c1 channels] | x2 of a concatenated input)
 // whose statistics the producing GEMMs left in st / st2 (GemmH16Args::stats: [B * HW / 64][channels / 4][2] floats per map):
-// y = SiLU?((x - mean) * rstd * gamma + beta [* (1 + ss[c]) + ss[C + c]]) as f16 (y16) or fp32 (y32).  HW a multiple of 64.
+// y = SiLU?((x - mean) * rstd * gamma + beta [* (1 + ss[c]) + ss[C + c]]) as f16 (y16) or fp32 (y32).  HW a multiple of 64, or 16 (the
+// 4 x 4 maps: statistics blocks of 16 pixels, GemmH16Args::stats_px = 16).
 // Returns -1 for a map it does not serve (the caller then takes launch_groupnorm_nhwc).
 int launch_groupnorm16_apply(const h16_t* x, const float* st, const h16_t* x2, const float* st2, int c1, const float* gamma, const float* beta,
                              const float* ss, int silu, h16_t* y16, float* y32, int B, int HW, int C, hipStream_t s);

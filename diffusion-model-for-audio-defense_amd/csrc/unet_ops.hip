@@ -57,6 +57,38 @@ __global__ void __launch_bounds__(256) conv3x3_c128_to1_kernel(const float* __re
     out[p] = (acc[0] + acc[1]) + (acc[2] + acc[3]) + bias[0];
 }
 
+// The same layer on an f16 map (the 16-bit tier): one workgroup per image row, thread = (pixel x, 8-channel octet o): the 16 octet
+// threads of a pixel read its 256-byte row with one 16-byte load each (whole lines, neighbouring pixels contiguous), keep their 9 x 8
+// weights in registers, and a 16-lane xor tree adds their partial dot products — where the one-lane-per-pixel form above has every
+// lane walk nine 512-byte fp32 rows of its own (0.9 TB/s).
+__global__ void __launch_bounds__(512) conv3x3_c128_to1_h16_kernel(const h16_t* __restrict__ in, const float* __restrict__ w,
+                                                                   const float* __restrict__ bias, float* __restrict__ out) {
+    const int t = threadIdx.x, o = t & 15, x = t >> 4;
+    const int y = blockIdx.x & 31;
+    const long b = blockIdx.x >> 5;
+    float wk[9][8];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const float4 a0 = *(const float4*)(w + tap * 128 + o * 8), a1 = *(const float4*)(w + tap * 128 + o * 8 + 4);
+        wk[tap][0] = a0.x; wk[tap][1] = a0.y; wk[tap][2] = a0.z; wk[tap][3] = a0.w;
+        wk[tap][4] = a1.x; wk[tap][5] = a1.y; wk[tap][6] = a1.z; wk[tap][7] = a1.w;
+    }
+    const h16_t* img = in + b * 1024 * 128 + o * 8;
+    float acc = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if ((unsigned)yy < 32u && (unsigned)xx < 32u) {
+            const f16x8 v = *(const f16x8*)(img + (yy * 32 + xx) * 128);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc = fmaf((float)v[r], wk[tap][r], acc);
+        }
+    }
+#pragma unroll
+    for (int m = 8; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    if (o == 0) out[b * 1024 + y * 32 + x] = acc + bias[0];
+}
+
 // GroupNorm32(32, C) over an NHWC map.  One workgroup per (sample, G neighbouring groups), G chosen so that the G groups'
 // slice of a pixel is whole 128-byte lines (C/32 = 4, 8, 12 or 16 channels per group -> G = 8, 4, 8 or 4, 2): every load and
 // store of a wave is then full cache lines (a single group's slice is only 16..64 bytes of its line).  The slab — HW pixels x
@@ -238,11 +270,11 @@ __global__ void __launch_bounds__(256) groupnorm16_apply_kernel(const h16_t* __r
                                                                 const float* __restrict__ st1, const float* __restrict__ st2,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 const float* __restrict__ ss, int silu, h16_t* __restrict__ y16,
-                                                                float* __restrict__ y32, int HW, int C, int wps) {
+                                                                float* __restrict__ y32, int HW, int C, int wps, int bshift) {
     __shared__ float mulc[512], addc[512], gsum[2][32];
     const int NT = blockDim.x, t = threadIdx.x;
     const int b = blockIdx.x / wps, part = blockIdx.x - b * wps;
-    const int cpg = C >> 5, qpg = cpg >> 2, nblk = HW >> 6;
+    const int cpg = C >> 5, qpg = cpg >> 2, nblk = HW >> bshift;     // statistics blocks of 64 pixels (bshift 6), or of 16 on the 4 x 4 maps
     const int ca = x2 ? c1 : C, cb = C - ca;                         // channels of the first / second part
     {   // group sums: 8 threads per group, entry e = (pixel block, quad of the group), fixed xor tree over the 8
         const int k = t & 7, entries = nblk * qpg;
@@ -555,6 +587,9 @@ void launch_conv3x3_c128_to1(const float* in, const float* w, const float* bias,
     const long total = (long)B * 1024;
     hipLaunchKernelGGL(conv3x3_c128_to1_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, in, w, bias, out, total);
 }
+void launch_conv3x3_c128_to1_h16(const h16_t* in, const float* w, const float* bias, float* out, int B, hipStream_t s) {
+    hipLaunchKernelGGL(conv3x3_c128_to1_h16_kernel, dim3((unsigned)B * 32u), dim3(512), 0, s, in, w, bias, out);
+}
 int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* ss, int silu, float* y, int B, int HW,
                           int C, hipStream_t s, const float* x2, int c1, h16_t* y16, const h16_t* x16, const h16_t* x2_16) {
     const bool in16 = x16 != nullptr;
@@ -596,11 +631,12 @@ int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta,
 }
 int launch_groupnorm16_apply(const h16_t* x, const float* st, const h16_t* x2, const float* st2, int c1, const float* gamma, const float* beta,
                              const float* ss, int silu, h16_t* y16, float* y32, int B, int HW, int C, hipStream_t s) {
-    if (C % 128 || C < 128 || C > 512 || B < 1 || HW < 64 || (HW & 63) || !x || !st || (!y16 && !y32)) return -1;
+    if (C % 128 || C < 128 || C > 512 || B < 1 || HW < 16 || (HW & 15) || (HW > 16 && (HW & 63)) || !x || !st || (!y16 && !y32)) return -1;
     if (x2 && (!st2 || c1 < 8 || c1 >= C || (c1 & 7))) return -1;
     const int wps = HW >= 1024 ? HW / 256 : 1;                      // 256 pixels per workgroup on the large maps, a whole sample otherwise
     const int nt = C == 384 ? 192 : 256;
-    hipLaunchKernelGGL(groupnorm16_apply_kernel, dim3((unsigned)(B * wps)), dim3(nt), 0, s, x, x2, c1, st, st2, gamma, beta, ss, silu, y16, y32, HW, C, wps);
+    hipLaunchKernelGGL(groupnorm16_apply_kernel, dim3((unsigned)(B * wps)), dim3(nt), 0, s, x, x2, c1, st, st2, gamma, beta, ss, silu, y16, y32, HW, C, wps,
+                       HW >= 64 ? 6 : 4);
     return 0;
 }
 void launch_silu(const float* x, float* y, long n, hipStream_t s) {

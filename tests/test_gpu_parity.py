@@ -1017,7 +1017,7 @@ def test_bench_contract():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--samples-per-step', '8',
-                        '--max-batch', '8', '--cpu-samples', '2', '--full-n', '64', '--c5-n', '16', '--c2-iters', '1', '--c2-batch', '8', '--c3-clips', '1',
+                        '--max-batch', '8', '--cpu-samples', '2', '--full-n', '64', '--c5-n', '16', '--c5-batch', '16', '--c2-iters', '1', '--c2-batch', '8', '--c3-clips', '1',
                         '--check-steps', '1', '--grid-steps', '1', '--resnext-steps', '1'], capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -1088,7 +1088,7 @@ def test_bench_two_ranks_rehearsal():
     env.update(DMAD_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
                         '--master-port', str(29700 + os.getpid() % 200), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2',
-                        '--warmup', '1', '--samples-per-step', '16', '--max-batch', '16', '--full-n', '200', '--c5-n', '16', '--c2-iters', '1',
+                        '--warmup', '1', '--samples-per-step', '16', '--max-batch', '16', '--full-n', '200', '--c5-n', '16', '--c5-batch', '16', '--c2-iters', '1',
                         '--c2-batch', '8', '--c3-clips', '1', '--check-steps', '1'], capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]

@@ -65,7 +65,7 @@ else:
     if os.environ.get('DMAD_LIB'):               # A/B of two builds on one box: DMAD_LIB=/path/to/other/libdmad_hip.so
         _lib.LIB_PATH = os.environ['DMAD_LIB']
     from dmad_hip import engine as E, synth
-    eng = E.Engine(max_batch=B, precision=E.BF16, with_classifier=False)
+    eng = E.Engine(max_batch=B, precision=E.BF16, with_classifier=False, with_wavenet=False)     # 16-bit tier (DMAD_MODE_FAST), no WaveNet workspace
     eng.load_unet(synth.unet_state_dict(5252))
     x = torch.randn(B, 32, 32, device='cuda') * 0.5
     eng.unet_eps(x, 40); torch.cuda.synchronize()
