@@ -7,7 +7,7 @@ NAME=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --side-steps 0 --c5-n 0 --c2-iters 0 --check-steps 0 --no-certify $*"   # the timed steps only: every layer launch carries 512 clips
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --side-steps 0 --c5-n 0 --c2-iters 0 --check-steps 0 --grid-steps 0 --resnext-steps 0 --no-certify $*"   # the timed steps only: every layer launch carries 512 clips
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$NAME -- $BENCH --steps 5 --warmup 1 > $OUT/prof_$NAME.json 2> $OUT/prof_$NAME.err || exit 1
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     set -- $pass; tag=$1; shift
