@@ -1579,6 +1579,31 @@ int dmad_conv_h16(const uint16_t* x, const uint16_t* x2, int32_t ksplit, const u
     return 0;
 }
 
+int dmad_conv_h16_stats(const uint16_t* x, const uint16_t* w, const float* bias, const uint16_t* res16, int32_t B, int32_t H, int32_t M, int32_t K,
+                        int32_t taps, int32_t stride, uint16_t* out16, float* stats, dmad_stream s) {
+    if (!x || !w || !out16 || !stats) return fail(DMAD_ERR_INVALID, "null argument");
+    if (B < 1 || H < 1 || M < 1 || K < 1 || (stride != 1 && stride != 2)) return fail(DMAD_ERR_INVALID, "bad geometry");
+    if (int r = gemm_h16_configure()) return fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS, f16 conv GEMM) failed: %d", r);
+    const int Ho = (H - 1) / stride + 1;
+    if (Ho * Ho != 16 && (Ho * Ho) % 64) return fail(DMAD_ERR_INVALID, "statistics blocks need maps of 16 or a multiple of 64 pixels");
+    GemmH16Args g{};
+    g.A = w; g.X = x; g.C16 = out16; g.shift = bias; g.res16 = res16; g.M = M; g.K = K; g.taps = taps; g.ldc = M;
+    g.N = (long)B * Ho * Ho; g.H = H; g.W = H; g.ldx = K; g.stride = stride; g.stats = stats; g.stats_px = Ho * Ho >= 64 ? 64 : 16;
+    launch_gemm_h16(g, (hipStream_t)s);
+    LASTCHK();
+    return 0;
+}
+
+int dmad_groupnorm16_apply(const uint16_t* x, const float* st, const uint16_t* x2, const float* st2, int32_t c1, const float* gamma,
+                           const float* beta, const float* ss, int32_t silu, int32_t B, int32_t HW, int32_t C, uint16_t* y16, float* y32,
+                           dmad_stream s) {
+    if (!x || !st || !gamma || !beta || (!y16 && !y32)) return fail(DMAD_ERR_INVALID, "null argument");
+    if (launch_groupnorm16_apply(x, st, x2, st2, c1, gamma, beta, ss, silu, y16, y32, B, HW, C, (hipStream_t)s))
+        return fail(DMAD_ERR_INVALID, "no one-pass GroupNorm for a %d-pixel x %d-channel map", HW, C);
+    LASTCHK();
+    return 0;
+}
+
 int dmad_vote(dmad_engine* e, const float* logits, int32_t B, int64_t* counts, dmad_stream s) {
     if (!e || !logits || !counts || B < 1) return fail(DMAD_ERR_INVALID, "bad argument to dmad_vote");
     launch_vote(logits, B, e->cfg.num_classes, (unsigned long long*)counts, nullptr, (hipStream_t)s);

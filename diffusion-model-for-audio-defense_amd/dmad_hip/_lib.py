@@ -52,6 +52,8 @@ _SIGNATURES = {
     'dmad_classify_tier': (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     'dmad_conv_h16': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_int32, _P, _P, _P]),
+    'dmad_conv_h16_stats': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    'dmad_groupnorm16_apply': (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     'dmad_smooth_votes': (C.c_int, [_P, _P, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_int64, C.c_int32,
                                     C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P]),
     'dmad_set_mode': (C.c_int, [_P, C.c_int32]),

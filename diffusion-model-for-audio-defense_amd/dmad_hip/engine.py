@@ -710,6 +710,46 @@ def conv_h16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = No
     return out32, out16
 
 
+def conv_h16_stats(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, res: Optional[torch.Tensor] = None):
+    """dmad_conv_h16_stats: dense f16 conv (x [B,H,H,K] f16, w [1,taps,M,K] f16) -> (out16 [B,Ho,Ho,M] f16, stats [B*Ho*Ho/blk, M/4, 2] fp32):
+    the GroupNorm statistics the producing GEMM's epilogue leaves for groupnorm16_apply (blk = 64 pixels, 16 on 4x4 maps)."""
+    lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float16 and w.dtype == torch.float16 and w.shape[0] == 1
+    x, w = x.contiguous(), w.contiguous()
+    B, H, _, K = x.shape
+    _, taps, M, K2 = w.shape
+    assert K2 == K
+    Ho = (H - 1) // stride + 1
+    blk = 64 if Ho * Ho >= 64 else 16
+    out16 = torch.empty((B, Ho, Ho, M), device=x.device, dtype=torch.float16)
+    stats = torch.zeros((B * Ho * Ho // blk, M // 4, 2), device=x.device, dtype=torch.float32)
+    if bias is not None:
+        bias = bias.detach().contiguous().float()
+    if res is not None:
+        res = res.contiguous()
+    check(lib.dmad_conv_h16_stats(_ptr(x), _ptr(w), _ptr(bias), _ptr(res), B, H, M, K, taps, int(stride), _ptr(out16), _ptr(stats), _stream()))
+    return out16, stats
+
+
+def groupnorm16_apply(x: torch.Tensor, st: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, silu: bool = True, ss: Optional[torch.Tensor] = None,
+                      x2: Optional[torch.Tensor] = None, st2: Optional[torch.Tensor] = None, out32: bool = False):
+    """dmad_groupnorm16_apply: one-pass GroupNorm32 (+ scale-shift, + SiLU) of the f16 map x [B,HW,c1] (| x2 [B,HW,C-c1]) from the
+    statistics slabs of conv_h16_stats.  Returns y [B,HW,C] (f16, or fp32 with out32)."""
+    lib = _lib.load()
+    x, st = x.contiguous(), st.contiguous()
+    B, HW, c1 = x.shape
+    C = c1 + (x2.shape[2] if x2 is not None else 0)
+    y = torch.empty((B, HW, C), device=x.device, dtype=torch.float32 if out32 else torch.float16)
+    if x2 is not None:
+        x2, st2 = x2.contiguous(), st2.contiguous()
+    gamma, beta = gamma.detach().contiguous().float(), beta.detach().contiguous().float()
+    if ss is not None:
+        ss = ss.detach().contiguous().float()
+    check(lib.dmad_groupnorm16_apply(_ptr(x), _ptr(st), _ptr(x2), _ptr(st2), int(c1 if x2 is not None else 0), _ptr(gamma), _ptr(beta), _ptr(ss),
+                                     1 if silu else 0, B, HW, C, None if out32 else _ptr(y), _ptr(y) if out32 else None, _stream()))
+    return y
+
+
 def bind_classifier(state_dict, loader_name: str, engine: Optional[Engine] = None) -> Engine:
     """Engine that holds exactly `state_dict` as its classifier: `engine` (refused if it holds another one), else the
     shared engine, else — when the shared engine already serves a different classifier — an engine of this module's own

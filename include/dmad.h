@@ -319,6 +319,16 @@ int dmad_profile_read_final(dmad_engine* e, float* total_ms, int32_t* launches);
 int dmad_conv_h16(const uint16_t* x, const uint16_t* x2, int32_t ksplit, const uint16_t* w, const float* bias, const uint16_t* res16,
                   int32_t B, int32_t H, int32_t M, int32_t K, int32_t taps, int32_t stride, int32_t groups, int32_t relu,
                   float* out32, uint16_t* out16, dmad_stream s);
+/* The same with the consumer's GroupNorm statistics accumulated in the epilogue: stats [N / blk][groups * M / 4][2] fp32 = (sum, sum of
+ * squares) of the f16-rounded outputs per block of blk = 64 pixels (16 when Ho * Ho == 16) and 4-channel quad — and the one-pass
+ * GroupNorm32 + SiLU (+ scale-shift) that consumes them (nn.py:15-17, unet.py:186-199 on the 16-bit tier):
+ * y = SiLU?(GroupNorm_32groups(cat(x, x2)) * gamma + beta [* (1 + ss[c]) + ss[C + c]]), x / x2 f16 NHWC maps [B][HW][c1 | C - c1] with
+ * their slabs st / st2 (x2, st2 NULL: one map), y16 f16 or y32 fp32 [B][HW][C].  Test hooks like dmad_conv_h16. */
+int dmad_conv_h16_stats(const uint16_t* x, const uint16_t* w, const float* bias, const uint16_t* res16, int32_t B, int32_t H, int32_t M, int32_t K,
+                        int32_t taps, int32_t stride, uint16_t* out16, float* stats, dmad_stream s);
+int dmad_groupnorm16_apply(const uint16_t* x, const float* st, const uint16_t* x2, const float* st2, int32_t c1, const float* gamma,
+                           const float* beta, const float* ss, int32_t silu, int32_t B, int32_t HW, int32_t C, uint16_t* y16, float* y32,
+                           dmad_stream s);
 
 /* Bytes of device memory held by the engine. */
 int64_t dmad_device_bytes(const dmad_engine* e);

@@ -774,6 +774,74 @@ def test_gemm_h16_family_vs_torch_conv(case):
     assert torch.equal(o16, o32.half())                     # the f16 twin IS the rounded fp32 output
 
 
+
+@pytest.mark.parametrize('case', [(3, 32, 128, 128, 0), (130, 32, 128, 128, 0), (2, 16, 256, 256, 128), (260, 16, 256, 256, 0), (5, 8, 128, 384, 256), (7, 4, 256, 256, 0),
+                                  (9, 4, 256, 512, 256)],
+                         ids=lambda c: 'B%d_H%d_K%d_C%d_c1_%d' % c)
+def test_groupnorm_from_epilogue_statistics_vs_torch(case):
+    """The 16-bit tier's GroupNorm (nn.py:15-17 GroupNorm32 in fp32, then SiLU; with the ResBlock's scale-shift, unet.py:190-194): the
+    statistics a conv GEMM's epilogue leaves (dmad_conv_h16_stats: per 64-pixel block — 16 on 4x4 maps — and channel quad, of the
+    f16-rounded outputs; every kernel of the family that can serve the shape) fed to the one-pass apply kernel, against
+    torch.nn.functional.group_norm on the same f16 map in fp32: statistics exact to fp32 summation order, output within one f16
+    rounding.  Also the two-part (concatenated) input and batch invariance."""
+    from dmad_hip import engine as E
+    B, H, K, C, c1 = case
+    g = torch.Generator().manual_seed(77 + B + H + C)
+    x = (torch.rand(B, H, H, K, generator=g) * 2 - 1).half().cuda()
+
+    def conv(M, seed_off):
+        gg = torch.Generator().manual_seed(500 + seed_off + M)
+        w = ((torch.rand(1, 9, M, K, generator=gg) * 2 - 1) * 0.08).half().cuda()
+        b = (torch.rand(M, generator=gg) * 4 - 1).cuda()                    # a non-zero mean: the variance is E[x^2] - mean^2 here
+        return E.conv_h16_stats(x, w, b)
+    HW = H * H
+    if c1:
+        a16, sta = conv(c1, 1)
+        b16, stb = conv(C - c1, 2)
+        full = torch.cat([a16, b16], dim=3)
+    else:
+        a16, sta = conv(C, 1)
+        b16 = stb = None
+        full = a16
+    # the statistics themselves: block sums of the f16 outputs
+    blk = 64 if HW >= 64 else 16
+    ref_blocks = a16.float().reshape(B * HW // blk, blk, a16.shape[3] // 4, 4)
+    assert torch.allclose(sta[..., 0], ref_blocks.sum((1, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(sta[..., 1], (ref_blocks ** 2).sum((1, 3)), rtol=1e-5, atol=1e-3)
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    beta = (torch.rand(C, generator=g) - 0.5).cuda()
+    ss = (torch.rand(2 * C, generator=g) - 0.5).cuda()
+    for silu, use_ss in ((True, False), (True, True), (False, False)):
+        y = E.groupnorm16_apply(a16.reshape(B, HW, -1), sta, gamma, beta, silu=silu, ss=ss if use_ss else None,
+                                x2=None if b16 is None else b16.reshape(B, HW, -1), st2=stb, out32=True)
+        ref = torch.nn.functional.group_norm(full.float().permute(0, 3, 1, 2), 32, gamma, beta, eps=1e-5)
+        if use_ss:
+            ref = ref * (1 + ss[:C, None, None]) + ss[C:, None, None]
+        if silu:
+            ref = torch.nn.functional.silu(ref)
+        ref = ref.permute(0, 2, 3, 1).reshape(B, HW, C)
+        assert float((y - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())), (silu, use_ss, float((y - ref).abs().max()))
+        y16 = E.groupnorm16_apply(a16.reshape(B, HW, -1), sta, gamma, beta, silu=silu, ss=ss if use_ss else None,
+                                  x2=None if b16 is None else b16.reshape(B, HW, -1), st2=stb)
+        assert torch.equal(y16, y.half())
+    # a sample's result does not depend on the batch it is in
+    lo = B // 2
+    xs = x[lo:lo + 1].contiguous()
+    x_saved, x = x, xs
+    if c1:
+        a1, s1 = conv(c1, 1); b1, s2 = conv(C - c1, 2)
+        solo = E.groupnorm16_apply(a1.reshape(1, HW, -1), s1, gamma, beta, x2=b1.reshape(1, HW, -1), st2=s2)
+    else:
+        a1, s1 = conv(C, 1)
+        solo = E.groupnorm16_apply(a1.reshape(1, HW, -1), s1, gamma, beta)
+    x = x_saved
+    assert torch.equal(solo[0], y_full_batch(E, a16, sta, b16, stb, gamma, beta, B, HW)[lo])
+
+
+def y_full_batch(E, a16, sta, b16, stb, gamma, beta, B, HW):
+    return E.groupnorm16_apply(a16.reshape(B, HW, -1), sta, gamma, beta, x2=None if b16 is None else b16.reshape(B, HW, -1), st2=stb)
+
+
 # ------------------------------------------------------------------------------------------ Improved-Diffusion UNet (N1)
 def test_unet_purifier_vs_reference_fixture(golden_dir):
     """UNetModel.forward, GaussianDiffusion.q_sample / p_sample and the ImprovedDiffusion wrapper on the HIP engine vs
