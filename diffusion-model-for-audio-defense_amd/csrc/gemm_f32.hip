@@ -594,8 +594,13 @@ int launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab
         return 0;
     }
     if (a.X2 && (a.mode != 2 || a.groups > 1 || a.M <= 64 || (a.ksplit % BK) || a.ksplit <= 0 || a.ksplit >= a.K)) { ++g_bad_shapes; return kGemmBadShape; }   // two-part input: plain NHWC convs only
-    const int BM = a.M <= 64 ? 64 : 128;          // 64-row tiles where a 128-row tile would be half empty
-    const unsigned gx = (unsigned)((a.N + BN - 1) / BN), gy = (unsigned)((a.M + BM - 1) / BM);
+    // 64-row tiles where a 128-row tile would be half empty — and for launches that leave most of the chip idle with 128-row tiles
+    // (a handful of samples on the fp32 tiers: the recheck of a vote loop, an audit): twice the workgroups for the same work.  Every
+    // output is the same K-ordered sum in both tile shapes (same bits); the split count below does not depend on the choice.
+    const long gx_ = (a.N + BN - 1) / BN, gy128 = (a.M + 127) / 128;
+    const bool small_grid = a.epi == 0 && !a.X2 && a.M > 64 && gx_ * gy128 * (a.groups > 1 ? a.groups : 1) < 128;
+    const int BM = (a.M <= 64 || small_grid) ? 64 : 128;
+    const unsigned gx = (unsigned)gx_, gy = (unsigned)((a.M + BM - 1) / BM);
     const int nks = a.taps * (a.K / BK);
     int S = 1;
     auto launch = [&](dim3 grid) {
@@ -613,7 +618,7 @@ int launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab
         // The split count is derived from the REFERENCE row count n_ref (the engine's max batch), not from the
         // rows of this launch, so that a sample's result does not depend on the batch it was computed in.
         const long nr = n_ref > 0 ? n_ref : a.N;
-        const long wgs_ref = ((nr + BN - 1) / BN) * gy;
+        const long wgs_ref = ((nr + BN - 1) / BN) * (a.M <= 64 ? 1 : gy128);       // (in 128-row tiles, whatever this launch uses)
         if (wgs_ref < 384) {                       // fewer than half the resident workgroups (3 per CU): split K
             S = (int)(768 / wgs_ref);
             if (S > nks / 4) S = nks / 4;          // keep >= 4 k-steps per split

@@ -53,7 +53,7 @@ def main():
     ap.add_argument('--fetch'); ap.add_argument('--write'); ap.add_argument('--mfma')
     ap.add_argument('--bench-line')
     ap.add_argument('--clips-per-launch', type=int, default=None, help='clips one layer launch carries (default: engine_batch of the bench line, else 512)')
-    ap.add_argument('--command', default='python3 bench.py --no-cpu-baseline --side-steps 0 --c5-n 0 --no-certify --steps 5 --warmup 1')
+    ap.add_argument('--command', default='python3 bench.py --no-cpu-baseline --side-steps 0 --c5-n 0 --c2-iters 0 --check-steps 0 --grid-steps 0 --resnext-steps 0 --no-certify --steps 5 --warmup 1')
     a = ap.parse_args()
     prof = os.path.join(ROOT, 'profiles')
     os.makedirs(prof, exist_ok=True)
