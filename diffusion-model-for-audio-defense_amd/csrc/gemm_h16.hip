@@ -15,6 +15,8 @@
 // per SIMD), two k-steps in flight while one is contracted, one barrier per k-step.
 #include "gemm_h16.h"
 #include <stdlib.h>
+#include <stdio.h>
+#include <vector>
 
 namespace dmad {
 
@@ -437,8 +439,19 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
 // Residual reads of the epilogue are issued right behind the k-step barrier (nothing else in flight) and retired by an explicit
 // count that leaves the next k-step's DMA pieces flying.
 // ----------------------------------------------------------------------------------------------------------------------------
-template <int BM, bool WIDE>      // WIDE: f16 map out, no fp32 output / residual (the epilogue with 16-byte stores); else the plain epilogue
-__global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, int nx) {
+// STAMP (diagnostic build only, DMAD_H16_STAMPS=1: never the product launch): s_memtime sums of wave 0 per part of a k-step —
+// phases 1-3 | barrier wait | phase 4 with the DMA issue | epilogue — into dbg[block][8].
+template <int BM, bool WIDE, bool STAMP = false>      // WIDE: f16 map out, no fp32 output / residual (the epilogue with 16-byte stores); else the plain epilogue
+__global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, int nx, unsigned long long* dbg = nullptr) {
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int k) {
+        if constexpr (STAMP) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (k >= 0) tacc[k] += now - tprev;
+            tprev = now;
+        }
+    };
+    stamp(-1);
     constexpr int BN = BM == 256 ? 256 : 512, AP = BM / 64, XP = BN / 64, NP = AP + XP, SLOTB = (BM + BN) * 128, WN = BN / 64;
     constexpr int MT = BM == 256 ? 8 : 8;            // accumulator row tiles per wave (wave tile 128 x 64 in both forms)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -555,6 +568,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
         const char* nxt = smem + ((g & 1) ^ 1) * SLOTB;
         const unsigned cur_lds = lds0 + (g & 1) * SLOTB;
         const bool last = s == nsteps - 1;
+        stamp(4);                                                    // (tile switch, loop overhead)
         // phase 1: (A0, B) k0; read A1 k0
         ldA(AY, cur, 1, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -569,7 +583,9 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
         __builtin_amdgcn_sched_barrier(0);
         PERS_MFMA4(AX, BQ, 0, 0); PERS_MFMA4(AX, BQ, 0, 1); PERS_MFMA4(AX, BQ, 0, 2); PERS_MFMA4(AX, BQ, 0, 3);
         // the next k-step of the stream has landed, every wave holds its last fragments of this slot
+        stamp(0);
         GH_WAIT_BARRIER(0);
+        stamp(1);
         // phase 4: (A1, B) k1; unless the tile ends here, read A0 k0, B k0 of the next k-step; stage the k-step after it into this slot
         if (!last) {
             ldA(AX, nxt, 0, 0);
@@ -586,6 +602,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
         if (more) { piece(6, cur_lds); piece(7, cur_lds); __builtin_amdgcn_sched_barrier(0); }
         PERS_MFMA4(AY, BQ, 4, 3);
         if (more) st_advance();
+        stamp(2);
         if (!last) { ++s; continue; }
         // ---- the tile is complete: epilogue straight from the accumulators (the fragment registers are free here) ---------------
         {
@@ -684,6 +701,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
                     for (int j = 0; j < 4; ++j) acc[ii][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+        stamp(3);
         ctile += G8;
         s = 0;
         if (g + 1 < total) {                                         // first units of the next tile (its k-step 0 landed before the barrier above)
@@ -694,6 +712,13 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
     }
 #undef PERS_MFMA4
     __builtin_amdgcn_s_waitcnt(0xC07F);
+    if constexpr (STAMP) {
+        if (tid == 0 && dbg) {
+            for (int k = 0; k < 5; ++k) dbg[(size_t)blockIdx.x * 8 + k] = tacc[k];
+            dbg[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)total;
+            dbg[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)my_tiles;
+        }
+    }
 }
 
 int gemm_h16_configure() {
@@ -719,6 +744,10 @@ int gemm_h16_configure() {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
         g_h16_cus = prop.multiProcessorCount & ~7;
+    e = hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<128, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
+    if (e != hipSuccess) return (int)e;
     return (int)hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
 }
 
@@ -747,6 +776,23 @@ int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
             const long nxp = (a.N + (bm == 256 ? 255 : 511)) / (bm == 256 ? 256 : 512), tiles = nxp * (a.M / bm);
             if (tiles >= g_h16_cus && nxp < (1l << 31) && a.N * (long)a.ldc < (1l << 31)) {
                 const bool wide = a.C16 && !a.C && !a.res && !(a.ldc & 7);
+                static const bool stamps = []() { const char* v = getenv("DMAD_H16_STAMPS"); return v && v[0] == '1'; }();
+                if (stamps && wide) {            // diagnostic: synchronous, prints wave 0's mean cycles per k-step and per tile
+                    static unsigned long long* dbg = nullptr;
+                    if (!dbg && hipMalloc((void**)&dbg, (size_t)g_h16_cus * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+                    (void)hipMemsetAsync(dbg, 0, (size_t)g_h16_cus * 64, s);
+                    if (bm == 256) hipLaunchKernelGGL((gemm_h16_pers_kernel<256, true, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp, dbg);
+                    else hipLaunchKernelGGL((gemm_h16_pers_kernel<128, true, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp, dbg);
+                    std::vector<unsigned long long> h((size_t)g_h16_cus * 8);
+                    if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                        double sum[5] = {0, 0, 0, 0, 0}, steps = 0, tiles_ = 0;
+                        for (int b = 0; b < g_h16_cus; ++b) { for (int k = 0; k < 5; ++k) sum[k] += (double)h[b * 8 + k]; steps += (double)h[b * 8 + 5]; tiles_ += (double)h[b * 8 + 6]; }
+                        if (steps > 0 && tiles_ > 0)
+                            fprintf(stderr, "[h16 stamps] M=%d K=%d taps=%d N=%ld res=%d: per k-step phases1-3 %.0f | barrier wait %.0f | phase4+DMA issue %.0f | loop top %.0f cycles; per tile epilogue %.0f cycles (%.1f k-steps per tile)\n",
+                                    a.M, a.K, a.taps, a.N, a.res16 ? 1 : 0, sum[0] / steps, sum[1] / steps, sum[2] / steps, sum[4] / steps, sum[3] / tiles_, steps / tiles_);
+                    }
+                    return 0;
+                }
                 if (bm == 256 && wide) hipLaunchKernelGGL((gemm_h16_pers_kernel<256, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
                 else if (bm == 256) hipLaunchKernelGGL((gemm_h16_pers_kernel<256, false>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
                 else if (wide) hipLaunchKernelGGL((gemm_h16_pers_kernel<128, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp);
