@@ -25,6 +25,9 @@ constexpr int HK = 64;                          // halves per k-step row (128 by
 constexpr int KSTEP = 384 * 128, H16_LDS = 3 * KSTEP;
 __device__ __attribute__((aligned(128))) unsigned short g_zero_page_h[64];     // 128 B of zeros
 
+#ifndef H16_PERS_EARLY
+#define H16_PERS_EARLY 1          // 0: the round-4 first form of the persistent kernel's k-step (one barrier, all pieces in phase 4) for A/B builds
+#endif
 #define GH_WAIT_BARRIER(N)                                                          \
     do {                                                                            \
         asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");                       \
@@ -37,8 +40,18 @@ thread_local int g_bad = 0;
 int g_h16_cus = 256;                            // workgroups of a persistent launch (one per CU, a multiple of 8: the XCD-aware tile walk)
 
 // GroupNorm statistics in the epilogue (GemmH16Args::stats): a lane adds the four channels of its pixel of a 16 x 16 accumulator tile,
-// as the f16 values the consumer will read; stats_store reduces over the 16 pixel lanes of the quad's row group (fixed xor tree) and
+// as the f16 values the consumer will read; stats_store reduces over the 16 pixel lanes of the quad's row group (fixed order: DPP row rotations) and
 // lane 0 of the group writes the (sum, sum of squares) of the wave's 64 pixels x 4 channels.
+// sum over the 16 lanes of a DPP row (the 16 pixel lanes of an accumulator tile's row quad): four rotate-and-add steps, no LDS traffic
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v = dpp_add<0x128>(v);      // row_ror:8
+    v = dpp_add<0x124>(v);      // row_ror:4
+    v = dpp_add<0x122>(v);      // row_ror:2
+    return dpp_add<0x121>(v);   // row_ror:1
+}
 __device__ __forceinline__ void stats_add(float& s1, float& s2, const f32x4& v) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -47,10 +60,11 @@ __device__ __forceinline__ void stats_add(float& s1, float& s2, const f32x4& v) 
         s2 = __builtin_fmaf(t, t, s2);
     }
 }
-__device__ __forceinline__ void stats_store(float s1, float s2, float* stats, long blk, int quads, int quad, int r16) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    if (r16 == 0) *(float2*)(stats + ((size_t)blk * quads + quad) * 2) = float2{s1, s2};
+// Blocks at or past nblk (the pixel tail of the last tile) are not written: the statistics array holds exactly N / stats_px blocks.
+__device__ __forceinline__ void stats_store(float s1, float s2, float* stats, long blk, long nblk, int quads, int quad, int r16) {
+    s1 = row_sum16(s1);
+    s2 = row_sum16(s2);
+    if (r16 == 0 && blk < nblk) *(float2*)(stats + ((size_t)blk * quads + quad) * 2) = float2{s1, s2};
 }
 
 // grouped conv: group z of a launch is an ordinary dense problem on shifted pointers
@@ -207,7 +221,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
             if (a.C16) *(f16x4*)(a.C16 + nn[j] + i * 16) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             stats_add(s1, s2, v);
         }
-        if (a.stats && a.stats_px != 16) stats_store(s1, s2, a.stats, (n0 + wn * 64) >> 6, a.ldc >> 2, (m0 + wm * 64 + i * 16 + q * 4) >> 2, r16);
+        if (a.stats && a.stats_px != 16) stats_store(s1, s2, a.stats, (n0 + wn * 64) >> 6, a.N >> 6, a.ldc >> 2, (m0 + wm * 64 + i * 16 + q * 4) >> 2, r16);
     }
     if (a.stats && a.stats_px == 16) {          // 16-pixel samples (4 x 4 maps): one statistics block per 16 x 16 accumulator tile
 #pragma unroll
@@ -218,7 +232,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
                 f32x4 v = acc[i][j];
                 if (a.relu) v = f32x4{relu_nan(v[0]), relu_nan(v[1]), relu_nan(v[2]), relu_nan(v[3])};
                 if (ok[j]) stats_add(s1, s2, v);
-                stats_store(s1, s2, a.stats, (n0 + wn * 64 + j * 16) >> 4, a.ldc >> 2, (m0 + wm * 64 + i * 16 + q * 4) >> 2, r16);
+                stats_store(s1, s2, a.stats, (n0 + wn * 64 + j * 16) >> 4, a.N >> 4, a.ldc >> 2, (m0 + wm * 64 + i * 16 + q * 4) >> 2, r16);
             }
     }
 }
@@ -422,7 +436,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
             if (a.C16) *(f16x4*)(a.C16 + nn[j] + i * 16) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             stats_add(s1, s2, v);
         }
-        if (a.stats) stats_store(s1, s2, a.stats, (n0 + wn * 64) >> 6, a.ldc >> 2, (m0 + wm * 128 + i * 16 + q * 4) >> 2, r16);
+        if (a.stats) stats_store(s1, s2, a.stats, (n0 + wn * 64) >> 6, a.N >> 6, a.ldc >> 2, (m0 + wm * 128 + i * 16 + q * 4) >> 2, r16);
     }
 }
 
@@ -443,7 +457,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
 // phases 1-3 | barrier wait | phase 4 with the DMA issue | epilogue — into dbg[block][8].
 template <int BM, bool WIDE, bool STAMP = false>      // WIDE: f16 map out, no fp32 output / residual (the epilogue with 16-byte stores); else the plain epilogue
 __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, int nx, unsigned long long* dbg = nullptr) {
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;      // [5]: the wait at the mid-k-step barrier
     auto stamp = [&](int k) {
         if constexpr (STAMP) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -578,6 +592,47 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
         ldB(BQ, cur, 1);
         __builtin_amdgcn_sched_barrier(0);
         PERS_MFMA4(AY, BP, 4, 0); PERS_MFMA4(AY, BP, 4, 1); PERS_MFMA4(AY, BP, 4, 2); PERS_MFMA4(AY, BP, 4, 3);
+        const bool more = st_left > 0;
+#if H16_PERS_EARLY
+        // Every wave holds its last fragments of this slot's pixel rows and A0 rows (3/4 of the slot; only the A1 rows are still to be
+        // read, in phase 3): a barrier without a memory wait frees them, and the pieces of the k-step after next start a phase earlier,
+        // one per MFMA group over phases 3 and 4 instead of eight in phase 4 (issued together they queue behind each other in the
+        // CU's one vector-memory pipe, 100-185 cycles of issue each, with every wave's MFMAs waiting behind its own pieces).
+        stamp(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stamp(5);
+        // phase 3: (A0, B) k1; read A1 k1; stage the pixel rows of the k-step after next
+        ldA(AY, cur, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) { piece(0, cur_lds); if (NP == 10) piece(4, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        PERS_MFMA4(AX, BQ, 0, 0);
+        if (more) { piece(1, cur_lds); if (NP == 10) piece(5, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        PERS_MFMA4(AX, BQ, 0, 1);
+        if (more) { piece(2, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        PERS_MFMA4(AX, BQ, 0, 2);
+        if (more) { piece(3, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        PERS_MFMA4(AX, BQ, 0, 3);
+        // the next k-step of the stream has landed (only this phase's pieces are younger), every wave holds its A1 k1 fragments
+        stamp(0);
+        if (more) { if (NP == 8) { GH_WAIT_BARRIER(4); } else { GH_WAIT_BARRIER(6); } } else { GH_WAIT_BARRIER(0); }
+        stamp(1);
+        // phase 4: (A1, B) k1; unless the tile ends here, read A0 k0, B k0 of the next k-step; stage the rest of the k-step after next
+        if (!last) {
+            ldA(AX, nxt, 0, 0);
+            ldB(BP, nxt, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) { piece(NP == 8 ? 4 : 6, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        PERS_MFMA4(AY, BQ, 4, 0);
+        if (more) { piece(NP == 8 ? 6 : 7, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        PERS_MFMA4(AY, BQ, 4, 1);
+        if (more) { piece(NP == 8 ? 5 : 8, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        PERS_MFMA4(AY, BQ, 4, 2);
+        if (more) { piece(NP == 8 ? 7 : 9, cur_lds); __builtin_amdgcn_sched_barrier(0); }
+        PERS_MFMA4(AY, BQ, 4, 3);
+#else
         // phase 3: (A0, B) k1; read A1 k1
         ldA(AY, cur, 1, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -592,7 +647,6 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
             ldB(BP, nxt, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const bool more = st_left > 0;
         if (more) { piece(0, cur_lds); piece(1, cur_lds); if (NP == 10) piece(8, cur_lds); __builtin_amdgcn_sched_barrier(0); }
         PERS_MFMA4(AY, BQ, 4, 0);
         if (more) { piece(2, cur_lds); piece(3, cur_lds); if (NP == 10) piece(9, cur_lds); __builtin_amdgcn_sched_barrier(0); }
@@ -601,6 +655,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
         PERS_MFMA4(AY, BQ, 4, 2);
         if (more) { piece(6, cur_lds); piece(7, cur_lds); __builtin_amdgcn_sched_barrier(0); }
         PERS_MFMA4(AY, BQ, 4, 3);
+#endif
         if (more) st_advance();
         stamp(2);
         if (!last) { ++s; continue; }
@@ -666,8 +721,8 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
                         acc[t1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                     if (a.stats) {
-                        stats_store(s10, s20, a.stats, (n0 + wn * 64) >> 6, a.ldc >> 2, (mw + t0 * 16 + q * 4) >> 2, r16);
-                        stats_store(s11, s21, a.stats, (n0 + wn * 64) >> 6, a.ldc >> 2, (mw + t1 * 16 + q * 4) >> 2, r16);
+                        stats_store(s10, s20, a.stats, (n0 + wn * 64) >> 6, a.N >> 6, a.ldc >> 2, (mw + t0 * 16 + q * 4) >> 2, r16);
+                        stats_store(s11, s21, a.stats, (n0 + wn * 64) >> 6, a.N >> 6, a.ldc >> 2, (mw + t1 * 16 + q * 4) >> 2, r16);
                     }
                 }
             } else {
@@ -693,7 +748,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
                             stats_add(s1, s2, v);
                         }
                     }
-                    if (a.stats) stats_store(s1, s2, a.stats, (n0 + wn * 64) >> 6, a.ldc >> 2, (mw + ii * 16 + q * 4) >> 2, r16);
+                    if (a.stats) stats_store(s1, s2, a.stats, (n0 + wn * 64) >> 6, a.N >> 6, a.ldc >> 2, (mw + ii * 16 + q * 4) >> 2, r16);
                 }
 #pragma unroll
                 for (int ii = 0; ii < MT; ++ii)
@@ -717,6 +772,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
             for (int k = 0; k < 5; ++k) dbg[(size_t)blockIdx.x * 8 + k] = tacc[k];
             dbg[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)total;
             dbg[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)my_tiles;
+            dbg[(size_t)blockIdx.x * 8 + 7] = tacc[5];
         }
     }
 }
@@ -785,11 +841,11 @@ int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
                     else hipLaunchKernelGGL((gemm_h16_pers_kernel<128, true, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp, dbg);
                     std::vector<unsigned long long> h((size_t)g_h16_cus * 8);
                     if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-                        double sum[5] = {0, 0, 0, 0, 0}, steps = 0, tiles_ = 0;
-                        for (int b = 0; b < g_h16_cus; ++b) { for (int k = 0; k < 5; ++k) sum[k] += (double)h[b * 8 + k]; steps += (double)h[b * 8 + 5]; tiles_ += (double)h[b * 8 + 6]; }
+                        double sum[5] = {0, 0, 0, 0, 0}, steps = 0, tiles_ = 0, mid = 0;
+                        for (int b = 0; b < g_h16_cus; ++b) { for (int k = 0; k < 5; ++k) sum[k] += (double)h[b * 8 + k]; mid += (double)h[b * 8 + 7]; steps += (double)h[b * 8 + 5]; tiles_ += (double)h[b * 8 + 6]; }
                         if (steps > 0 && tiles_ > 0)
-                            fprintf(stderr, "[h16 stamps] M=%d K=%d taps=%d N=%ld res=%d: per k-step phases1-3 %.0f | barrier wait %.0f | phase4+DMA issue %.0f | loop top %.0f cycles; per tile epilogue %.0f cycles (%.1f k-steps per tile)\n",
-                                    a.M, a.K, a.taps, a.N, a.res16 ? 1 : 0, sum[0] / steps, sum[1] / steps, sum[2] / steps, sum[4] / steps, sum[3] / tiles_, steps / tiles_);
+                            fprintf(stderr, "[h16 stamps] M=%d K=%d taps=%d N=%ld res=%d: per k-step phases1-3 %.0f (+ mid barrier %.0f) | barrier wait %.0f | phase4+DMA issue %.0f | loop top %.0f cycles; per tile epilogue %.0f cycles (%.1f k-steps per tile)\n",
+                                    a.M, a.K, a.taps, a.N, a.res16 ? 1 : 0, sum[0] / steps, mid / steps, sum[1] / steps, sum[2] / steps, sum[4] / steps, sum[3] / tiles_, steps / tiles_);
                     }
                     return 0;
                 }
