@@ -25,6 +25,12 @@ constexpr int HK = 64;                          // halves per k-step row (128 by
 constexpr int KSTEP = 384 * 128, H16_LDS = 3 * KSTEP;
 __device__ __attribute__((aligned(128))) unsigned short g_zero_page_h[64];     // 128 B of zeros
 
+#ifndef PP_PHASES
+#define PP_PHASES 2               // phases per K-tile of the ping-pong kernel: 2 (32-MFMA clusters) or 4 (16)
+#endif
+#ifndef PP_ABLATE
+#define PP_ABLATE 0               // development builds only (tools/…): 1 no staging DMA, 2 staging from cache-resident rows, 3 fragments read once, 4 one MFMA per quadrant
+#endif
 #ifndef H16_PERS_EARLY
 #define H16_PERS_EARLY 1          // 0: the round-4 first form of the persistent kernel's k-step (one barrier, all pieces in phase 4) for A/B builds
 #endif
@@ -120,7 +126,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
         }
     }
     auto stage = [&](int ks, char* base) {               // base: this k-step's 48 KiB (rows 0..383 of 128 B)
-        const int tap = ks / steps_per_tap, kc = (ks - tap * steps_per_tap) * HK;
+        const int kq = ks / a.taps, tap = ks - kq * a.taps, kc = kq * HK;      // the taps of a 64-channel slice back to back (every kernel of the family: one summation order)
         char* la = base + wv * 1024;
 #pragma unroll
         for (int p = 0; p < AP; ++p) glds16(arow[p] + (size_t)tap * a.M * a.K + kc, la + p * 8192);
@@ -310,7 +316,8 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
     const char* st_a = Ab;
     tap_rows(0);
     auto st_advance = [&]() {
-        if (++st_kq == steps_per_tap) { st_kq = 0; ++st_tap; if (st_tap < a.taps) tap_rows(st_tap); }
+        if (++st_tap == a.taps) { st_tap = 0; ++st_kq; }
+        tap_rows(st_tap);
         st_a = Ab + (size_t)st_tap * a_tap + (size_t)st_kq * 128;
     };
     auto piece = [&](int k, unsigned slot_lds) {              // k < XP: pixel rows, then the AP weight pieces
@@ -441,6 +448,107 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
 }
 
 
+// Epilogue of a persistent tile, straight from the accumulators (acc[i][j]: row tile i, pixel tile j of the wave's 128 x 64 output;
+// wm / wn: the wave's position in the tile): bias, residual, ReLU, GroupNorm statistics, stores; leaves the accumulators zeroed.
+template <int BM, bool WIDE>
+__device__ __forceinline__ void pers_epilogue(const GemmH16Args& a, f32x4 (&acc)[8][4], long ctile, int ny, int wm, int wn, int q, int r16) {
+    constexpr int BN = BM == 256 ? 256 : 512, MT = 8;
+    const long tx = ctile / ny;
+    const int m0 = (int)(ctile - tx * ny) * BM;
+    const long n0 = tx * BN;
+    unsigned nrow[4];                                        // element offset of the lane's four pixel rows (N * ldc < 2^31: launcher)
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long n = n0 + wn * 64 + j * 16 + r16;
+        ok[j] = n < a.N;
+        nrow[j] = (unsigned)((ok[j] ? n : a.N - 1) * a.ldc);
+    }
+    const int mw = m0 + wm * 128;                            // first output channel of this wave
+    if constexpr (WIDE) {
+        // f16 map out (the common case): 16-BYTE stores.  A lane holds 4 channels x 1 pixel per accumulator tile (8 bytes as f16);
+        // lanes q / q ^ 1 exchange halves (one v_permlane16_swap per dword) so that every lane ends up with 8 consecutive
+        // channels — even q: of row tile 2p, odd q: of row tile 2p + 1 — and a row tile pair costs one 16-byte store per pixel
+        // block instead of two 8-byte ones (the epilogue of a short-K tile is bound by the NUMBER of its store instructions:
+        // 32 per lane were ~9 us of a 17 us K = 256 tile).  The f16 residual is fetched in the same chunks and un-swapped.
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {                        // row tile pairs (2p, 2p + 1)
+            const int t0 = 2 * p, t1 = t0 + 1;
+            const unsigned coff = (unsigned)(mw + (t0 + (q & 1)) * 16 + (q >> 1) * 8);
+            constexpr int JB = BM == 256 ? 4 : 2;              // residual chunks in flight (the 128 x 512 form has 16 more registers of staging state)
+            u32x4 rc[JB];
+            const float4 z4 = float4{0.f, 0.f, 0.f, 0.f};
+            const float4 b0 = a.shift ? *(const float4*)(a.shift + mw + t0 * 16 + q * 4) : z4;
+            const float4 b1 = a.shift ? *(const float4*)(a.shift + mw + t1 * 16 + q * 4) : z4;
+            float s10 = 0.f, s20 = 0.f, s11 = 0.f, s21 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (a.res16 && j % JB == 0) {
+#pragma unroll
+                    for (int jj = 0; jj < JB; ++jj) rc[jj] = *(const u32x4*)(a.res16 + nrow[j + jj] + coff);
+                }
+                f32x4 v0 = acc[t0][j], v1 = acc[t1][j];
+                v0[0] += b0.x; v0[1] += b0.y; v0[2] += b0.z; v0[3] += b0.w;
+                v1[0] += b1.x; v1[1] += b1.y; v1[2] += b1.z; v1[3] += b1.w;
+                if (a.res16) {
+                    const auto h0 = __builtin_amdgcn_permlane16_swap(rc[j % JB][0], rc[j % JB][2], false, false);
+                    const auto h1 = __builtin_amdgcn_permlane16_swap(rc[j % JB][1], rc[j % JB][3], false, false);
+                    const f16x4 hx = __builtin_bit_cast(f16x4, u32x2{h0[0], h1[0]}), hy = __builtin_bit_cast(f16x4, u32x2{h0[1], h1[1]});
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v0[r] += (float)hx[r]; v1[r] += (float)hy[r]; }
+                }
+                if (a.relu) {
+                    v0 = f32x4{relu_nan(v0[0]), relu_nan(v0[1]), relu_nan(v0[2]), relu_nan(v0[3])};
+                    v1 = f32x4{relu_nan(v1[0]), relu_nan(v1[1]), relu_nan(v1[2]), relu_nan(v1[3])};
+                }
+                if (ok[j]) { stats_add(s10, s20, v0); stats_add(s11, s21, v1); }
+                const u32x2 ox = __builtin_bit_cast(u32x2, f16x4{(_Float16)v0[0], (_Float16)v0[1], (_Float16)v0[2], (_Float16)v0[3]});
+                const u32x2 oy = __builtin_bit_cast(u32x2, f16x4{(_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]});
+                const auto x0 = __builtin_amdgcn_permlane16_swap(ox[0], oy[0], false, false);
+                const auto x1 = __builtin_amdgcn_permlane16_swap(ox[1], oy[1], false, false);
+                if (ok[j]) *(u32x4*)(a.C16 + nrow[j] + coff) = u32x4{x0[0], x1[0], x0[1], x1[1]};
+                acc[t0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[t1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (a.stats) {
+                stats_store(s10, s20, a.stats, (n0 + wn * 64) >> 6, a.N >> 6, a.ldc >> 2, (mw + t0 * 16 + q * 4) >> 2, r16);
+                stats_store(s11, s21, a.stats, (n0 + wn * 64) >> 6, a.N >> 6, a.ldc >> 2, (mw + t1 * 16 + q * 4) >> 2, r16);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ii = 0; ii < MT; ++ii) {                    // fp32 map out and / or fp32 residual (rare: a classifier's last block): plain form
+            const float4 b4 = a.shift ? *(const float4*)(a.shift + mw + ii * 16 + q * 4) : float4{0.f, 0.f, 0.f, 0.f};
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned off = nrow[j] + mw + ii * 16 + q * 4;
+                f32x4 v = acc[ii][j];
+                v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                if (a.res) { const float4 rr = *(const float4*)(a.res + off); v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+                if (a.res16) {
+                    const f16x4 rh = *(const f16x4*)(a.res16 + off);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rh[r];
+                }
+                if (a.relu) v = f32x4{relu_nan(v[0]), relu_nan(v[1]), relu_nan(v[2]), relu_nan(v[3])};
+                if (ok[j]) {
+                    if (a.C) *(float4*)(a.C + off) = float4{v[0], v[1], v[2], v[3]};
+                    if (a.C16) *(f16x4*)(a.C16 + off) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    stats_add(s1, s2, v);
+                }
+            }
+            if (a.stats) stats_store(s1, s2, a.stats, (n0 + wn * 64) >> 6, a.N >> 6, a.ldc >> 2, (mw + ii * 16 + q * 4) >> 2, r16);
+        }
+#pragma unroll
+        for (int ii = 0; ii < MT; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[ii][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------------------------------
 // Persistent form of the register-prefetched tile (round 4).  One workgroup per CU walks over output tiles; the 2-slot k-step ring
 // NEVER drains between them: the staging cursor runs two k-steps ahead of the compute cursor through the concatenated k-steps of
@@ -512,16 +620,16 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
     };
     auto st_advance = [&]() {                                        // after a k-step's pieces have been issued
         --st_left;
-        if (++st_kq == steps_per_tap) {
-            st_kq = 0;
-            if (++st_tap == a.taps) {
-                st_tap = 0;
+        if (++st_tap == a.taps) {                                    // tap-inner order, as in every kernel of the family
+            st_tap = 0;
+            if (++st_kq == steps_per_tap) {
+                st_kq = 0;
                 stile += G8;
                 if (st_left > 0) tile_rows(stile);
             }
-            st_dy = a.taps == 9 ? st_tap / 3 - 1 : 0;
-            st_dx = a.taps == 9 ? st_tap % 3 - 1 : 0;
         }
+        st_dy = a.taps == 9 ? st_tap / 3 - 1 : 0;
+        st_dx = a.taps == 9 ? st_tap % 3 - 1 : 0;
         st_a = Ab + (size_t)st_tap * a_tap + (size_t)st_kq * 128;
     };
     const h16_t* zrow = g_zero_page_big + (lane & 7) * 8;
@@ -660,102 +768,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
         stamp(2);
         if (!last) { ++s; continue; }
         // ---- the tile is complete: epilogue straight from the accumulators (the fragment registers are free here) ---------------
-        {
-            const long tx = ctile / ny;
-            const int m0 = (int)(ctile - tx * ny) * BM;
-            const long n0 = tx * BN;
-            unsigned nrow[4];                                        // element offset of the lane's four pixel rows (N * ldc < 2^31: launcher)
-            bool ok[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const long n = n0 + wn * 64 + j * 16 + r16;
-                ok[j] = n < a.N;
-                nrow[j] = (unsigned)((ok[j] ? n : a.N - 1) * a.ldc);
-            }
-            const int mw = m0 + wm * 128;                            // first output channel of this wave
-            if constexpr (WIDE) {
-                // f16 map out (the common case): 16-BYTE stores.  A lane holds 4 channels x 1 pixel per accumulator tile (8 bytes as f16);
-                // lanes q / q ^ 1 exchange halves (one v_permlane16_swap per dword) so that every lane ends up with 8 consecutive
-                // channels — even q: of row tile 2p, odd q: of row tile 2p + 1 — and a row tile pair costs one 16-byte store per pixel
-                // block instead of two 8-byte ones (the epilogue of a short-K tile is bound by the NUMBER of its store instructions:
-                // 32 per lane were ~9 us of a 17 us K = 256 tile).  The f16 residual is fetched in the same chunks and un-swapped.
-                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {                        // row tile pairs (2p, 2p + 1)
-                    const int t0 = 2 * p, t1 = t0 + 1;
-                    const unsigned coff = (unsigned)(mw + (t0 + (q & 1)) * 16 + (q >> 1) * 8);
-                    constexpr int JB = BM == 256 ? 4 : 2;              // residual chunks in flight (the 128 x 512 form has 16 more registers of staging state)
-                    u32x4 rc[JB];
-                    const float4 z4 = float4{0.f, 0.f, 0.f, 0.f};
-                    const float4 b0 = a.shift ? *(const float4*)(a.shift + mw + t0 * 16 + q * 4) : z4;
-                    const float4 b1 = a.shift ? *(const float4*)(a.shift + mw + t1 * 16 + q * 4) : z4;
-                    float s10 = 0.f, s20 = 0.f, s11 = 0.f, s21 = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (a.res16 && j % JB == 0) {
-#pragma unroll
-                            for (int jj = 0; jj < JB; ++jj) rc[jj] = *(const u32x4*)(a.res16 + nrow[j + jj] + coff);
-                        }
-                        f32x4 v0 = acc[t0][j], v1 = acc[t1][j];
-                        v0[0] += b0.x; v0[1] += b0.y; v0[2] += b0.z; v0[3] += b0.w;
-                        v1[0] += b1.x; v1[1] += b1.y; v1[2] += b1.z; v1[3] += b1.w;
-                        if (a.res16) {
-                            const auto h0 = __builtin_amdgcn_permlane16_swap(rc[j % JB][0], rc[j % JB][2], false, false);
-                            const auto h1 = __builtin_amdgcn_permlane16_swap(rc[j % JB][1], rc[j % JB][3], false, false);
-                            const f16x4 hx = __builtin_bit_cast(f16x4, u32x2{h0[0], h1[0]}), hy = __builtin_bit_cast(f16x4, u32x2{h0[1], h1[1]});
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) { v0[r] += (float)hx[r]; v1[r] += (float)hy[r]; }
-                        }
-                        if (a.relu) {
-                            v0 = f32x4{relu_nan(v0[0]), relu_nan(v0[1]), relu_nan(v0[2]), relu_nan(v0[3])};
-                            v1 = f32x4{relu_nan(v1[0]), relu_nan(v1[1]), relu_nan(v1[2]), relu_nan(v1[3])};
-                        }
-                        if (ok[j]) { stats_add(s10, s20, v0); stats_add(s11, s21, v1); }
-                        const u32x2 ox = __builtin_bit_cast(u32x2, f16x4{(_Float16)v0[0], (_Float16)v0[1], (_Float16)v0[2], (_Float16)v0[3]});
-                        const u32x2 oy = __builtin_bit_cast(u32x2, f16x4{(_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]});
-                        const auto x0 = __builtin_amdgcn_permlane16_swap(ox[0], oy[0], false, false);
-                        const auto x1 = __builtin_amdgcn_permlane16_swap(ox[1], oy[1], false, false);
-                        if (ok[j]) *(u32x4*)(a.C16 + nrow[j] + coff) = u32x4{x0[0], x1[0], x0[1], x1[1]};
-                        acc[t0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        acc[t1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                    if (a.stats) {
-                        stats_store(s10, s20, a.stats, (n0 + wn * 64) >> 6, a.N >> 6, a.ldc >> 2, (mw + t0 * 16 + q * 4) >> 2, r16);
-                        stats_store(s11, s21, a.stats, (n0 + wn * 64) >> 6, a.N >> 6, a.ldc >> 2, (mw + t1 * 16 + q * 4) >> 2, r16);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int ii = 0; ii < MT; ++ii) {                    // fp32 map out and / or fp32 residual (rare: a classifier's last block): plain form
-                    const float4 b4 = a.shift ? *(const float4*)(a.shift + mw + ii * 16 + q * 4) : float4{0.f, 0.f, 0.f, 0.f};
-                    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const unsigned off = nrow[j] + mw + ii * 16 + q * 4;
-                        f32x4 v = acc[ii][j];
-                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-                        if (a.res) { const float4 rr = *(const float4*)(a.res + off); v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
-                        if (a.res16) {
-                            const f16x4 rh = *(const f16x4*)(a.res16 + off);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += (float)rh[r];
-                        }
-                        if (a.relu) v = f32x4{relu_nan(v[0]), relu_nan(v[1]), relu_nan(v[2]), relu_nan(v[3])};
-                        if (ok[j]) {
-                            if (a.C) *(float4*)(a.C + off) = float4{v[0], v[1], v[2], v[3]};
-                            if (a.C16) *(f16x4*)(a.C16 + off) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                            stats_add(s1, s2, v);
-                        }
-                    }
-                    if (a.stats) stats_store(s1, s2, a.stats, (n0 + wn * 64) >> 6, a.N >> 6, a.ldc >> 2, (mw + ii * 16 + q * 4) >> 2, r16);
-                }
-#pragma unroll
-                for (int ii = 0; ii < MT; ++ii)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[ii][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
+        pers_epilogue<BM, WIDE>(a, acc, ctile, ny, wm, wn, q, r16);
         stamp(3);
         ctile += G8;
         s = 0;
@@ -775,6 +788,276 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, in
             dbg[(size_t)blockIdx.x * 8 + 7] = tacc[5];
         }
     }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------------
+// Ping-pong form of the persistent tile (round 4, second form).  Same tile (256 x 256, or 128 x 512 for the 128-channel layers),
+// same 8 waves with a 128 x 64 output each, same ring that never drains across tiles — but the two waves of a SIMD no longer do the
+// same thing at the same time.  Waves 0-3 and waves 4-7 (one of each per SIMD) run half a phase apart: while one group contracts
+// a quadrant of its output (16 MFMAs, the matrix pipe's 256 cycles), the other reads its next fragments from LDS and issues its
+// share of the staging DMA; a barrier, and the roles swap.  In the first persistent form both waves of a SIMD issued their eight
+// DMA pieces in the same phase and then both waited for them: the stamps showed the matrix pipe busy half of a k-step.
+//   K-tile (64 deep) = four half-tiles: A0 A1 (rows h * 64 .. + 64 of each wave row's 128) and B0 B1 (pixels h * 32 .. + 32 of each
+//   wave column's 64); two K-tiles resident (2 x 64 KiB, or 2 x 80 KiB for 128 x 512).  Four phases per K-tile:
+//       phase 0: read A0 (8 x ds_read_b128), B0 (4)   stage B1 of the cursor K-tile     quadrant (0, 0)
+//       phase 1: read B1 (4)                          stage A1, advance the cursor      quadrant (0, 1)
+//       phase 2: read A1 (8)                          stage A0 of the new cursor        quadrant (1, 1)
+//       phase 3: (B0 is still in registers)           stage B0; wait                    quadrant (1, 0)
+//   each phase = { reads + DMA issue | s_barrier | lgkmcnt(0), 16 MFMAs | s_barrier }.  The cursor runs 1.5 K-tiles ahead; a half-tile
+//   is overwritten two phases or more after the phase that last read it (with the groups half a phase apart, one phase is not
+//   enough: the later group's reads retire behind the barrier the earlier group's next phase starts at).  ONE counted wait per
+//   K-tile, in phase 3 ahead of its first barrier: all of the next K-tile has landed, the two half-tiles just issued stay in flight;
+//   the first read of that K-tile comes a phase later, behind a barrier both groups' waits precede.
+//   At a tile's end the leading group waits one barrier for the other, both run the epilogue at once, and the trailing group waits
+//   one barrier to fall half a phase behind again.
+// ----------------------------------------------------------------------------------------------------------------------------
+template <int BM, bool WIDE>
+__global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int nx) {
+    constexpr int WR = BM / 128, WC = 8 / WR, BN = WC * 64;
+    constexpr int AH = BM / 2, BH = BN / 2;                         // rows of an A / B half-tile
+    constexpr int APW = AH / 64, BPW = BH / 64;                     // 1-KiB pieces (8 rows x 128 B) per wave and half-tile
+    constexpr int AHB = AH * 128, BHB = BH * 128, BUFB = 2 * (AHB + BHB);      // a K-tile in LDS: A0 A1 B0 B1
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = WR == 2 ? wv >> 2 : 0, wc = WR == 2 ? wv & 3 : wv, grp = wv >> 2, q = lane >> 4, r16 = lane & 15;
+    const int ny = a.M / BM;
+    const long T = (long)nx * ny;
+    const int G8 = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7), jw = (int)(blockIdx.x >> 3);
+    const long chunk = (((T + 7) / 8 + ny - 1) / ny) * ny;          // whole pixel tiles per XCD
+    const long lo = xcd * chunk, hi = lo + chunk < T ? lo + chunk : T;
+    long ctile = lo + jw;                                            // compute cursor (tile id)
+    if (ctile >= hi) return;
+    const int my_tiles = (int)((hi - ctile + G8 - 1) / G8);
+    const int steps_per_tap = a.K / HK, nsteps = a.taps * steps_per_tap;
+    const int l8 = lane >> 3, ch8 = ((lane & 7) ^ (((wv & 1) * 4 + (l8 >> 1)) & 7)) * 8;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    const unsigned voffA = (unsigned)((l8 * a.K + ch8) * 2);
+    const size_t a_tap = (size_t)a.M * a.K * 2, a_row = (size_t)a.K * 2;
+    const int st = a.stride > 1 ? a.stride : 1;
+    const int Wo = (a.W - 1) / st + 1, Ho = (a.H - 1) / st + 1, hw = Ho * Wo;
+    // ---- staging cursor: tile, tap, K-tile inside the tap; per-lane pixel rows of the staging tile ---------------------------
+    long stile = ctile;
+    int st_tap = 0, st_kq = 0, st_left = my_tiles * nsteps;         // K-tiles not completely staged yet
+    unsigned st_lds = lds0;                                          // the cursor K-tile's buffer
+    int xpix[2 * BPW], xyx[2 * BPW];                                 // [h * BPW + p]: image base pixel (or -1: past N), (y << 16) | x
+    int st_dy = a.taps == 9 ? -1 : 0, st_dx = st_dy;
+    const char* Ab = nullptr;
+    const char* st_a = nullptr;
+    auto tile_rows = [&](long id) {
+        const long tx = id / ny;
+        const int mb = (int)(id - tx * ny);
+        Ab = (const char*)(a.A + (size_t)mb * BM * a.K);
+        const unsigned n0 = (unsigned)tx * BN;                       // N < 2^31 (launcher): 32-bit pixel arithmetic
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int p = 0; p < BPW; ++p) {
+                const unsigned n = n0 + (2 * p + (wv >> 2)) * 64 + h * 32 + (wv & 3) * 8 + l8;
+                xpix[h * BPW + p] = -1; xyx[h * BPW + p] = 0;
+                if (n < (unsigned)a.N) {
+                    const unsigned b = n / (unsigned)hw, pix = n - b * (unsigned)hw, py = pix / (unsigned)Wo;
+                    xpix[h * BPW + p] = (int)(b * (unsigned)(a.H * a.W));
+                    xyx[h * BPW + p] = (int)(((py * st) << 16) | ((pix - py * Wo) * st));
+                }
+            }
+    };
+    // K-tile order inside a tile: the nine taps of one 64-channel slice back to back, then the next slice.  The taps of a slice read
+    // the SAME pixel rows shifted by a pixel or a row (32 KiB per workgroup and slice), so eight of the nine reads hit the XCD's L2;
+    // tap-major order (all slices of a tap, then the next tap) re-reads the tile's whole input — 256 px x K x 2 B per workgroup,
+    // 8 MB per XCD at K = 512 — nine times from beyond the 4 MB L2 (measured: 2 % of the UNet's conv time).  Every kernel of the
+    // family walks the K-tiles in this order, so a sample's f16 result does not depend on which kernel its batch size selects.
+    auto st_advance = [&]() {                                        // after the cursor K-tile's last half-tile (A1) has been issued
+        --st_left;
+        st_lds = lds0 + ((st_lds - lds0) ^ BUFB);
+        if (++st_tap == a.taps) {
+            st_tap = 0;
+            if (++st_kq == steps_per_tap) {
+                st_kq = 0;
+                stile += G8;
+                if (st_left > 0) tile_rows(stile);
+            }
+        }
+        st_dy = a.taps == 9 ? st_tap / 3 - 1 : 0;
+        st_dx = a.taps == 9 ? st_tap % 3 - 1 : 0;
+        st_a = Ab + (size_t)st_tap * a_tap + (size_t)st_kq * 128;
+    };
+    const h16_t* zrow = g_zero_page_big + (lane & 7) * 8;
+    auto stageA = [&](int h) {                                       // weights: wave-uniform base + one lane offset
+#if PP_ABLATE != 1
+#pragma unroll
+        for (int p = 0; p < APW; ++p)
+            dma16s((PP_ABLATE == 2 ? Ab : st_a) + (size_t)(p * 128 + h * 64 + wv * 8) * a_row, voffA, st_lds + h * AHB + (p * 64 + wv * 8) * 128);
+#endif
+    };
+    auto stageB = [&](int h) {                                       // gathered pixel rows (a tap outside the image: the zero page)
+#pragma unroll
+        for (int p = 0; p < BPW; ++p) {
+            const int k = h * BPW + p;
+            const int yy = (xyx[k] >> 16) + st_dy, xq = (xyx[k] & 0xffff) + st_dx;
+            const bool ok = xpix[k] >= 0 && (unsigned)yy < (unsigned)a.H && (unsigned)xq < (unsigned)a.W;
+            const h16_t* src = ok ? a.X + ((long)xpix[k] + yy * a.W + xq) * a.ldx + ch8 + st_kq * HK : zrow;
+#if PP_ABLATE == 2
+            src = ok ? zrow + 64 : zrow;
+#endif
+#if PP_ABLATE != 1
+            dma16v(src, st_lds + 2 * AHB + h * BHB + (p * 64 + wv * 8) * 128);
+#else
+            asm volatile("" ::"v"(src));
+#endif
+        }
+    };
+    tile_rows(stile);
+    st_a = Ab;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int sw = (r16 >> 1) & 7;
+    const int fk[2] = {r16 * 128 + ((q ^ sw) * 16), r16 * 128 + (((4 + q) ^ sw) * 16)};
+    const int aoff = wr * 8192, boff = 2 * AHB + wc * 4096;
+    f16x8 AF[4][2], B0[2][2], B1[2][2];
+    bool rd = true;                                                  // (PP_ABLATE == 3: fragments read once)
+    auto ldA = [&](const char* buf, int i) {
+        if (PP_ABLATE == 3 && !rd) return;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) AF[mt][kh] = *(const f16x8*)(buf + i * AHB + aoff + mt * 2048 + fk[kh]);
+    };
+    auto ldB = [&](f16x8 (&U)[2][2], const char* buf, int j) {
+        if (PP_ABLATE == 3 && !rd) return;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) U[nt][kh] = *(const f16x8*)(buf + j * BHB + boff + nt * 2048 + fk[kh]);
+    };
+#define PP_BARRIER()                                 \
+    do {                                             \
+        __builtin_amdgcn_sched_barrier(0);           \
+        __builtin_amdgcn_s_barrier();                \
+        asm volatile("" ::: "memory");               \
+        __builtin_amdgcn_sched_barrier(0);           \
+    } while (0)
+    // the quadrant (i, j) of the wave's output: 4 x 2 accumulator tiles x the K-tile's two 32-deep halves
+#define PP_MFMA(BU, i, j)                                                                                                    \
+    _Pragma("unroll") for (int kh_ = 0; kh_ < 2; ++kh_)                                                                      \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_)                                                                  \
+            _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)                                                              \
+                if (PP_ABLATE != 4 || (mt_ | nt_ | kh_) == 0)                                                                \
+                    acc[(i) * 4 + mt_][(j) * 2 + nt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                              \
+                        AF[mt_][kh_], BU[nt_][kh_], acc[(i) * 4 + mt_][(j) * 2 + nt_], 0, 0, 0);
+#define PP_QUAD(BU, i, j)                                                                                                    \
+    do {                                                                                                                     \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                                       \
+        PP_MFMA(BU, i, j)                                                                                                    \
+        __builtin_amdgcn_s_setprio(0);                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    } while (0)
+#define PP_QUAD2(BU, i, j, BV, i2, j2)                                                                                       \
+    do {                                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                                       \
+        PP_MFMA(BU, i, j)                                                                                                    \
+        PP_MFMA(BV, i2, j2)                                                                                                  \
+        __builtin_amdgcn_s_setprio(0);                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    } while (0)
+    // prologue: K-tile 0 staged whole, A0 / B0 of K-tile 1 behind it; K-tile 0 landed
+    stageA(0); stageB(0); stageB(1); stageA(1);
+    st_advance();
+    if (st_left > 0) {
+        stageA(0); stageB(0);
+        if (APW + BPW == 4) { GH_WAIT_BARRIER(4); } else { GH_WAIT_BARRIER(5); }
+    } else {
+        GH_WAIT_BARRIER(0);
+    }
+    if (grp == 1) PP_BARRIER();                                      // the second group runs half a phase behind
+    const int total = my_tiles * nsteps;
+    int s = 0;                                                       // K-tile inside the compute tile
+    for (int g = 0; g < total; ++g) {
+        const char* cur = smem + (g & 1) * BUFB;
+#if PP_PHASES == 2
+        // phase A: quadrants (0, 0) and (0, 1); the cursor K-tile's B1 and A1 go out (its A0 / B0 went a phase earlier), the cursor advances
+        ldB(B0, cur, 0);
+        ldB(B1, cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        ldA(cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st_left > 0) { stageB(1); stageA(1); st_advance(); }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                          // the reads retire AHEAD of the barrier: what they read may be restaged a phase later
+        PP_BARRIER();
+        PP_QUAD2(B0, 0, 0, B1, 0, 1);
+        PP_BARRIER();
+        // phase B: quadrants (1, 1) and (1, 0); A0 and B0 of the new cursor K-tile; the next K-tile has landed (those two are younger)
+        ldA(cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st_left > 0) {
+            stageA(0); stageB(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (APW + BPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        PP_BARRIER();
+        PP_QUAD2(B1, 1, 1, B0, 1, 0);
+        PP_BARRIER();
+#else
+        // phase 0
+        ldB(B0, cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ldA(cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st_left > 0) stageB(1);
+        PP_BARRIER();
+        PP_QUAD(B0, 0, 0);
+        PP_BARRIER();
+        // phase 1
+        ldB(B1, cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st_left > 0) { stageA(1); st_advance(); }
+        PP_BARRIER();
+        PP_QUAD(B1, 0, 1);
+        PP_BARRIER();
+        // phase 2
+        ldA(cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = st_left > 0;
+        if (more) stageA(0);
+        PP_BARRIER();
+        PP_QUAD(B1, 1, 1);
+        PP_BARRIER();
+        // phase 3: the next K-tile has landed (younger: the A0 and B0 half-tiles of the one after it)
+        if (more) {
+            stageB(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (APW + BPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_BARRIER();
+        PP_QUAD(B0, 1, 0);
+        PP_BARRIER();
+#endif
+        if (PP_ABLATE == 3 && g >= 1) rd = false;
+        if (s != nsteps - 1) { ++s; continue; }
+        // ---- the tile is complete: both groups run the epilogue at the same time -------------------------------------------------
+        if (grp == 0) PP_BARRIER();
+        pers_epilogue<BM, WIDE>(a, acc, ctile, ny, wr, wc, q, r16);
+        ctile += G8;
+        s = 0;
+        if (grp == 1 && g + 1 < total) PP_BARRIER();
+    }
+#undef PP_QUAD
+#undef PP_QUAD2
+#undef PP_MFMA
+#undef PP_BARRIER
 }
 
 int gemm_h16_configure() {
@@ -803,6 +1086,14 @@ int gemm_h16_configure() {
     e = hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<128, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_h16_pp_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_h16_pp_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_h16_pp_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_h16_pp_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
     if (e != hipSuccess) return (int)e;
     return (int)hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
 }
@@ -847,6 +1138,15 @@ int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
                             fprintf(stderr, "[h16 stamps] M=%d K=%d taps=%d N=%ld res=%d: per k-step phases1-3 %.0f (+ mid barrier %.0f) | barrier wait %.0f | phase4+DMA issue %.0f | loop top %.0f cycles; per tile epilogue %.0f cycles (%.1f k-steps per tile)\n",
                                     a.M, a.K, a.taps, a.N, a.res16 ? 1 : 0, sum[0] / steps, mid / steps, sum[1] / steps, sum[2] / steps, sum[4] / steps, sum[3] / tiles_, steps / tiles_);
                     }
+                    return 0;
+                }
+                // the ping-pong form (DMAD_H16_PP=0: the first persistent form, for A/B runs)
+                static const bool pp_on = []() { const char* v = getenv("DMAD_H16_PP"); return !(v && v[0] == '0'); }();
+                if (pp_on) {
+                    if (bm == 256 && wide) hipLaunchKernelGGL((gemm_h16_pp_kernel<256, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
+                    else if (bm == 256) hipLaunchKernelGGL((gemm_h16_pp_kernel<256, false>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
+                    else if (wide) hipLaunchKernelGGL((gemm_h16_pp_kernel<128, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp);
+                    else hipLaunchKernelGGL((gemm_h16_pp_kernel<128, false>), dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp);
                     return 0;
                 }
                 if (bm == 256 && wide) hipLaunchKernelGGL((gemm_h16_pers_kernel<256, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
