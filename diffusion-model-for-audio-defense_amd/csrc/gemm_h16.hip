@@ -29,7 +29,7 @@ __device__ __attribute__((aligned(128))) unsigned short g_zero_page_h[64];     /
 #define PP_PHASES 2               // phases per K-tile of the ping-pong kernel: 2 (32-MFMA clusters) or 4 (16)
 #endif
 #ifndef PP_ABLATE
-#define PP_ABLATE 0               // development builds only (tools/…): 1 no staging DMA, 2 staging from cache-resident rows, 3 fragments read once, 4 one MFMA per quadrant
+#define PP_ABLATE 0               // development builds only (tools/…): 1 no staging DMA, 2 staging from cache-resident rows (5: the pixel rows only; 7: 32 real pixel rows), 3 fragments read once, 4 one MFMA per quadrant
 #endif
 #ifndef H16_PERS_EARLY
 #define H16_PERS_EARLY 1          // 0: the round-4 first form of the persistent kernel's k-step (one barrier, all pieces in phase 4) for A/B builds
@@ -259,8 +259,17 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_kernel(GemmH16Args a) {
 namespace {
 constexpr int BIG_LDS_256 = 2 * 512 * 128, BIG_LDS_128 = 2 * 640 * 128, BIG_KMAX = 2048;      // 128 KiB / 160 KiB (all of a CU's LDS)
 __device__ __attribute__((aligned(128))) unsigned short g_zero_page_big[BIG_KMAX + 64];
+// Optional non-temporal hint on the weight pieces (a weight K-tile is read once per workgroup and tile, and its 32 KiB pass through
+// the CU's 32 KiB L1 between two taps that read nearly the same pixel rows).
+#ifndef H16_NT_WEIGHTS
+#define H16_NT_WEIGHTS 0          // measured: 2 % slower on the UNet's convs (the 1 x 1 / qkv convs 10 %), the pixel rows do not stay in L1 either way
+#endif
 __device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, unsigned lds) {
+#if H16_NT_WEIGHTS
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+#else
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+#endif
 }
 __device__ __forceinline__ void dma16v(const void* vaddr, unsigned lds) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds) : "memory");
@@ -867,6 +876,15 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
     // tap-major order (all slices of a tap, then the next tap) re-reads the tile's whole input — 256 px x K x 2 B per workgroup,
     // 8 MB per XCD at K = 512 — nine times from beyond the 4 MB L2 (measured: 2 % of the UNet's conv time).  Every kernel of the
     // family walks the K-tiles in this order, so a sample's f16 result does not depend on which kernel its batch size selects.
+    const h16_t* st_x = a.X;                                         // the cursor slice's input map, row stride and channel offset:
+    int st_ld = a.ldx, st_ko = 0;                                    // the second part of a concatenated input (th.cat(dim=1)) from a.ksplit on
+    auto slice_source = [&]() {
+        const int kc = st_kq * HK;
+        const bool second = a.X2 != nullptr && kc >= a.ksplit;
+        st_x = second ? a.X2 : a.X;
+        st_ld = second ? a.ldx2 : a.ldx;
+        st_ko = second ? kc - a.ksplit : kc;
+    };
     auto st_advance = [&]() {                                        // after the cursor K-tile's last half-tile (A1) has been issued
         --st_left;
         st_lds = lds0 + ((st_lds - lds0) ^ BUFB);
@@ -881,6 +899,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
         st_dy = a.taps == 9 ? st_tap / 3 - 1 : 0;
         st_dx = a.taps == 9 ? st_tap % 3 - 1 : 0;
         st_a = Ab + (size_t)st_tap * a_tap + (size_t)st_kq * 128;
+        slice_source();
     };
     const h16_t* zrow = g_zero_page_big + (lane & 7) * 8;
     auto stageA = [&](int h) {                                       // weights: wave-uniform base + one lane offset
@@ -896,9 +915,11 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
             const int k = h * BPW + p;
             const int yy = (xyx[k] >> 16) + st_dy, xq = (xyx[k] & 0xffff) + st_dx;
             const bool ok = xpix[k] >= 0 && (unsigned)yy < (unsigned)a.H && (unsigned)xq < (unsigned)a.W;
-            const h16_t* src = ok ? a.X + ((long)xpix[k] + yy * a.W + xq) * a.ldx + ch8 + st_kq * HK : zrow;
-#if PP_ABLATE == 2
+            const h16_t* src = ok ? st_x + ((long)xpix[k] + yy * a.W + xq) * st_ld + ch8 + st_ko : zrow;
+#if PP_ABLATE == 2 || PP_ABLATE == 5
             src = ok ? zrow + 64 : zrow;
+#elif PP_ABLATE == 7
+            src = ok ? st_x + (long)(l8 + 8 * (wv & 3)) * st_ld + ch8 + st_ko : zrow;      // 32 real (non-zero) rows: cache-resident, same operand statistics
 #endif
 #if PP_ABLATE != 1
             dma16v(src, st_lds + 2 * AHB + h * BHB + (p * 64 + wv * 8) * 128);
@@ -1117,14 +1138,16 @@ int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
     static const bool pers_on = []() { const char* v = getenv("DMAD_H16_PERS"); return !(v && v[0] == '0'); }();
     const bool st16 = a.stats && a.stats_px == 16;           // 16-pixel statistics blocks: the 384-row kernel only
     if (a.stats && a.stats_px != 0 && a.stats_px != 16 && a.stats_px != 64) { ++g_bad; return -1; }
-    if (pers_on && big_on && ng == 1 && !two && !st16 && a.K <= BIG_KMAX && a.H < 32768 && a.W < 32768 && a.N * (long)a.ldx < (1l << 31)) {
+    static const bool pp_on = []() { const char* v = getenv("DMAD_H16_PP"); return !(v && v[0] == '0'); }();      // DMAD_H16_PP=0: the first persistent form (A/B runs)
+    if (pers_on && big_on && ng == 1 && (!two || (pp_on && a.N * (long)a.ldx2 < (1l << 31))) && !st16 && a.K <= BIG_KMAX && a.H < 32768 && a.W < 32768 &&
+        a.N * (long)a.ldx < (1l << 31)) {
         const int bm = a.M % 256 == 0 ? 256 : (a.M == 128 ? 128 : 0);
         if (bm) {
             const long nxp = (a.N + (bm == 256 ? 255 : 511)) / (bm == 256 ? 256 : 512), tiles = nxp * (a.M / bm);
             if (tiles >= g_h16_cus && nxp < (1l << 31) && a.N * (long)a.ldc < (1l << 31)) {
                 const bool wide = a.C16 && !a.C && !a.res && !(a.ldc & 7);
                 static const bool stamps = []() { const char* v = getenv("DMAD_H16_STAMPS"); return v && v[0] == '1'; }();
-                if (stamps && wide) {            // diagnostic: synchronous, prints wave 0's mean cycles per k-step and per tile
+                if (stamps && wide && !two) {            // diagnostic: synchronous, prints wave 0's mean cycles per k-step and per tile
                     static unsigned long long* dbg = nullptr;
                     if (!dbg && hipMalloc((void**)&dbg, (size_t)g_h16_cus * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
                     (void)hipMemsetAsync(dbg, 0, (size_t)g_h16_cus * 64, s);
@@ -1140,8 +1163,7 @@ int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
                     }
                     return 0;
                 }
-                // the ping-pong form (DMAD_H16_PP=0: the first persistent form, for A/B runs)
-                static const bool pp_on = []() { const char* v = getenv("DMAD_H16_PP"); return !(v && v[0] == '0'); }();
+                // the ping-pong form (it also takes a two-part input)
                 if (pp_on) {
                     if (bm == 256 && wide) hipLaunchKernelGGL((gemm_h16_pp_kernel<256, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
                     else if (bm == 256) hipLaunchKernelGGL((gemm_h16_pp_kernel<256, false>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);

@@ -738,6 +738,8 @@ H16_CASES = [   # B, H, cin, cout, taps, stride, c1 (two-part input: first map's
     # the 128 x 512 tile (M = 128): 3x3 with residual, N tail, stride 2, K = 384
     (128, 32, 128, 128, 9, 1, 0, True, 1, False), (129, 32, 128, 128, 9, 1, 0, False, 1, False), (512, 32, 128, 128, 9, 2, 0, False, 1, False),
     (128, 32, 384, 128, 9, 1, 0, True, 1, False),
+    # two-part (concatenated) input through the persistent tiles: the 1x1 skip conv of an output block, a 3x3 with residual and N tail
+    (128, 32, 384, 128, 1, 1, 256, False, 1, False), (257, 16, 512, 256, 9, 1, 256, True, 1, False),
     # ResNeXt29's forms: K = 64, ReLU, 1x1 with stride 2, grouped 3x3 (4 paired / 8 groups; stride 2; small and chip-filling launches)
     (3, 32, 64, 512, 1, 1, 0, False, 1, True), (2, 32, 256, 512, 1, 2, 0, False, 1, False), (2, 16, 512, 512, 9, 1, 0, False, 4, True),
     (3, 16, 1024, 1024, 9, 2, 0, False, 8, True), (64, 32, 512, 512, 9, 1, 0, False, 4, True), (128, 16, 2048, 2048, 9, 2, 0, False, 8, True),
