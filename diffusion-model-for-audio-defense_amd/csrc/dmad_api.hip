@@ -1019,9 +1019,9 @@ bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, 
         H *= 2;
         Hout = H;
         launch_gemm_h16(un_h16_args(o.w1h, o.b1, e->un_uph, nullptr, outh, o.cout, o.cin, 9, B, H, 1, nullptr, outst), s);
-    } else {                                // input conv 1 -> 128 (direct kernel, fp32 arithmetic): no statistics slab
-        if (launch_conv1ch_3x3(in.f, o.w1, o.b1, outf, B, o.cout, s, outh)) { fail(DMAD_ERR_STATE, "input conv: %d output channels > 128", o.cout); return false; }
-        outst = nullptr;
+    } else {                                // input conv 1 -> 128 (direct kernel, fp32 arithmetic): the f16 map and its statistics only
+        if (launch_conv1ch_3x3(in.f, o.w1, o.b1, nullptr, B, o.cout, s, outh, (o.cout & 3) ? nullptr : outst)) { fail(DMAD_ERR_STATE, "input conv: %d output channels > 128", o.cout); return false; }
+        if (o.cout & 3) outst = nullptr;
     }
     *result = UMap{outf, outh, Hout * Hout >= 16 ? outst : nullptr};
     return true;

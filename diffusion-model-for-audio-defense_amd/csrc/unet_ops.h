@@ -7,8 +7,10 @@
 namespace dmad {
 
 // conv 3x3, one input channel, padding 1, bias: in [B][32][32] -> out [B][1024][Cout]   (input_blocks.0.0)
-// out16: optional f16 twin of the output (the 16-bit tier's GEMMs read f16 maps).  Returns -1 for Cout > 128.
-int launch_conv1ch_3x3(const float* in, const float* w, const float* bias, float* out, int B, int Cout, hipStream_t s, h16_t* out16 = nullptr);
+// out16: optional f16 twin of the output (the 16-bit tier's GEMMs read f16 maps; out may then be null); stats: optional GroupNorm
+// statistics of the f16 twin (GemmH16Args::stats layout, 64-pixel blocks).  Returns -1 for Cout > 128.
+int launch_conv1ch_3x3(const float* in, const float* w, const float* bias, float* out, int B, int Cout, hipStream_t s, h16_t* out16 = nullptr,
+                       float* stats = nullptr);
 // conv 3x3, 128 -> 1 channel, padding 1, bias: in [B][1024][128] (NHWC), w [9][128] (tap-major), out [B][1024]   (out.2)
 void launch_conv3x3_c128_to1(const float* in, const float* w, const float* bias, float* out, int B, hipStream_t s);
 void launch_conv3x3_c128_to1_h16(const h16_t* in, const float* w, const float* bias, float* out, int B, hipStream_t s);   // the same on an f16 map

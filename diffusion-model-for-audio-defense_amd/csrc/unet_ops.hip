@@ -7,30 +7,45 @@ namespace dmad {
 namespace {
 inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1) / b); }
 
-// one workgroup per image row, one thread per output channel: its 9 weights live in registers, the 3 x 34 input values the
-// row needs are wave-uniform (scalar loads), every store instruction writes whole 256-byte channel rows
+// one workgroup per pair of image rows (64 pixels: one GroupNorm statistics block), one thread per output channel: its 9 weights live
+// in registers, the input values a row needs are wave-uniform (scalar loads), every store instruction writes whole channel rows.
+// out (fp32 map) and out16 (f16 twin) are both optional; stats != nullptr: the (sum, sum of squares) of the f16-rounded outputs per
+// 64-pixel block and channel quad, in GemmH16Args::stats layout, so that the consumer GroupNorm is the one-pass kernel.
 __global__ void __launch_bounds__(128) conv1ch_3x3_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
-                                                          float* __restrict__ out, int Cout, h16_t* __restrict__ out16) {
-    const int co = threadIdx.x, y = blockIdx.x & 31;
-    const long b = blockIdx.x >> 5;
+                                                          float* __restrict__ out, int Cout, h16_t* __restrict__ out16, float* __restrict__ stats) {
+    const int co = threadIdx.x, yp = blockIdx.x & 15;
+    const long b = blockIdx.x >> 4;
     if (co >= Cout) return;
     float k[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) k[t] = w[co * 9 + t];
     const float bv = bias[co];
     const float* img = in + (b << 10);
-    float* o = out + ((b << 10) + y * 32) * Cout + co;
-    for (int x = 0; x < 32; ++x) {
-        float s = 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < 2; ++r) {
+        const int y = yp * 2 + r;
+        const long row = ((b << 10) + y * 32) * Cout + co;
+        for (int x = 0; x < 32; ++x) {
+            float s = 0.f;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int yy = y + ky - 1, xx = x + kx - 1;
-                if ((unsigned)yy < 32u && (unsigned)xx < 32u) s = fmaf(k[ky * 3 + kx], img[yy * 32 + xx], s);
-            }
-        o[(long)x * Cout] = s + bv;
-        if (out16) out16[((b << 10) + y * 32 + x) * Cout + co] = __builtin_bit_cast(h16_t, (_Float16)(s + bv));
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int yy = y + ky - 1, xx = x + kx - 1;
+                    if ((unsigned)yy < 32u && (unsigned)xx < 32u) s = fmaf(k[ky * 3 + kx], img[yy * 32 + xx], s);
+                }
+            const _Float16 hv = (_Float16)(s + bv);
+            if (out) out[row + (long)x * Cout] = s + bv;
+            if (out16) out16[row + (long)x * Cout] = __builtin_bit_cast(h16_t, hv);
+            const float t = (float)hv;
+            s1 += t;
+            s2 = fmaf(t, t, s2);
+        }
+    }
+    if (stats) {                                   // Cout % 4 == 0 (launcher): the four channels of a quad are four adjacent lanes
+        s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1);
+        s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2);
+        if ((co & 3) == 0) *(float2*)(stats + (((b << 4) + yp) * (Cout >> 2) + (co >> 2)) * 2) = float2{s1, s2};
     }
 }
 
@@ -578,9 +593,9 @@ void launch_spec_unstandardize(const float* x, float lo, float hi, float* spec, 
     hipLaunchKernelGGL(spec_unstandardize_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, x, lo, hi - lo, spec, n);
 }
 
-int launch_conv1ch_3x3(const float* in, const float* w, const float* bias, float* out, int B, int Cout, hipStream_t s, h16_t* out16) {
-    if (Cout > 128) return -1;                     // one thread per output channel (this network: 128)
-    hipLaunchKernelGGL(conv1ch_3x3_kernel, dim3((unsigned)B * 32u), dim3(128), 0, s, in, w, bias, out, Cout, out16);
+int launch_conv1ch_3x3(const float* in, const float* w, const float* bias, float* out, int B, int Cout, hipStream_t s, h16_t* out16, float* stats) {
+    if (Cout > 128 || (stats && (Cout & 3)) || (!out && !out16)) return -1;      // one thread per output channel (this network: 128)
+    hipLaunchKernelGGL(conv1ch_3x3_kernel, dim3((unsigned)B * 16u), dim3(128), 0, s, in, w, bias, out, Cout, out16, stats);
     return 0;
 }
 void launch_conv3x3_c128_to1(const float* in, const float* w, const float* bias, float* out, int B, hipStream_t s) {

@@ -22,6 +22,7 @@ pytestmark = pytest.mark.gpu
 FP32_TOL = 2e-5
 BF16_MAX_TOL, BF16_RMS_TOL = 3e-2, 2.5e-2
 F16_MAX_TOL = 4e-3
+UNET_F16_TOL = 6e-3         # the UNet's 16-bit tier vs the reference fixture (f16 maps between ~180 ops): measured 4.1e-3 / 2.2e-3 of max|eps| at t = 3 / 40 (tools/gpu_unet_tolerance.py)
 UNET_FP32_TOL = 1e-5        # the exact-fp32 UNet tier vs the reference fixture: measured 2.6e-6 / 1.7e-6 at t = 3 / 40 (tools/gpu_unet_tolerance.py)
 SPLIT_TOL = 8e-5            # the split-f16 tier (three f16 MFMAs per product): what an exact-vote engine's waveform surfaces deliver
 
@@ -886,7 +887,7 @@ def test_unet_purifier_vs_reference_fixture(golden_dir):
     eng.set_mode(E.MODE_FAST)
     for t in (3, 40):
         e16 = model(torch.from_numpy(z['x_t%d' % t]).cuda(), torch.full((2,), t, dtype=torch.long).cuda())
-        assert 1e-5 < relmax(e16.cpu().numpy(), z['eps_t%d' % t]) < F16_MAX_TOL, (t, relmax(e16.cpu().numpy(), z['eps_t%d' % t]))
+        assert 1e-5 < relmax(e16.cpu().numpy(), z['eps_t%d' % t]) < UNET_F16_TOL, (t, relmax(e16.cpu().numpy(), z['eps_t%d' % t]))
     solo16 = model(torch.from_numpy(z['x_t3'][1:]).cuda(), torch.tensor([3]))
     assert torch.equal(solo16, model(torch.from_numpy(z['x_t3']).cuda(), torch.tensor([3, 3]))[1:])    # batch invariance holds on this tier too
     with pytest.raises(E.DmadError):
