@@ -741,6 +741,8 @@ H16_CASES = [   # B, H, cin, cout, taps, stride, c1 (two-part input: first map's
     (128, 32, 384, 128, 9, 1, 0, True, 1, False),
     # two-part (concatenated) input through the persistent tiles: the 1x1 skip conv of an output block, a 3x3 with residual and N tail
     (128, 32, 384, 128, 1, 1, 256, False, 1, False), (257, 16, 512, 256, 9, 1, 256, True, 1, False),
+    # the slice-resident 3x3 form on 32-, 8- and 4-pixel-wide maps (tiles spanning 1/4, 4 and 16 images; N tail on the last)
+    (64, 32, 256, 256, 9, 1, 0, False, 1, False), (1024, 8, 128, 256, 9, 1, 0, True, 1, False), (4100, 4, 256, 256, 9, 1, 0, False, 1, False),
     # ResNeXt29's forms: K = 64, ReLU, 1x1 with stride 2, grouped 3x3 (4 paired / 8 groups; stride 2; small and chip-filling launches)
     (3, 32, 64, 512, 1, 1, 0, False, 1, True), (2, 32, 256, 512, 1, 2, 0, False, 1, False), (2, 16, 512, 512, 9, 1, 0, False, 4, True),
     (3, 16, 1024, 1024, 9, 2, 0, False, 8, True), (64, 32, 512, 512, 9, 1, 0, False, 4, True), (128, 16, 2048, 2048, 9, 2, 0, False, 8, True),
@@ -751,7 +753,7 @@ H16_CASES = [   # B, H, cin, cout, taps, stride, c1 (two-part input: first map's
 @pytest.mark.parametrize('case', H16_CASES, ids=lambda c: 'B%d_H%d_%dto%d_t%d_s%d_c1%d_r%d_g%d_relu%d' % tuple(int(v) for v in c))
 def test_gemm_h16_family_vs_torch_conv(case):
     """Every form of the f16 conv-GEMM family (csrc/gemm_h16.hip: the 384-row kernel in both splits, the 256 x 256 and 128 x 512
-    register-prefetched tiles, two-part input, stride 2, N tails, grouped convs, ReLU) through dmad_conv_h16 against a torch fp32
+    persistent tiles (ping-pong and slice-resident), two-part input, stride 2, N tails, grouped convs, ReLU) through dmad_conv_h16 against a torch fp32
     convolution of the same f16-rounded operands (improved_diffusion/unet.py:107-252, models/resnext.py:23-62 are the callers' ops):
     the fp32 output within 2e-3 absolute (fp32 accumulation order only), the f16 twin within one f16 rounding of it."""
     from dmad_hip import engine as E
