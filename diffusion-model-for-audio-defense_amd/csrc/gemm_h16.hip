@@ -25,6 +25,12 @@ constexpr int HK = 64;                          // halves per k-step row (128 by
 constexpr int KSTEP = 384 * 128, H16_LDS = 3 * KSTEP;
 __device__ __attribute__((aligned(128))) unsigned short g_zero_page_h[64];     // 128 B of zeros
 
+#ifndef SR_SKEW
+#define SR_SKEW 0                 // development: cycles per K-tile for the start skew experiment
+#endif
+#ifndef SR_ABLATE_EPI
+#define SR_ABLATE_EPI 0
+#endif
 #ifndef PP_PHASES
 #define PP_PHASES 2               // phases per K-tile of the ping-pong kernel: 2 (32-MFMA clusters) or 4 (16)
 #endif
@@ -459,9 +465,8 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
 
 // Epilogue of a persistent tile, straight from the accumulators (acc[i][j]: row tile i, pixel tile j of the wave's 128 x 64 output;
 // wm / wn: the wave's position in the tile): bias, residual, ReLU, GroupNorm statistics, stores; leaves the accumulators zeroed.
-template <int BM, bool WIDE>
-__device__ __forceinline__ void pers_epilogue(const GemmH16Args& a, f32x4 (&acc)[8][4], long ctile, int ny, int wm, int wn, int q, int r16) {
-    constexpr int BN = BM == 256 ? 256 : 512, MT = 8;
+template <int BM, bool WIDE, int BN = (BM == 256 ? 256 : 512), int MT = 8>      // MT: accumulator row tiles per wave (wave rows = 16 MT)
+__device__ __forceinline__ void pers_epilogue(const GemmH16Args& a, f32x4 (&acc)[MT][4], long ctile, int ny, int wm, int wn, int q, int r16) {
     const long tx = ctile / ny;
     const int m0 = (int)(ctile - tx * ny) * BM;
     const long n0 = tx * BN;
@@ -473,7 +478,7 @@ __device__ __forceinline__ void pers_epilogue(const GemmH16Args& a, f32x4 (&acc)
         ok[j] = n < a.N;
         nrow[j] = (unsigned)((ok[j] ? n : a.N - 1) * a.ldc);
     }
-    const int mw = m0 + wm * 128;                            // first output channel of this wave
+    const int mw = m0 + wm * (MT * 16);                            // first output channel of this wave
     if constexpr (WIDE) {
         // f16 map out (the common case): 16-BYTE stores.  A lane holds 4 channels x 1 pixel per accumulator tile (8 bytes as f16);
         // lanes q / q ^ 1 exchange halves (one v_permlane16_swap per dword) so that every lane ends up with 8 consecutive
@@ -483,10 +488,10 @@ __device__ __forceinline__ void pers_epilogue(const GemmH16Args& a, f32x4 (&acc)
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
         typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {                        // row tile pairs (2p, 2p + 1)
+        for (int p = 0; p < MT / 2; ++p) {                   // row tile pairs (2p, 2p + 1)
             const int t0 = 2 * p, t1 = t0 + 1;
             const unsigned coff = (unsigned)(mw + (t0 + (q & 1)) * 16 + (q >> 1) * 8);
-            constexpr int JB = BM == 256 ? 4 : 2;              // residual chunks in flight (the 128 x 512 form has 16 more registers of staging state)
+            constexpr int JB = (BM == 256 || BN == 256) ? 4 : 2;              // residual chunks in flight (the 128 x 512 form has 16 more registers of staging state)
             u32x4 rc[JB];
             const float4 z4 = float4{0.f, 0.f, 0.f, 0.f};
             const float4 b0 = a.shift ? *(const float4*)(a.shift + mw + t0 * 16 + q * 4) : z4;
@@ -1101,9 +1106,11 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
 namespace {
 constexpr int SR_XROWS = 328, SR_XB = (SR_XROWS + 1) * 128, SR_ARING = 2 * 256 * 128, SR_LDS = SR_ARING + 2 * SR_XB;     // 149 760 B
 }
-template <bool WIDE>
+template <int BM, bool WIDE>           // 256: 256 x 256 tile (waves 2 x 4, 128 x 64 each, two phases per K-tile); 128: 128 x 256 (waves 2 x 4, 64 x 64 each, one phase)
 __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int nx) {
-    constexpr int BM = 256, BN = 256, AHB = 128 * 128, ABUF = 2 * AHB;
+    constexpr int BN = 256, MT = BM / 32;                            // accumulator row tiles per wave
+    constexpr int AHB = 128 * 128;                                   // 16 KiB: a half K-tile of the 256-row form, a whole K-tile of the 128-row form
+    constexpr int ASLOTB = BM == 256 ? 2 * AHB : AHB, ASLOTS = SR_ARING / ASLOTB;     // weight ring: 2 K-tiles (A0 | A1) or 4 K-tiles
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1124,15 +1131,14 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
     const int W = a.W, hw = a.H * a.W, halo = W + 1;
     const int xpieces = (BN + 2 * halo + 7) >> 3;                    // 1-KiB pieces of a slice (41 at W = 32)
     for (int i = tid; i < 64; i += 512) ((unsigned*)(smem + SR_ARING + (i >> 5) * SR_XB + SR_XROWS * 128))[i & 31] = 0u;      // the two zero rows
-    // ---- weight cursor (K-tiles, 1.5 ahead of the compute cursor) ----------------------------------------------------------------
+    // ---- weight cursor (K-tiles ahead of the compute cursor) ---------------------------------------------------------------------
     long atile = ctile;
-    int a_tapi = 0, a_kq = 0, a_left = my_tiles * nsteps;           // K-tiles whose weights are not completely staged yet
-    unsigned a_lds = lds0;
+    int a_tapi = 0, a_kq = 0, a_left = my_tiles * nsteps, a_slot = 0;          // K-tiles whose weights are not completely staged yet
     const char* Ab = (const char*)(a.A + (size_t)(ctile % ny) * BM * a.K);
     const char* st_a = Ab;
     auto a_advance = [&]() {
         --a_left;
-        a_lds = lds0 + ((a_lds - lds0) ^ ABUF);
+        a_slot = (a_slot + 1) & (ASLOTS - 1);
         if (++a_tapi == 9) {
             a_tapi = 0;
             if (++a_kq == nslices) {
@@ -1143,9 +1149,12 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
         }
         st_a = Ab + (size_t)a_tapi * a_tap + (size_t)a_kq * 128;
     };
-    auto stageA = [&](int h) {
+    auto stageA = [&](int h) {                                       // 256 rows: half-tile h (rows h * 64 .. + 64 of each wave row); 128 rows: the K-tile (h = 0)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) dma16s(st_a + (size_t)(p * 128 + h * 64 + wv * 8) * a_row, voffA, a_lds + h * AHB + (p * 64 + wv * 8) * 128);
+        for (int p = 0; p < 2; ++p) {
+            const int grow = BM == 256 ? p * 128 + h * 64 + wv * 8 : p * 64 + wv * 8;
+            dma16s(st_a + (size_t)grow * a_row, voffA, lds0 + a_slot * ASLOTB + h * AHB + (p * 64 + wv * 8) * 128);
+        }
     };
     // ---- slice cursor (one slice ahead of the compute cursor) ----------------------------------------------------------------
     long xtile = ctile;
@@ -1203,14 +1212,14 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
     };
     tile_pixels(ctile);
     x_source();
-    f32x4 acc[8][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int sw = (r16 >> 1) & 7;
     const int fk[2] = {r16 * 128 + ((q ^ sw) * 16), r16 * 128 + (((4 + q) ^ sw) * 16)};
-    const int aoff = wr * 8192;
+    const int aoff = wr * 8192;                                      // the wave row's 64 rows inside a 128-row (half) K-tile
     f16x8 AF[4][2], B0[2][2], B1[2][2];
     auto ldA = [&](const char* buf, int i) {
 #pragma unroll
@@ -1250,48 +1259,90 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
         __builtin_amdgcn_s_setprio(0);                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
     } while (0)
-    // prologue: slice 0 and the weights of K-tile 0 staged whole, A0 of K-tile 1 behind them; everything but that A0 landed
+#if SR_SKEW
+    if constexpr (BM == 128) {                                       // experiment: workgroups start a quarter of a tile apart, so their epilogue store bursts do not coincide
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), wait = (unsigned long long)(blockIdx.x >> 3 & 3) * (unsigned long long)nsteps * (SR_SKEW / 4);
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+    // prologue: slice 0 and the weights of K-tile 0 staged whole, the next weights behind them; everything but those landed
 #pragma unroll
     for (int i = 0; i < 6; ++i) stageX(i);
     x_advance();
-    stageA(0); stageA(1);
-    a_advance();
-    if (a_left > 0) { stageA(0); GH_WAIT_BARRIER(2); } else { GH_WAIT_BARRIER(0); }
+    if constexpr (BM == 256) {
+        stageA(0); stageA(1);
+        a_advance();
+        if (a_left > 0) { stageA(0); GH_WAIT_BARRIER(2); } else { GH_WAIT_BARRIER(0); }
+    } else {
+        int ahead = 0;                                               // K-tiles 1 and 2 (two pieces each) stay in flight
+        stageA(0); a_advance();
+        if (a_left > 0) { stageA(0); a_advance(); ++ahead; }
+        if (a_left > 0) { stageA(0); a_advance(); ++ahead; }
+        if (ahead == 2) { GH_WAIT_BARRIER(4); } else if (ahead == 1) { GH_WAIT_BARRIER(2); } else { GH_WAIT_BARRIER(0); }
+    }
     if (grp == 1) PP_BARRIER();                                      // the second group runs half a phase behind
     const int total = my_tiles * nsteps;
     int s = 0, tap = 0, toff = -W - 1;                               // K-tile inside the compute tile, its tap and the tap's row offset
     const char* xbuf = smem + SR_ARING;
+    bool xprev = false;                                              // (128 rows) the previous phase issued a slice piece
     for (int g = 0; g < total; ++g) {
-        const char* cur = smem + (g & 1) * ABUF;
-        // phase A: quadrants (0, 0) and (0, 1); the weight cursor's A1 goes out (its A0 went a phase earlier), the cursor advances
-        ldB(B0, xbuf, 0, tap, toff);
-        ldB(B1, xbuf, 1, tap, toff);
-        __builtin_amdgcn_sched_barrier(0);
-        ldA(cur, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (a_left > 0) { stageA(1); a_advance(); }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0xC07F);                          // the reads retire AHEAD of the barrier: what they read may be restaged a phase later
-        PP_BARRIER();
-        PP_QUAD2(B0, 0, 0, B1, 0, 1);
-        PP_BARRIER();
-        // phase B: quadrants (1, 1) and (1, 0); A0 of the new weight cursor, one piece of the next slice; the next K-tile's weights have landed
-        ldA(cur, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const bool xp = tap < 6 && x_left > 0 && wv + 8 * tap < xpieces;
-        if (a_left > 0) {
-            stageA(0);
-            if (xp) stageX(tap);
+        const char* cur = smem + (g & (ASLOTS - 1)) * ASLOTB;
+        const bool xp = tap < 6 && x_left > 0 && wv + 8 * tap < xpieces;       // this K-tile issues a piece of the next slice
+        if constexpr (BM == 256) {
+            // phase A: quadrants (0, 0) and (0, 1); the weight cursor's A1 goes out (its A0 went a phase earlier), the cursor advances
+            ldB(B0, xbuf, 0, tap, toff);
+            ldB(B1, xbuf, 1, tap, toff);
             __builtin_amdgcn_sched_barrier(0);
-            if (xp) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            ldA(cur, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (a_left > 0) { stageA(1); a_advance(); }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);                      // the reads retire AHEAD of the barrier: what they read may be restaged a phase later
+            PP_BARRIER();
+            PP_QUAD2(B0, 0, 0, B1, 0, 1);
+            PP_BARRIER();
+            // phase B: quadrants (1, 1) and (1, 0); A0 of the new weight cursor, one piece of the next slice; the next K-tile's weights have landed
+            ldA(cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (a_left > 0) {
+                stageA(0);
+                if (xp) stageX(tap);
+                __builtin_amdgcn_sched_barrier(0);
+                if (xp) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            PP_BARRIER();
+            PP_QUAD2(B1, 1, 1, B0, 1, 0);
+            PP_BARRIER();
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // one phase per K-tile: the 64 x 64 wave tile's 32 MFMAs; the weights of K-tile g + 3 go into the slot K-tile g - 1 left a phase
+            // ago, with a piece of the next slice; K-tile g + 1 has landed (younger: K-tiles g + 2 and g + 3, and the slice pieces beside them)
+            ldB(B0, xbuf, 0, tap, toff);
+            ldB(B1, xbuf, 1, tap, toff);
+            __builtin_amdgcn_sched_barrier(0);
+            ldA(cur, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (a_left > 0) {
+                stageA(0); a_advance();
+                if (xp) stageX(tap);
+                __builtin_amdgcn_sched_barrier(0);
+                const int young = (xp ? 1 : 0) + (xprev ? 1 : 0);
+                if (young == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (young == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            xprev = xp;
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            PP_BARRIER();
+            PP_QUAD2(B0, 0, 0, B1, 0, 1);
+            PP_BARRIER();
         }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        PP_BARRIER();
-        PP_QUAD2(B1, 1, 1, B0, 1, 0);
-        PP_BARRIER();
         if (++tap == 9) {                                            // the slice is complete: the next one (staged during taps 0-5) becomes current
             tap = 0;
             if (x_left > 0) x_advance();
@@ -1301,7 +1352,28 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
         if (s != nsteps - 1) { ++s; continue; }
         // ---- the tile is complete: both groups run the epilogue at the same time -------------------------------------------------
         if (grp == 0) PP_BARRIER();
-        pers_epilogue<BM, WIDE>(a, acc, ctile, ny, wr, wc, q, r16);
+#if SR_ABLATE_EPI == 1
+        {                                                            // development: no epilogue (the accumulators stay live through one dummy sum)
+            float keep = 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            if (keep == 12345.678f && a.C16) a.C16[0] = 0;
+        }
+#else
+#if SR_ABLATE_EPI == 2
+        if constexpr (BM == 128) {                                   // development: the epilogue twice (same values), to price it with valid data downstream
+            f32x4 twin[MT][4];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) twin[i][j] = acc[i][j];
+            pers_epilogue<BM, WIDE, BN, MT>(a, twin, ctile, ny, wr, wc, q, r16);
+        }
+#endif
+        pers_epilogue<BM, WIDE, BN, MT>(a, acc, ctile, ny, wr, wc, q, r16);
+#endif
         ctile += G8;
         s = 0;
         if (g + 1 < total) tile_pixels(ctile);
@@ -1339,9 +1411,13 @@ int gemm_h16_configure() {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<128, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_h16_sr_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS);
+    e = hipFuncSetAttribute((const void*)gemm_h16_sr_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_h16_sr_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS);
+    e = hipFuncSetAttribute((const void*)gemm_h16_sr_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_h16_sr_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_h16_sr_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_h16_pp_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
     if (e != hipSuccess) return (int)e;
@@ -1399,10 +1475,16 @@ int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
                     return 0;
                 }
                 // 3 x 3, stride 1, maps up to 32 pixels wide, 256-row blocks: the slice-resident form (DMAD_H16_SR=0: off, A/B runs)
-                static const bool sr_on = []() { const char* v = getenv("DMAD_H16_SR"); return !(v && v[0] == '0'); }();
-                if (pp_on && sr_on && bm == 256 && a.taps == 9 && a.stride <= 1 && a.W <= 32 && a.W >= 1) {
-                    if (wide) hipLaunchKernelGGL((gemm_h16_sr_kernel<true>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, (int)nxp);
-                    else hipLaunchKernelGGL((gemm_h16_sr_kernel<false>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, (int)nxp);
+                static const int sr_on = []() { const char* v = getenv("DMAD_H16_SR"); return v ? atoi(v) : 1; }();      // 0: off, 256: the 256-row form only
+                if (pp_on && sr_on && (sr_on != 256 || bm == 256) && a.taps == 9 && a.stride <= 1 && a.W <= 32 && a.W >= 1) {
+                    if (bm == 256) {
+                        if (wide) hipLaunchKernelGGL((gemm_h16_sr_kernel<256, true>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, (int)nxp);
+                        else hipLaunchKernelGGL((gemm_h16_sr_kernel<256, false>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, (int)nxp);
+                    } else {                                     // M = 128: 128 x 256 tiles (twice the ping-pong form's tile count)
+                        const long nx2 = (a.N + 255) / 256;
+                        if (wide) hipLaunchKernelGGL((gemm_h16_sr_kernel<128, true>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, (int)nx2);
+                        else hipLaunchKernelGGL((gemm_h16_sr_kernel<128, false>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, (int)nx2);
+                    }
                     return 0;
                 }
                 // the ping-pong form (it also takes a two-part input)
