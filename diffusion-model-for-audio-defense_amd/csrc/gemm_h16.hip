@@ -25,20 +25,11 @@ constexpr int HK = 64;                          // halves per k-step row (128 by
 constexpr int KSTEP = 384 * 128, H16_LDS = 3 * KSTEP;
 __device__ __attribute__((aligned(128))) unsigned short g_zero_page_h[64];     // 128 B of zeros
 
-#ifndef SR_SKEW
-#define SR_SKEW 0                 // development: cycles per K-tile for the start skew experiment
-#endif
-#ifndef SR_ABLATE_EPI
-#define SR_ABLATE_EPI 0
-#endif
 #ifndef PP_PHASES
 #define PP_PHASES 2               // phases per K-tile of the ping-pong kernel: 2 (32-MFMA clusters) or 4 (16)
 #endif
 #ifndef PP_ABLATE
 #define PP_ABLATE 0               // development builds only (tools/…): 1 no staging DMA, 2 staging from cache-resident rows (5: the pixel rows only; 7: 32 real pixel rows), 3 fragments read once, 4 one MFMA per quadrant
-#endif
-#ifndef H16_PERS_EARLY
-#define H16_PERS_EARLY 1          // 0: the round-4 first form of the persistent kernel's k-step (one barrier, all pieces in phase 4) for A/B builds
 #endif
 #define GH_WAIT_BARRIER(N)                                                          \
     do {                                                                            \
@@ -564,247 +555,6 @@ __device__ __forceinline__ void pers_epilogue(const GemmH16Args& a, f32x4 (&acc)
 }
 
 // ----------------------------------------------------------------------------------------------------------------------------
-// Persistent form of the register-prefetched tile (round 4).  One workgroup per CU walks over output tiles; the 2-slot k-step ring
-// NEVER drains between them: the staging cursor runs two k-steps ahead of the compute cursor through the concatenated k-steps of
-// the workgroup's tiles, so a tile's first k-steps land while the previous tile's last ones are contracted and its epilogue
-// stores run.  What this removes is everything a tile pays around its k-loop as a workgroup of its own — dispatch of a 128-160 KiB-LDS
-// workgroup behind the previous one's store tail, the per-lane pixel arithmetic, two cold k-steps — which is most of the time of
-// the short-K launches (K = 256 1x1 / qkv convs: 4 k-steps per tile, 166-189 TFLOP/s as separate workgroups).
-// Tile walk: XCD x (blockIdx % 8) owns a contiguous range of tile ids (id = pixel tile * ny + row block, so the row blocks of one
-// pixel tile stay on one XCD: their pixel rows are L2 hits), its workgroups take the ids of that range round-robin.
-// Residual reads of the epilogue are issued right behind the k-step barrier (nothing else in flight) and retired by an explicit
-// count that leaves the next k-step's DMA pieces flying.
-// ----------------------------------------------------------------------------------------------------------------------------
-// STAMP (diagnostic build only, DMAD_H16_STAMPS=1: never the product launch): s_memtime sums of wave 0 per part of a k-step —
-// phases 1-3 | barrier wait | phase 4 with the DMA issue | epilogue — into dbg[block][8].
-template <int BM, bool WIDE, bool STAMP = false>      // WIDE: f16 map out, no fp32 output / residual (the epilogue with 16-byte stores); else the plain epilogue
-__global__ void __launch_bounds__(512, 2) gemm_h16_pers_kernel(GemmH16Args a, int nx, unsigned long long* dbg = nullptr) {
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;      // [5]: the wait at the mid-k-step barrier
-    auto stamp = [&](int k) {
-        if constexpr (STAMP) {
-            const unsigned long long now = __builtin_amdgcn_s_memtime();
-            if (k >= 0) tacc[k] += now - tprev;
-            tprev = now;
-        }
-    };
-    stamp(-1);
-    constexpr int BN = BM == 256 ? 256 : 512, AP = BM / 64, XP = BN / 64, NP = AP + XP, SLOTB = (BM + BN) * 128, WN = BN / 64;
-    constexpr int MT = BM == 256 ? 8 : 8;            // accumulator row tiles per wave (wave tile 128 x 64 in both forms)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wv / WN, wn = wv % WN, q = lane >> 4, r16 = lane & 15;
-    const int ny = a.M / BM;
-    const long T = (long)nx * ny;
-    const int G8 = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7), jw = (int)(blockIdx.x >> 3);
-    const long chunk = (((T + 7) / 8 + ny - 1) / ny) * ny;          // whole pixel tiles per XCD
-    const long lo = xcd * chunk, hi = lo + chunk < T ? lo + chunk : T;
-    long ctile = lo + jw;                                            // compute cursor (tile id)
-    if (ctile >= hi) return;
-    const int my_tiles = (int)((hi - ctile + G8 - 1) / G8);
-    const int steps_per_tap = a.K / HK, nsteps = a.taps * steps_per_tap;
-    const int rloc = wv * 8 + (lane >> 3), ch8 = ((lane & 7) ^ ((rloc >> 1) & 7)) * 8;
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
-    const unsigned voffA = (unsigned)((rloc * a.K + ch8) * 2);
-    const size_t a_piece = (size_t)64 * a.K * 2, a_tap = (size_t)a.M * a.K * 2;
-    const int st = a.stride > 1 ? a.stride : 1;
-    const int Wo = (a.W - 1) / st + 1, Ho = (a.H - 1) / st + 1, hw = Ho * Wo;
-    // ---- staging cursor: tile, tap, k-step inside the tap; per-lane pixel rows of the staging tile --------------------------
-    long stile = ctile;
-    int st_tap = 0, st_kq = 0, st_left = my_tiles * nsteps;         // k-steps not staged yet
-    int xpix[XP], xyx[XP];                                           // image base pixel (or -1: row past N), (y << 16) | x per staged row
-    int st_dy = a.taps == 9 ? -1 : 0, st_dx = st_dy;                 // the staging tap's offsets
-    const char* Ab = nullptr;
-    const char* st_a = nullptr;
-    auto tile_rows = [&](long id) {
-        const long tx = id / ny;
-        const int mb = (int)(id - tx * ny);
-        Ab = (const char*)(a.A + (size_t)mb * BM * a.K);
-        const unsigned n0 = (unsigned)tx * BN;                       // N < 2^31 (launcher): 32-bit pixel arithmetic
-#pragma unroll
-        for (int p = 0; p < XP; ++p) {
-            const unsigned n = n0 + p * 64 + rloc;
-            xpix[p] = -1; xyx[p] = 0;
-            if (n < (unsigned)a.N) {
-                const unsigned b = n / (unsigned)hw, pix = n - b * (unsigned)hw, py = pix / (unsigned)Wo;
-                xpix[p] = (int)(b * (unsigned)(a.H * a.W));
-                xyx[p] = (int)(((py * st) << 16) | ((pix - py * Wo) * st));
-            }
-        }
-    };
-    auto st_advance = [&]() {                                        // after a k-step's pieces have been issued
-        --st_left;
-        if (++st_tap == a.taps) {                                    // tap-inner order, as in every kernel of the family
-            st_tap = 0;
-            if (++st_kq == steps_per_tap) {
-                st_kq = 0;
-                stile += G8;
-                if (st_left > 0) tile_rows(stile);
-            }
-        }
-        st_dy = a.taps == 9 ? st_tap / 3 - 1 : 0;
-        st_dx = a.taps == 9 ? st_tap % 3 - 1 : 0;
-        st_a = Ab + (size_t)st_tap * a_tap + (size_t)st_kq * 128;
-    };
-    const h16_t* zrow = g_zero_page_big + (lane & 7) * 8;
-    auto piece = [&](int k, unsigned slot_lds) {                     // k < XP: pixel rows (address formed here: 16 registers of state), then the AP weight pieces
-        if (k < XP) {
-            const int yy = (xyx[k] >> 16) + st_dy, xq = (xyx[k] & 0xffff) + st_dx;
-            const bool ok = xpix[k] >= 0 && (unsigned)yy < (unsigned)a.H && (unsigned)xq < (unsigned)a.W;
-            const h16_t* src = ok ? a.X + ((long)xpix[k] + yy * a.W + xq) * a.ldx + ch8 + st_kq * HK : zrow;
-            dma16v(src, slot_lds + BM * 128 + k * 8192 + wv * 1024);
-        } else {
-            dma16s(st_a + (size_t)(k - XP) * a_piece, voffA, slot_lds + (k - XP) * 8192 + wv * 1024);
-        }
-    };
-    tile_rows(stile);
-    st_a = Ab;
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int sw = (r16 >> 1) & 7;
-    const int fk[2] = {r16 * 128 + ((q ^ sw) * 16), r16 * 128 + (((4 + q) ^ sw) * 16)};
-    const int aoff = wm * 16384, boff = BM * 128 + wn * 8192;
-    f16x8 AX[4], AY[4], BP[4], BQ[4];
-    auto ldA = [&](f16x8 (&U)[4], const char* slot, int half, int kh) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) U[i] = *(const f16x8*)(slot + aoff + half * 8192 + i * 2048 + fk[kh]);
-    };
-    auto ldB = [&](f16x8 (&U)[4], const char* slot, int kh) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) U[j] = *(const f16x8*)(slot + boff + j * 2048 + fk[kh]);
-    };
-#define PERS_MFMA4(AU, BU, i0, ii)                                                                                   \
-    do {                                                                                                             \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                             \
-            acc[(i0) + (ii)][j_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AU[ii], BU[j_], acc[(i0) + (ii)][j_], 0, 0, 0); \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-    } while (0)
-    // prologue: the first two k-steps of the stream staged, the first one landed, its first units in registers
-#pragma unroll
-    for (int k = 0; k < NP; ++k) piece(k, lds0);
-    st_advance();
-    if (st_left > 0) {
-#pragma unroll
-        for (int k = 0; k < NP; ++k) piece(k, lds0 + SLOTB);
-        st_advance();
-        if (NP == 8) { GH_WAIT_BARRIER(8); } else { GH_WAIT_BARRIER(10); }
-    } else {
-        GH_WAIT_BARRIER(0);
-    }
-    ldA(AX, smem, 0, 0);
-    ldB(BP, smem, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    const int total = my_tiles * nsteps;
-    int s = 0;                                                       // k-step inside the compute tile
-    for (int g = 0; g < total; ++g) {
-        const char* cur = smem + (g & 1) * SLOTB;
-        const char* nxt = smem + ((g & 1) ^ 1) * SLOTB;
-        const unsigned cur_lds = lds0 + (g & 1) * SLOTB;
-        const bool last = s == nsteps - 1;
-        stamp(4);                                                    // (tile switch, loop overhead)
-        // phase 1: (A0, B) k0; read A1 k0
-        ldA(AY, cur, 1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        PERS_MFMA4(AX, BP, 0, 0); PERS_MFMA4(AX, BP, 0, 1); PERS_MFMA4(AX, BP, 0, 2); PERS_MFMA4(AX, BP, 0, 3);
-        // phase 2: (A1, B) k0; read A0 k1, B k1
-        ldA(AX, cur, 0, 1);
-        ldB(BQ, cur, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        PERS_MFMA4(AY, BP, 4, 0); PERS_MFMA4(AY, BP, 4, 1); PERS_MFMA4(AY, BP, 4, 2); PERS_MFMA4(AY, BP, 4, 3);
-        const bool more = st_left > 0;
-#if H16_PERS_EARLY
-        // Every wave holds its last fragments of this slot's pixel rows and A0 rows (3/4 of the slot; only the A1 rows are still to be
-        // read, in phase 3): a barrier without a memory wait frees them, and the pieces of the k-step after next start a phase earlier,
-        // one per MFMA group over phases 3 and 4 instead of eight in phase 4 (issued together they queue behind each other in the
-        // CU's one vector-memory pipe, 100-185 cycles of issue each, with every wave's MFMAs waiting behind its own pieces).
-        stamp(0);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        stamp(5);
-        // phase 3: (A0, B) k1; read A1 k1; stage the pixel rows of the k-step after next
-        ldA(AY, cur, 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) { piece(0, cur_lds); if (NP == 10) piece(4, cur_lds); __builtin_amdgcn_sched_barrier(0); }
-        PERS_MFMA4(AX, BQ, 0, 0);
-        if (more) { piece(1, cur_lds); if (NP == 10) piece(5, cur_lds); __builtin_amdgcn_sched_barrier(0); }
-        PERS_MFMA4(AX, BQ, 0, 1);
-        if (more) { piece(2, cur_lds); __builtin_amdgcn_sched_barrier(0); }
-        PERS_MFMA4(AX, BQ, 0, 2);
-        if (more) { piece(3, cur_lds); __builtin_amdgcn_sched_barrier(0); }
-        PERS_MFMA4(AX, BQ, 0, 3);
-        // the next k-step of the stream has landed (only this phase's pieces are younger), every wave holds its A1 k1 fragments
-        stamp(0);
-        if (more) { if (NP == 8) { GH_WAIT_BARRIER(4); } else { GH_WAIT_BARRIER(6); } } else { GH_WAIT_BARRIER(0); }
-        stamp(1);
-        // phase 4: (A1, B) k1; unless the tile ends here, read A0 k0, B k0 of the next k-step; stage the rest of the k-step after next
-        if (!last) {
-            ldA(AX, nxt, 0, 0);
-            ldB(BP, nxt, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) { piece(NP == 8 ? 4 : 6, cur_lds); __builtin_amdgcn_sched_barrier(0); }
-        PERS_MFMA4(AY, BQ, 4, 0);
-        if (more) { piece(NP == 8 ? 6 : 7, cur_lds); __builtin_amdgcn_sched_barrier(0); }
-        PERS_MFMA4(AY, BQ, 4, 1);
-        if (more) { piece(NP == 8 ? 5 : 8, cur_lds); __builtin_amdgcn_sched_barrier(0); }
-        PERS_MFMA4(AY, BQ, 4, 2);
-        if (more) { piece(NP == 8 ? 7 : 9, cur_lds); __builtin_amdgcn_sched_barrier(0); }
-        PERS_MFMA4(AY, BQ, 4, 3);
-#else
-        // phase 3: (A0, B) k1; read A1 k1
-        ldA(AY, cur, 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        PERS_MFMA4(AX, BQ, 0, 0); PERS_MFMA4(AX, BQ, 0, 1); PERS_MFMA4(AX, BQ, 0, 2); PERS_MFMA4(AX, BQ, 0, 3);
-        // the next k-step of the stream has landed, every wave holds its last fragments of this slot
-        stamp(0);
-        GH_WAIT_BARRIER(0);
-        stamp(1);
-        // phase 4: (A1, B) k1; unless the tile ends here, read A0 k0, B k0 of the next k-step; stage the k-step after it into this slot
-        if (!last) {
-            ldA(AX, nxt, 0, 0);
-            ldB(BP, nxt, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) { piece(0, cur_lds); piece(1, cur_lds); if (NP == 10) piece(8, cur_lds); __builtin_amdgcn_sched_barrier(0); }
-        PERS_MFMA4(AY, BQ, 4, 0);
-        if (more) { piece(2, cur_lds); piece(3, cur_lds); if (NP == 10) piece(9, cur_lds); __builtin_amdgcn_sched_barrier(0); }
-        PERS_MFMA4(AY, BQ, 4, 1);
-        if (more) { piece(4, cur_lds); piece(5, cur_lds); __builtin_amdgcn_sched_barrier(0); }
-        PERS_MFMA4(AY, BQ, 4, 2);
-        if (more) { piece(6, cur_lds); piece(7, cur_lds); __builtin_amdgcn_sched_barrier(0); }
-        PERS_MFMA4(AY, BQ, 4, 3);
-#endif
-        if (more) st_advance();
-        stamp(2);
-        if (!last) { ++s; continue; }
-        // ---- the tile is complete: epilogue straight from the accumulators (the fragment registers are free here) ---------------
-        pers_epilogue<BM, WIDE>(a, acc, ctile, ny, wm, wn, q, r16);
-        stamp(3);
-        ctile += G8;
-        s = 0;
-        if (g + 1 < total) {                                         // first units of the next tile (its k-step 0 landed before the barrier above)
-            ldA(AX, nxt, 0, 0);
-            ldB(BP, nxt, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#undef PERS_MFMA4
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    if constexpr (STAMP) {
-        if (tid == 0 && dbg) {
-            for (int k = 0; k < 5; ++k) dbg[(size_t)blockIdx.x * 8 + k] = tacc[k];
-            dbg[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)total;
-            dbg[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)my_tiles;
-            dbg[(size_t)blockIdx.x * 8 + 7] = tacc[5];
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------------------------------------------------------
 // Ping-pong form of the persistent tile (round 4, second form).  Same tile (256 x 256, or 128 x 512 for the 128-channel layers),
 // same 8 waves with a 128 x 64 output each, same ring that never drains across tiles — but the two waves of a SIMD no longer do the
 // same thing at the same time.  Waves 0-3 and waves 4-7 (one of each per SIMD) run half a phase apart: while one group contracts
@@ -1102,15 +852,15 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
 //   K-tile order: slice-major, the nine taps of a slice back to back (the order of every kernel of the family).  Per K-tile a wave
 //   issues four weight pieces and, during taps 0-5 of a slice, one piece of the NEXT slice (41 pieces per slice and workgroup).
 //   Phases, waits and the half-phase offset of the two wave groups are the ping-pong kernel's.
+//   (A 128-row variant — 128 x 256 tiles, 64 x 64 per wave, one phase per K-tile — measured no faster than the ping-pong kernel's
+//   128 x 512 tile on the 128-channel layers and is not kept: HISTORY.md, round 4.)
 // ----------------------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int SR_XROWS = 328, SR_XB = (SR_XROWS + 1) * 128, SR_ARING = 2 * 256 * 128, SR_LDS = SR_ARING + 2 * SR_XB;     // 149 760 B
 }
-template <int BM, bool WIDE>           // 256: 256 x 256 tile (waves 2 x 4, 128 x 64 each, two phases per K-tile); 128: 128 x 256 (waves 2 x 4, 64 x 64 each, one phase)
+template <bool WIDE>
 __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int nx) {
-    constexpr int BN = 256, MT = BM / 32;                            // accumulator row tiles per wave
-    constexpr int AHB = 128 * 128;                                   // 16 KiB: a half K-tile of the 256-row form, a whole K-tile of the 128-row form
-    constexpr int ASLOTB = BM == 256 ? 2 * AHB : AHB, ASLOTS = SR_ARING / ASLOTB;     // weight ring: 2 K-tiles (A0 | A1) or 4 K-tiles
+    constexpr int BM = 256, BN = 256, AHB = 128 * 128, ABUF = 2 * AHB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1131,14 +881,15 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
     const int W = a.W, hw = a.H * a.W, halo = W + 1;
     const int xpieces = (BN + 2 * halo + 7) >> 3;                    // 1-KiB pieces of a slice (41 at W = 32)
     for (int i = tid; i < 64; i += 512) ((unsigned*)(smem + SR_ARING + (i >> 5) * SR_XB + SR_XROWS * 128))[i & 31] = 0u;      // the two zero rows
-    // ---- weight cursor (K-tiles ahead of the compute cursor) ---------------------------------------------------------------------
+    // ---- weight cursor (K-tiles, 1.5 ahead of the compute cursor) ----------------------------------------------------------------
     long atile = ctile;
-    int a_tapi = 0, a_kq = 0, a_left = my_tiles * nsteps, a_slot = 0;          // K-tiles whose weights are not completely staged yet
+    int a_tapi = 0, a_kq = 0, a_left = my_tiles * nsteps;           // K-tiles whose weights are not completely staged yet
+    unsigned a_lds = lds0;
     const char* Ab = (const char*)(a.A + (size_t)(ctile % ny) * BM * a.K);
     const char* st_a = Ab;
     auto a_advance = [&]() {
         --a_left;
-        a_slot = (a_slot + 1) & (ASLOTS - 1);
+        a_lds = lds0 + ((a_lds - lds0) ^ ABUF);
         if (++a_tapi == 9) {
             a_tapi = 0;
             if (++a_kq == nslices) {
@@ -1149,12 +900,9 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
         }
         st_a = Ab + (size_t)a_tapi * a_tap + (size_t)a_kq * 128;
     };
-    auto stageA = [&](int h) {                                       // 256 rows: half-tile h (rows h * 64 .. + 64 of each wave row); 128 rows: the K-tile (h = 0)
+    auto stageA = [&](int h) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int grow = BM == 256 ? p * 128 + h * 64 + wv * 8 : p * 64 + wv * 8;
-            dma16s(st_a + (size_t)grow * a_row, voffA, lds0 + a_slot * ASLOTB + h * AHB + (p * 64 + wv * 8) * 128);
-        }
+        for (int p = 0; p < 2; ++p) dma16s(st_a + (size_t)(p * 128 + h * 64 + wv * 8) * a_row, voffA, a_lds + h * AHB + (p * 64 + wv * 8) * 128);
     };
     // ---- slice cursor (one slice ahead of the compute cursor) ----------------------------------------------------------------
     long xtile = ctile;
@@ -1212,14 +960,14 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
     };
     tile_pixels(ctile);
     x_source();
-    f32x4 acc[MT][4];
+    f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int sw = (r16 >> 1) & 7;
     const int fk[2] = {r16 * 128 + ((q ^ sw) * 16), r16 * 128 + (((4 + q) ^ sw) * 16)};
-    const int aoff = wr * 8192;                                      // the wave row's 64 rows inside a 128-row (half) K-tile
+    const int aoff = wr * 8192;
     f16x8 AF[4][2], B0[2][2], B1[2][2];
     auto ldA = [&](const char* buf, int i) {
 #pragma unroll
@@ -1259,90 +1007,48 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
         __builtin_amdgcn_s_setprio(0);                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
     } while (0)
-#if SR_SKEW
-    if constexpr (BM == 128) {                                       // experiment: workgroups start a quarter of a tile apart, so their epilogue store bursts do not coincide
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), wait = (unsigned long long)(blockIdx.x >> 3 & 3) * (unsigned long long)nsteps * (SR_SKEW / 4);
-        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
-    // prologue: slice 0 and the weights of K-tile 0 staged whole, the next weights behind them; everything but those landed
+    // prologue: slice 0 and the weights of K-tile 0 staged whole, A0 of K-tile 1 behind them; everything but that A0 landed
 #pragma unroll
     for (int i = 0; i < 6; ++i) stageX(i);
     x_advance();
-    if constexpr (BM == 256) {
-        stageA(0); stageA(1);
-        a_advance();
-        if (a_left > 0) { stageA(0); GH_WAIT_BARRIER(2); } else { GH_WAIT_BARRIER(0); }
-    } else {
-        int ahead = 0;                                               // K-tiles 1 and 2 (two pieces each) stay in flight
-        stageA(0); a_advance();
-        if (a_left > 0) { stageA(0); a_advance(); ++ahead; }
-        if (a_left > 0) { stageA(0); a_advance(); ++ahead; }
-        if (ahead == 2) { GH_WAIT_BARRIER(4); } else if (ahead == 1) { GH_WAIT_BARRIER(2); } else { GH_WAIT_BARRIER(0); }
-    }
+    stageA(0); stageA(1);
+    a_advance();
+    if (a_left > 0) { stageA(0); GH_WAIT_BARRIER(2); } else { GH_WAIT_BARRIER(0); }
     if (grp == 1) PP_BARRIER();                                      // the second group runs half a phase behind
     const int total = my_tiles * nsteps;
     int s = 0, tap = 0, toff = -W - 1;                               // K-tile inside the compute tile, its tap and the tap's row offset
     const char* xbuf = smem + SR_ARING;
-    bool xprev = false;                                              // (128 rows) the previous phase issued a slice piece
     for (int g = 0; g < total; ++g) {
-        const char* cur = smem + (g & (ASLOTS - 1)) * ASLOTB;
-        const bool xp = tap < 6 && x_left > 0 && wv + 8 * tap < xpieces;       // this K-tile issues a piece of the next slice
-        if constexpr (BM == 256) {
-            // phase A: quadrants (0, 0) and (0, 1); the weight cursor's A1 goes out (its A0 went a phase earlier), the cursor advances
-            ldB(B0, xbuf, 0, tap, toff);
-            ldB(B1, xbuf, 1, tap, toff);
+        const char* cur = smem + (g & 1) * ABUF;
+        // phase A: quadrants (0, 0) and (0, 1); the weight cursor's A1 goes out (its A0 went a phase earlier), the cursor advances
+        ldB(B0, xbuf, 0, tap, toff);
+        ldB(B1, xbuf, 1, tap, toff);
+        __builtin_amdgcn_sched_barrier(0);
+        ldA(cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (a_left > 0) { stageA(1); a_advance(); }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                          // the reads retire AHEAD of the barrier: what they read may be restaged a phase later
+        PP_BARRIER();
+        PP_QUAD2(B0, 0, 0, B1, 0, 1);
+        PP_BARRIER();
+        // phase B: quadrants (1, 1) and (1, 0); A0 of the new weight cursor, one piece of the next slice; the next K-tile's weights have landed
+        ldA(cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool xp = tap < 6 && x_left > 0 && wv + 8 * tap < xpieces;
+        if (a_left > 0) {
+            stageA(0);
+            if (xp) stageX(tap);
             __builtin_amdgcn_sched_barrier(0);
-            ldA(cur, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (a_left > 0) { stageA(1); a_advance(); }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xC07F);                      // the reads retire AHEAD of the barrier: what they read may be restaged a phase later
-            PP_BARRIER();
-            PP_QUAD2(B0, 0, 0, B1, 0, 1);
-            PP_BARRIER();
-            // phase B: quadrants (1, 1) and (1, 0); A0 of the new weight cursor, one piece of the next slice; the next K-tile's weights have landed
-            ldA(cur, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (a_left > 0) {
-                stageA(0);
-                if (xp) stageX(tap);
-                __builtin_amdgcn_sched_barrier(0);
-                if (xp) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            PP_BARRIER();
-            PP_QUAD2(B1, 1, 1, B0, 1, 0);
-            PP_BARRIER();
+            if (xp) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
-            // one phase per K-tile: the 64 x 64 wave tile's 32 MFMAs; the weights of K-tile g + 3 go into the slot K-tile g - 1 left a phase
-            // ago, with a piece of the next slice; K-tile g + 1 has landed (younger: K-tiles g + 2 and g + 3, and the slice pieces beside them)
-            ldB(B0, xbuf, 0, tap, toff);
-            ldB(B1, xbuf, 1, tap, toff);
-            __builtin_amdgcn_sched_barrier(0);
-            ldA(cur, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (a_left > 0) {
-                stageA(0); a_advance();
-                if (xp) stageX(tap);
-                __builtin_amdgcn_sched_barrier(0);
-                const int young = (xp ? 1 : 0) + (xprev ? 1 : 0);
-                if (young == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else if (young == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            xprev = xp;
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            PP_BARRIER();
-            PP_QUAD2(B0, 0, 0, B1, 0, 1);
-            PP_BARRIER();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        PP_BARRIER();
+        PP_QUAD2(B1, 1, 1, B0, 1, 0);
+        PP_BARRIER();
         if (++tap == 9) {                                            // the slice is complete: the next one (staged during taps 0-5) becomes current
             tap = 0;
             if (x_left > 0) x_advance();
@@ -1352,28 +1058,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
         if (s != nsteps - 1) { ++s; continue; }
         // ---- the tile is complete: both groups run the epilogue at the same time -------------------------------------------------
         if (grp == 0) PP_BARRIER();
-#if SR_ABLATE_EPI == 1
-        {                                                            // development: no epilogue (the accumulators stay live through one dummy sum)
-            float keep = 0.f;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            if (keep == 12345.678f && a.C16) a.C16[0] = 0;
-        }
-#else
-#if SR_ABLATE_EPI == 2
-        if constexpr (BM == 128) {                                   // development: the epilogue twice (same values), to price it with valid data downstream
-            f32x4 twin[MT][4];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) twin[i][j] = acc[i][j];
-            pers_epilogue<BM, WIDE, BN, MT>(a, twin, ctile, ny, wr, wc, q, r16);
-        }
-#endif
-        pers_epilogue<BM, WIDE, BN, MT>(a, acc, ctile, ny, wr, wc, q, r16);
-#endif
+        pers_epilogue<BM, WIDE>(a, acc, ctile, ny, wr, wc, q, r16);
         ctile += G8;
         s = 0;
         if (g + 1 < total) tile_pixels(ctile);
@@ -1397,28 +1082,15 @@ int gemm_h16_configure() {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_h16_big_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
-    if (e != hipSuccess) return (int)e;
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
         g_h16_cus = prop.multiProcessorCount & ~7;
-    e = hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
+    e = hipFuncSetAttribute((const void*)gemm_h16_sr_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<128, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
+    e = hipFuncSetAttribute((const void*)gemm_h16_sr_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_h16_sr_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_h16_sr_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_h16_sr_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_h16_sr_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS);
-    if (e != hipSuccess) return (int)e;
+
     e = hipFuncSetAttribute((const void*)gemm_h16_pp_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_h16_pp_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_256);
@@ -1427,7 +1099,7 @@ int gemm_h16_configure() {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_h16_pp_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
     if (e != hipSuccess) return (int)e;
-    return (int)hipFuncSetAttribute((const void*)gemm_h16_pers_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_128);
+    return 0;
 }
 
 int gemm_h16_take_bad_shapes() { const int n = g_bad; g_bad = 0; return n; }
@@ -1441,64 +1113,31 @@ int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
         ++g_bad;
         return -1;
     }
-    // 256-row tiles where the output channels fill them; 128 x 256 otherwise (128-channel layers, 384 / 768-row qkv convs use
-    // whichever divides M)
-    // the 256 x 256 tile where it fills the chip: >= 256 workgroups (DMAD_H16_BIG=0 switches it off: A/B runs)
+    // Routing.  Dense convs whose tiles fill the chip at least once: the persistent forms (one workgroup per CU walks over tiles) —
+    // slice-resident for 3 x 3 / stride 1 / 256-row blocks, ping-pong otherwise (also the two-part input).  Grouped convs with >= 256
+    // tiles: the 256 x 256 / 128 x 512 tile as separate workgroups.  Everything else (small maps, 16-pixel statistics blocks): the
+    // 384-row kernel.  DMAD_H16_PERS=0 / DMAD_H16_SR=0 / DMAD_H16_BIG=0 switch a form off for A/B runs.
     static const bool big_on = []() { const char* v = getenv("DMAD_H16_BIG"); return !(v && v[0] == '0'); }();
-    // the persistent form (DMAD_H16_PERS=0 switches it off: A/B runs): dense convs whose tiles fill the chip at least once
     static const bool pers_on = []() { const char* v = getenv("DMAD_H16_PERS"); return !(v && v[0] == '0'); }();
+    static const bool sr_on = []() { const char* v = getenv("DMAD_H16_SR"); return !(v && v[0] == '0'); }();
     const bool st16 = a.stats && a.stats_px == 16;           // 16-pixel statistics blocks: the 384-row kernel only
     if (a.stats && a.stats_px != 0 && a.stats_px != 16 && a.stats_px != 64) { ++g_bad; return -1; }
-    static const bool pp_on = []() { const char* v = getenv("DMAD_H16_PP"); return !(v && v[0] == '0'); }();      // DMAD_H16_PP=0: the first persistent form (A/B runs)
-    if (pers_on && big_on && ng == 1 && (!two || (pp_on && a.N * (long)a.ldx2 < (1l << 31))) && !st16 && a.K <= BIG_KMAX && a.H < 32768 && a.W < 32768 &&
+    if (pers_on && big_on && ng == 1 && (!two || a.N * (long)a.ldx2 < (1l << 31)) && !st16 && a.K <= BIG_KMAX && a.H < 32768 && a.W < 32768 &&
         a.N * (long)a.ldx < (1l << 31)) {
         const int bm = a.M % 256 == 0 ? 256 : (a.M == 128 ? 128 : 0);
         if (bm) {
             const long nxp = (a.N + (bm == 256 ? 255 : 511)) / (bm == 256 ? 256 : 512), tiles = nxp * (a.M / bm);
             if (tiles >= g_h16_cus && nxp < (1l << 31) && a.N * (long)a.ldc < (1l << 31)) {
                 const bool wide = a.C16 && !a.C && !a.res && !(a.ldc & 7);
-                static const bool stamps = []() { const char* v = getenv("DMAD_H16_STAMPS"); return v && v[0] == '1'; }();
-                if (stamps && wide && !two) {            // diagnostic: synchronous, prints wave 0's mean cycles per k-step and per tile
-                    static unsigned long long* dbg = nullptr;
-                    if (!dbg && hipMalloc((void**)&dbg, (size_t)g_h16_cus * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-                    (void)hipMemsetAsync(dbg, 0, (size_t)g_h16_cus * 64, s);
-                    if (bm == 256) hipLaunchKernelGGL((gemm_h16_pers_kernel<256, true, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp, dbg);
-                    else hipLaunchKernelGGL((gemm_h16_pers_kernel<128, true, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp, dbg);
-                    std::vector<unsigned long long> h((size_t)g_h16_cus * 8);
-                    if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-                        double sum[5] = {0, 0, 0, 0, 0}, steps = 0, tiles_ = 0, mid = 0;
-                        for (int b = 0; b < g_h16_cus; ++b) { for (int k = 0; k < 5; ++k) sum[k] += (double)h[b * 8 + k]; mid += (double)h[b * 8 + 7]; steps += (double)h[b * 8 + 5]; tiles_ += (double)h[b * 8 + 6]; }
-                        if (steps > 0 && tiles_ > 0)
-                            fprintf(stderr, "[h16 stamps] M=%d K=%d taps=%d N=%ld res=%d: per k-step phases1-3 %.0f (+ mid barrier %.0f) | barrier wait %.0f | phase4+DMA issue %.0f | loop top %.0f cycles; per tile epilogue %.0f cycles (%.1f k-steps per tile)\n",
-                                    a.M, a.K, a.taps, a.N, a.res16 ? 1 : 0, sum[0] / steps, mid / steps, sum[1] / steps, sum[2] / steps, sum[4] / steps, sum[3] / tiles_, steps / tiles_);
-                    }
+                if (sr_on && bm == 256 && a.taps == 9 && a.stride <= 1 && a.W <= 32 && a.W >= 1) {
+                    if (wide) hipLaunchKernelGGL((gemm_h16_sr_kernel<true>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, (int)nxp);
+                    else hipLaunchKernelGGL((gemm_h16_sr_kernel<false>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, (int)nxp);
                     return 0;
                 }
-                // 3 x 3, stride 1, maps up to 32 pixels wide, 256-row blocks: the slice-resident form (DMAD_H16_SR=0: off, A/B runs)
-                static const int sr_on = []() { const char* v = getenv("DMAD_H16_SR"); return v ? atoi(v) : 1; }();      // 0: off, 256: the 256-row form only
-                if (pp_on && sr_on && (sr_on != 256 || bm == 256) && a.taps == 9 && a.stride <= 1 && a.W <= 32 && a.W >= 1) {
-                    if (bm == 256) {
-                        if (wide) hipLaunchKernelGGL((gemm_h16_sr_kernel<256, true>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, (int)nxp);
-                        else hipLaunchKernelGGL((gemm_h16_sr_kernel<256, false>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, (int)nxp);
-                    } else {                                     // M = 128: 128 x 256 tiles (twice the ping-pong form's tile count)
-                        const long nx2 = (a.N + 255) / 256;
-                        if (wide) hipLaunchKernelGGL((gemm_h16_sr_kernel<128, true>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, (int)nx2);
-                        else hipLaunchKernelGGL((gemm_h16_sr_kernel<128, false>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, (int)nx2);
-                    }
-                    return 0;
-                }
-                // the ping-pong form (it also takes a two-part input)
-                if (pp_on) {
-                    if (bm == 256 && wide) hipLaunchKernelGGL((gemm_h16_pp_kernel<256, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
-                    else if (bm == 256) hipLaunchKernelGGL((gemm_h16_pp_kernel<256, false>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
-                    else if (wide) hipLaunchKernelGGL((gemm_h16_pp_kernel<128, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp);
-                    else hipLaunchKernelGGL((gemm_h16_pp_kernel<128, false>), dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp);
-                    return 0;
-                }
-                if (bm == 256 && wide) hipLaunchKernelGGL((gemm_h16_pers_kernel<256, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
-                else if (bm == 256) hipLaunchKernelGGL((gemm_h16_pers_kernel<256, false>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
-                else if (wide) hipLaunchKernelGGL((gemm_h16_pers_kernel<128, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp);
-                else hipLaunchKernelGGL((gemm_h16_pers_kernel<128, false>), dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp);
+                if (bm == 256 && wide) hipLaunchKernelGGL((gemm_h16_pp_kernel<256, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
+                else if (bm == 256) hipLaunchKernelGGL((gemm_h16_pp_kernel<256, false>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
+                else if (wide) hipLaunchKernelGGL((gemm_h16_pp_kernel<128, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp);
+                else hipLaunchKernelGGL((gemm_h16_pp_kernel<128, false>), dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp);
                 return 0;
             }
         }
