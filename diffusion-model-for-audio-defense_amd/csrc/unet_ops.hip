@@ -72,36 +72,58 @@ __global__ void __launch_bounds__(256) conv3x3_c128_to1_kernel(const float* __re
     out[p] = (acc[0] + acc[1]) + (acc[2] + acc[3]) + bias[0];
 }
 
-// The same layer on an f16 map (the 16-bit tier): one workgroup per image row, thread = (pixel x, 8-channel octet o): the 16 octet
-// threads of a pixel read its 256-byte row with one 16-byte load each (whole lines, neighbouring pixels contiguous), keep their 9 x 8
-// weights in registers, and a 16-lane xor tree adds their partial dot products — where the one-lane-per-pixel form above has every
-// lane walk nine 512-byte fp32 rows of its own (0.9 TB/s).
-__global__ void __launch_bounds__(512) conv3x3_c128_to1_h16_kernel(const h16_t* __restrict__ in, const float* __restrict__ w,
+// The same conv on an f16 map (the 16-bit tier's last layer), on the matrix cores: per pixel the nine taps' dot products with its OWN
+// 128 channels — a 16 x 16 x 32 MFMA chain with the taps as rows (9 of 16) and 16 pixels as columns, the weights split into f16
+// hi + lo parts so that they keep fp32 precision — go to LDS, and an output pixel is the sum of nine neighbours' partials.  Every
+// input byte is read once (the direct form above re-reads each row nine times through L2: 675 us per 2048 spectrograms; this 1).
+// One workgroup per image: 4 waves x 16 pixels per step, 16 steps, then 4 outputs per thread.
+__global__ void __launch_bounds__(256) conv3x3_c128_to1_h16_kernel(const h16_t* __restrict__ in, const float* __restrict__ w,
                                                                    const float* __restrict__ bias, float* __restrict__ out) {
-    const int t = threadIdx.x, o = t & 15, x = t >> 4;
-    const int y = blockIdx.x & 31;
-    const long b = blockIdx.x >> 5;
-    float wk[9][8];
+    __shared__ float P[1024 * 9];                          // [pixel][tap]: 9-float rows (odd stride: conflict-free column reads)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = lane >> 4, r16 = lane & 15;
+    const long b = blockIdx.x;
+    f16x8 ah[4], al[4];                                    // A fragments: row = tap r16 (rows 9-15 zero), k = 32 kk + 8 q ..
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const float4 a0 = *(const float4*)(w + tap * 128 + o * 8), a1 = *(const float4*)(w + tap * 128 + o * 8 + 4);
-        wk[tap][0] = a0.x; wk[tap][1] = a0.y; wk[tap][2] = a0.z; wk[tap][3] = a0.w;
-        wk[tap][4] = a1.x; wk[tap][5] = a1.y; wk[tap][6] = a1.z; wk[tap][7] = a1.w;
-    }
-    const h16_t* img = in + b * 1024 * 128 + o * 8;
-    float acc = 0.f;
+    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-        if ((unsigned)yy < 32u && (unsigned)xx < 32u) {
-            const f16x8 v = *(const f16x8*)(img + (yy * 32 + xx) * 128);
+        for (int r = 0; r < 8; ++r) {
+            const float wf = r16 < 9 ? w[r16 * 128 + kk * 32 + q * 8 + r] : 0.f;
+            const _Float16 h = (_Float16)wf;
+            ah[kk][r] = h;
+            al[kk][r] = (_Float16)(wf - (float)h);
+        }
+    const h16_t* img = in + b * 1024 * 128;
+    for (int it = 0; it < 16; ++it) {
+        const int px = it * 64 + wv * 16 + r16;
+        f16x8 x[4];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) acc = fmaf((float)v[r], wk[tap][r], acc);
+        for (int kk = 0; kk < 4; ++kk) x[kk] = *(const f16x8*)(img + px * 128 + kk * 32 + q * 8);
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kk], x[kk], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk], x[kk], acc, 0, 0, 0);
+        }
+        if (q < 2) {                                       // lane (q, r16): taps 4 q .. 4 q + 3 of pixel r16
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[px * 9 + q * 4 + r] = acc[r];
+        } else if (q == 2) {
+            P[px * 9 + 8] = acc[0];
         }
     }
+    __syncthreads();
+    const float bv = bias[0];
 #pragma unroll
-    for (int m = 8; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
-    if (o == 0) out[b * 1024 + y * 32 + x] = acc + bias[0];
+    for (int i = 0; i < 4; ++i) {
+        const int p = tid + i * 256, y = p >> 5, xq = p & 31;
+        float sum = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = xq + tap % 3 - 1;
+            if ((unsigned)yy < 32u && (unsigned)xx < 32u) sum += P[(yy * 32 + xx) * 9 + tap];
+        }
+        out[b * 1024 + p] = sum + bv;
+    }
 }
 
 // GroupNorm32(32, C) over an NHWC map.  One workgroup per (sample, G neighbouring groups), G chosen so that the G groups'
@@ -603,7 +625,7 @@ void launch_conv3x3_c128_to1(const float* in, const float* w, const float* bias,
     hipLaunchKernelGGL(conv3x3_c128_to1_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, in, w, bias, out, total);
 }
 void launch_conv3x3_c128_to1_h16(const h16_t* in, const float* w, const float* bias, float* out, int B, hipStream_t s) {
-    hipLaunchKernelGGL(conv3x3_c128_to1_h16_kernel, dim3((unsigned)B * 32u), dim3(512), 0, s, in, w, bias, out);
+    hipLaunchKernelGGL(conv3x3_c128_to1_h16_kernel, dim3((unsigned)B), dim3(256), 0, s, in, w, bias, out);
 }
 int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* ss, int silu, float* y, int B, int HW,
                           int C, hipStream_t s, const float* x2, int c1, h16_t* y16, const h16_t* x16, const h16_t* x2_16) {
