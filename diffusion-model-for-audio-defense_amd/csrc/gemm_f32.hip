@@ -44,11 +44,49 @@ __device__ __forceinline__ void x3_dma16(const void* sbase, unsigned voff, unsig
 }
 }  // namespace
 
-template <int BM, bool TWO>               // TWO: the input channels come from two maps (GemmF32Args::X2); an instantiation of its own
-                                          // because the extra test in the staging loop costs the common kernel 2 %
+// s_waitcnt vmcnt(PIECES * stages) + lgkmcnt(0) + barrier for a run-time number of stages in flight (the deep ring's tail; the deep
+// ring exists for 64-row tiles only: 3 pieces per stage, 2 with the narrow tile)
+template <int PIECES>
+__device__ __forceinline__ void gf_wait_stages(int stages) {
+    static_assert(PIECES == 2 || PIECES == 3, "pieces per stage");
+    if (PIECES == 3) {
+        switch (stages) {
+            case 0: GF_WAIT_BARRIER(0); break;
+            case 1: GF_WAIT_BARRIER(3); break;
+            case 2: GF_WAIT_BARRIER(6); break;
+            case 3: GF_WAIT_BARRIER(9); break;
+            case 4: GF_WAIT_BARRIER(12); break;
+            case 5: GF_WAIT_BARRIER(15); break;
+            default: GF_WAIT_BARRIER(18); break;
+        }
+    } else {
+        switch (stages) {
+            case 0: GF_WAIT_BARRIER(0); break;
+            case 1: GF_WAIT_BARRIER(2); break;
+            case 2: GF_WAIT_BARRIER(4); break;
+            case 3: GF_WAIT_BARRIER(6); break;
+            case 4: GF_WAIT_BARRIER(8); break;
+            case 5: GF_WAIT_BARRIER(10); break;
+            default: GF_WAIT_BARRIER(12); break;
+        }
+    }
+}
+
+// TWO: the input channels come from two maps (GemmF32Args::X2); an instantiation of its own because the extra test in the staging
+//      loop costs the common kernel 2 %.
+// NS, NT: ring slots and 16-pixel accumulator tiles per wave along N (tile width 32 NT).  3 / 4 for launches that fill the chip.
+//      8 / 1 for launches of fewer workgroups than CUs (the recheck of a few samples on a large engine, whose split-K count is
+//      derived from the engine's max batch): there a workgroup's K loop is serial fp32 MFMA work, 32 cycles each, and the launch
+//      is bound by ONE workgroup's 64 x 128 tile — 64 x 32 tiles are four times as many workgroups; and alone on its CU a workgroup
+//      sees the staging latency over its prefetch distance, hence 7 stages in flight instead of 2.  Same k order, same MFMA
+//      sequence per output: the same bits.
+template <int BM, bool TWO, int NS = 3, int NT = 4>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
     constexpr int MT = BM / 32;            // 16-row accumulator tiles per wave along M (2 M-waves)
-    __shared__ __attribute__((aligned(16))) char smem[3 * SLOT];
+    constexpr int BNT = 32 * NT, XP = NT == 4 ? 2 : 1;      // tile width in pixels; 64-row activation pieces per stage
+    static_assert(NT == 4 || (NT == 1 && BM == 64 && !TWO), "the narrow tile is built for the plain 64-row kernel");
+    static_assert(NS == 3 || (BM == 64 && NS == 8), "the deep ring is built for 64-row tiles and 8 slots");
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // NS * SLOT bytes
     if (a.groups > 1) {                      // grouped conv: this workgroup's group = blockIdx.z
         const int g = blockIdx.z;
         a.A += (size_t)g * a.taps * a.M * a.K;
@@ -61,7 +99,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1, q = lane >> 4, r16 = lane & 15;
-    const long n0 = (long)blockIdx.x * BN;
+    const long n0 = (long)blockIdx.x * BNT;
     const int m0 = blockIdx.y * BM;
     const int ksteps_per_tap = a.K / BK, nks_all = a.taps * ksteps_per_tap;
     const int S = a.splits > 1 ? a.splits : 1, z = a.groups > 1 ? 0 : blockIdx.z;
@@ -79,7 +117,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
         const int m = m0 + p * 64 + rloc;
         arow[p] = (p * 64 < BM && m < a.M) ? a.A + (size_t)m * a.K + chunk4 : nullptr;
         const long n = n0 + p * 64 + rloc;
-        xok[p] = n < a.N;
+        xok[p] = n < a.N && p * 64 + rloc < BNT;
         xbase[p] = 0; xy[p] = 0; xx[p] = 0;
         if (xok[p]) {
             if (a.mode == 2) {
@@ -105,7 +143,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
             glds16(src, la + p * 4096);
         }
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < XP; ++p) {
             const float* src = zero;
             if (xok[p]) {
                 if (a.mode == 2) {
@@ -129,29 +167,35 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frag = r16 * 64 + ((q ^ swz64(r16)) * 16);
-    if (ks_begin < nks) stage(ks_begin, 0);
-    if (ks_begin + 1 < nks) stage(ks_begin + 1, 1);
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i)
+        if (ks_begin + i < nks) stage(ks_begin + i, i);
     int slot = 0;
     for (int ks = ks_begin; ks < nks; ++ks) {
-        // stage ks landed (the 4 pieces of stage ks+1 may still fly); every wave is done reading slot (ks-1) % 3
-        if (ks + 1 < nks) { if (BM == 128) { GF_WAIT_BARRIER(4); } else { GF_WAIT_BARRIER(3); } } else { GF_WAIT_BARRIER(0); }
-        if (ks + 2 < nks) stage(ks + 2, slot >= 1 ? slot - 1 : 2);
+        // stage ks landed (the pieces of the NS - 2 stages behind it may still fly); every wave is done reading slot (ks-1) % NS
+        if constexpr (NS == 3) {
+            if (ks + 1 < nks) { if (BM == 128) { GF_WAIT_BARRIER(4); } else { GF_WAIT_BARRIER(3); } } else { GF_WAIT_BARRIER(0); }
+        } else {
+            const int behind = nks - 1 - ks;
+            gf_wait_stages<BM / 64 + XP>(behind < NS - 2 ? behind : NS - 2);
+        }
+        if (ks + NS - 1 < nks) stage(ks + NS - 1, slot >= 1 ? slot - 1 : NS - 1);
         const char* As = smem + slot * SLOT + wm * (BM * 32) + frag;
-        const char* Bs = smem + slot * SLOT + 8192 + wn * 4096 + frag;
+        const char* Bs = smem + slot * SLOT + 8192 + wn * (NT * 1024) + frag;
         f32x4 af[MT], bf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < MT) af[i] = *(const f32x4*)(As + i * 1024);
-            bf[i] = *(const f32x4*)(Bs + i * 1024);
+            if (i < NT) bf[i] = *(const f32x4*)(Bs + i * 1024);
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
-        slot = slot == 2 ? 0 : slot + 1;
+        slot = slot == NS - 1 ? 0 : slot + 1;
     }
 
     if (S > 1) {   // split-K: raw partial sums to this split's slab; scale/shift/act happen in the reduce kernel
@@ -159,8 +203,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
         for (int i = 0; i < MT; ++i) {
             const int m = m0 + wm * (BM / 2) + i * 16 + q * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const long n = n0 + wn * 64 + j * 16 + r16;
+            for (int j = 0; j < NT; ++j) {
+                const long n = n0 + wn * (NT * 16) + j * 16 + r16;
                 if (n >= a.N) continue;
                 float* dst = a.slab + ((long)z * a.N + n) * a.ldc + m;
 #pragma unroll
@@ -231,8 +275,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
     long nrow[4];
     bool nok[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const long n = n0 + wn * 64 + j * 16 + r16;
+    for (int j = 0; j < NT; ++j) {
+        const long n = n0 + wn * (NT * 16) + j * 16 + r16;
         nok[j] = n < a.N;
         nrow[j] = (nok[j] ? n : a.N - 1) * a.ldc;
     }
@@ -246,7 +290,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
             sh[r] = (a.shift && m + r < a.M) ? a.shift[m + r] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = a.scale ? acc[i][j][r] * sc[r] + sh[r] : acc[i][j][r] + sh[r];
     }
@@ -256,7 +300,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
         if (a.res) {                         // the four residual chunks of this row tile ahead of its stores
             float rr[4][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 if (vec && m + 3 < a.M) {
                     const float4 r4 = *(const float4*)(a.res + nrow[j] + m);
                     rr[j][0] = r4.x; rr[j][1] = r4.y; rr[j][2] = r4.z; rr[j][3] = r4.w;
@@ -266,12 +310,12 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args a) {
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += rr[j][r];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NT; ++j) {
             if (!nok[j]) continue;
             float v[4];
 #pragma unroll
@@ -579,6 +623,13 @@ int gemm_x3_configure() {
     return (int)hipFuncSetAttribute((const void*)gemm_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
 }
 
+namespace {
+bool narrow_ready() {                      // 128 KiB of dynamic LDS for the 8-slot instantiation, asked for once
+    static const bool ok = hipFuncSetAttribute((const void*)gemm_f32_kernel<64, false, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * SLOT) == hipSuccess;
+    return ok;
+}
+}  // namespace
+
 int launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab_floats, long n_ref) {
     GemmF32Args a = a0;
     // the update epilogue indexes positions in 32 bits and serves M = 256 residual rows (the skip convs are one GEMM of their own)
@@ -603,10 +654,13 @@ int launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab
     const unsigned gx = (unsigned)gx_, gy = (unsigned)((a.M + BM - 1) / BM);
     const int nks = a.taps * (a.K / BK);
     int S = 1;
+    static const bool narrow_on = []() { const char* v = getenv("DMAD_F32_NARROW"); return !(v && v[0] == '0'); }();      // A/B switch
     auto launch = [&](dim3 grid) {
-        if (a.X2) hipLaunchKernelGGL((gemm_f32_kernel<128, true>), grid, dim3(256), 0, s, a);
-        else if (BM == 64) hipLaunchKernelGGL((gemm_f32_kernel<64, false>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((gemm_f32_kernel<128, false>), grid, dim3(256), 0, s, a);
+        if (a.X2) hipLaunchKernelGGL((gemm_f32_kernel<128, true>), grid, dim3(256), 3 * SLOT, s, a);
+        else if (BM == 64 && narrow_on && (long)grid.x * grid.y * grid.z < 256 && nks >= 8 && narrow_ready())       // fewer workgroups than CUs:
+            hipLaunchKernelGGL((gemm_f32_kernel<64, false, 8, 1>), dim3((unsigned)((a.N + 31) / 32), grid.y, grid.z), dim3(256), 8 * SLOT, s, a);   // 64 x 32 tiles, 8-slot ring
+        else if (BM == 64) hipLaunchKernelGGL((gemm_f32_kernel<64, false>), grid, dim3(256), 3 * SLOT, s, a);
+        else hipLaunchKernelGGL((gemm_f32_kernel<128, false>), grid, dim3(256), 3 * SLOT, s, a);
     };
     if (a.groups > 1) {
         a.splits = 1;
