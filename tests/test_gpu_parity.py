@@ -743,7 +743,7 @@ H16_CASES = [   # B, H, cin, cout, taps, stride, c1 (two-part input: first map's
     (128, 32, 384, 128, 1, 1, 256, False, 1, False), (257, 16, 512, 256, 9, 1, 256, True, 1, False),
     # the slice-resident 3x3 form on 32-, 8- and 4-pixel-wide maps (tiles spanning 1/4, 4 and 16 images; N tail on the last)
     (64, 32, 256, 256, 9, 1, 0, False, 1, False), (1024, 8, 128, 256, 9, 1, 0, True, 1, False), (4100, 4, 256, 256, 9, 1, 0, False, 1, False),
-    # the two-workgroups-per-CU 1x1 form: proj with residual and an N tail, K = 512 two-part skip conv
+    # chip-filling 1x1 convs through the ping-pong form: proj with residual and an N tail, K = 512 two-part skip conv
     (130, 16, 256, 256, 1, 1, 0, True, 1, False), (65, 32, 512, 128, 1, 1, 256, False, 1, False),
     # ResNeXt29's forms: K = 64, ReLU, 1x1 with stride 2, grouped 3x3 (4 paired / 8 groups; stride 2; small and chip-filling launches)
     (3, 32, 64, 512, 1, 1, 0, False, 1, True), (2, 32, 256, 512, 1, 2, 0, False, 1, False), (2, 16, 512, 512, 9, 1, 0, False, 4, True),
