@@ -1297,7 +1297,7 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     e->tau2 = 1e-3f;                        // the same for the split-f16 tier (dmad_set_recheck_margin2)
     e->un_h16 = cfg->precision != DMAD_FP32;    // engines with a 16-bit side also get the UNet's f16 tier (once UNet weights are loaded)
     e->rx_h16 = cfg->precision != DMAD_FP32;    // ... and ResNeXt29's (once its weights are loaded)
-    e->tau_spec = 0.4f;                     // spec-domain vote loop: measured logit-difference error of the f16 UNet chain x headroom (see dmad.h)
+    e->tau_spec = 0.5f;                     // spec-domain vote loop: measured logit-difference error of the f16 UNet chain x headroom (see dmad.h)
     const bool wn = cfg->with_wavenet != 0;
     if (e->bf16 && !wn_final_p_supported(cfg->num_res_layers)) {
         delete e;

@@ -34,7 +34,7 @@ DEFAULT_RECHECK_MARGIN2 = 1e-3
 # Spec-domain vote loop (BASELINE C5): the UNet's 16-bit tier runs the whole 26-evaluation chain on f16 operands; a sample whose
 # top-2 logit margin is below this bound re-runs its chain on the exact-fp32 UNet.  Measured with tools/gpu_c5_flip_study.py
 # (profiles/r03_c5_flip_study.md): the same leader-difference statistic as DEFAULT_RECHECK_MARGIN, x headroom.
-DEFAULT_SPEC_RECHECK_MARGIN = 0.4
+DEFAULT_SPEC_RECHECK_MARGIN = 0.5
 # Tail rule shared by the committed default and calibrate_recheck (tools/fit_recheck_tail.py): with s the
 # Gaussian scale of the per-sample leader-difference error, a bound of TAIL_Z * s keeps the modelled miss probability per
 # sample (error beyond the bound AND an exact margin small enough to be overturned) at or below 1e-9.

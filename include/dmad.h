@@ -260,7 +260,7 @@ int dmad_spec_smooth_votes(dmad_engine* e, const float* clip, float sigma, int32
  * evaluate the exact-fp32 UNet unless the engine is in DMAD_MODE_FAST (or dmad_set_waveform_tier chose the 16-bit tier): the 16-bit
  * tier is opt-in there (DMAD_FP32 engines have only the fp32 one).  In DMAD_MODE_EXACT_VOTES
  * dmad_spec_smooth_votes runs every sample's chain on the 16-bit tier, queues the samples whose top-2 logit margin is below
- * tau_spec (dmad_set_spec_recheck_margin; default 0.4 = 1.45 x the largest leader-difference error (0.276) of the 16-bit chain measured on 6 144 samples) and re-runs their WHOLE chain on the exact-fp32
+ * tau_spec (dmad_set_spec_recheck_margin; default 0.5 = 1.66 x the largest leader-difference error (0.30) of the 16-bit chain measured on 6 144 samples) and re-runs their WHOLE chain on the exact-fp32
  * UNet from the same Philox keys — the same empirical guarantee as the waveform loop's (dmad_set_mode).
  * dmad_spec_recheck_stats: samples voted by dmad_spec_smooth_votes, samples whose chain was re-run in fp32. */
 int dmad_set_spec_recheck_margin(dmad_engine* e, float tau);
