@@ -607,11 +607,14 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
     long stile = ctile;
     int st_tap = 0, st_kq = 0, st_left = my_tiles * nsteps;         // K-tiles not completely staged yet
     unsigned st_lds = lds0;                                          // the cursor K-tile's buffer
-    int xpix[2 * BPW], xyx[2 * BPW];                                 // [h * BPW + p]: image base pixel (or -1: past N), (y << 16) | x
-    int st_dy = a.taps == 9 ? -1 : 0, st_dx = st_dy;
+    // per staged pixel row of the lane, [h * BPW + p]: flat input pixel of tap (0, 0) and the taps that fall inside the image (nine
+    // bits; 0: row past N) — a piece's address is then one select and one multiply-add (the load parts are this kernel's critical path)
+    int xflat[2 * BPW];
+    unsigned xmask[2 * BPW];
+    int st_toff = a.taps == 9 ? -a.W - 1 : 0;                        // the staging tap's pixel offset, dy * W + dx
     const char* Ab = nullptr;
     const char* st_a = nullptr;
-    auto tile_rows = [&](long id) {
+    auto tile_rows = [&](long id) __attribute__((always_inline)) {       // (inlined by force: out of line, the cursor state it writes would live in memory — and in VGPRs)
         const long tx = id / ny;
         const int mb = (int)(id - tx * ny);
         Ab = (const char*)(a.A + (size_t)mb * BM * a.K);
@@ -621,11 +624,19 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
 #pragma unroll
             for (int p = 0; p < BPW; ++p) {
                 const unsigned n = n0 + (2 * p + (wv >> 2)) * 64 + h * 32 + (wv & 3) * 8 + l8;
-                xpix[h * BPW + p] = -1; xyx[h * BPW + p] = 0;
+                xflat[h * BPW + p] = 0; xmask[h * BPW + p] = 0u;
                 if (n < (unsigned)a.N) {
                     const unsigned b = n / (unsigned)hw, pix = n - b * (unsigned)hw, py = pix / (unsigned)Wo;
-                    xpix[h * BPW + p] = (int)(b * (unsigned)(a.H * a.W));
-                    xyx[h * BPW + p] = (int)(((py * st) << 16) | ((pix - py * Wo) * st));
+                    const int y = (int)(py * st), x = (int)((pix - py * Wo) * st);
+                    xflat[h * BPW + p] = (int)(b * (unsigned)(a.H * a.W)) + y * a.W + x;
+                    unsigned bits = 0x1ffu;
+                    if (a.taps == 9) {
+                        bits = 0u;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t)
+                            if ((unsigned)(y + t / 3 - 1) < (unsigned)a.H && (unsigned)(x + t % 3 - 1) < (unsigned)a.W) bits |= 1u << t;
+                    }
+                    xmask[h * BPW + p] = bits;
                 }
             }
     };
@@ -643,7 +654,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
         st_ld = second ? a.ldx2 : a.ldx;
         st_ko = second ? kc - a.ksplit : kc;
     };
-    auto st_advance = [&]() {                                        // after the cursor K-tile's last half-tile (A1) has been issued
+    auto st_advance = [&]() __attribute__((always_inline)) {         // after the cursor K-tile's last half-tile (A1) has been issued
         --st_left;
         st_lds = lds0 + ((st_lds - lds0) ^ BUFB);
         if (++st_tap == a.taps) {
@@ -654,8 +665,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
                 if (st_left > 0) tile_rows(stile);
             }
         }
-        st_dy = a.taps == 9 ? st_tap / 3 - 1 : 0;
-        st_dx = a.taps == 9 ? st_tap % 3 - 1 : 0;
+        st_toff = a.taps == 9 ? (st_tap / 3 - 1) * a.W + st_tap % 3 - 1 : 0;
         st_a = Ab + (size_t)st_tap * a_tap + (size_t)st_kq * 128;
         slice_source();
     };
@@ -671,9 +681,8 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
 #pragma unroll
         for (int p = 0; p < BPW; ++p) {
             const int k = h * BPW + p;
-            const int yy = (xyx[k] >> 16) + st_dy, xq = (xyx[k] & 0xffff) + st_dx;
-            const bool ok = xpix[k] >= 0 && (unsigned)yy < (unsigned)a.H && (unsigned)xq < (unsigned)a.W;
-            const h16_t* src = ok ? st_x + ((long)xpix[k] + yy * a.W + xq) * st_ld + ch8 + st_ko : zrow;
+            const bool ok = (xmask[k] >> st_tap) & 1u;
+            const h16_t* src = ok ? st_x + (unsigned)(xflat[k] + st_toff) * (unsigned)st_ld + ch8 + st_ko : zrow;      // (N * ldx < 2^31: launcher)
 #if PP_ABLATE == 2 || PP_ABLATE == 5
             src = ok ? zrow + 64 : zrow;
 #elif PP_ABLATE == 7
