@@ -945,8 +945,8 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
     auto stageX = [&](int i) {                                       // piece wv + 8 i of the cursor slice (rows 8 z .. 8 z + 7)
         const int z = wv + 8 * i;
         if (z < xpieces) {
-            const long n = x_n0 + z * 8 + l8;
-            const h16_t* src = (n >= 0 && n < a.N) ? x_src + n * x_ld + x_ko + xch : zrow;
+            const unsigned n = (unsigned)((int)x_n0 + z * 8 + l8);           // (N * ldx < 2^31, launcher; a row before the tensor wraps to a huge value)
+            const h16_t* src = n < (unsigned)a.N ? x_src + n * (unsigned)x_ld + x_ko + xch : zrow;
             dma16v(src, x_lds + z * 1024);
         }
     };
@@ -960,7 +960,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
             const long n = n0 + p;
             unsigned bits = 0;
             if (n < a.N) {
-                const unsigned pix = (unsigned)(n % hw), y = pix / (unsigned)W, x = pix - y * (unsigned)W;
+                const unsigned pix = (unsigned)n % (unsigned)hw, y = pix / (unsigned)W, x = pix - y * (unsigned)W;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int yy = (int)y + t / 3 - 1, xx = (int)x + t % 3 - 1;
