@@ -459,8 +459,12 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_big_kernel(GemmH16Args a) {
 
 // Epilogue of a persistent tile, straight from the accumulators (acc[i][j]: row tile i, pixel tile j of the wave's 128 x 64 output;
 // wm / wn: the wave's position in the tile): bias, residual, ReLU, GroupNorm statistics, stores; leaves the accumulators zeroed.
-template <int BM, bool WIDE, int BN = (BM == 256 ? 256 : 512), int MT = 8>      // MT: accumulator row tiles per wave (wave rows = 16 MT)
-__device__ __forceinline__ void pers_epilogue(const GemmH16Args& a, f32x4 (&acc)[MT][4], long ctile, int ny, int wm, int wn, int q, int r16) {
+// RES (16-byte form): the f16 residual as a COMPILE-TIME branch.  With run-time `if (a.res16)` blocks around the loads and around their
+// uses, hipcc's wait-count pass sees a path on which a residual load is still pending at the end of the epilogue, carries it round
+// the persistent loop and puts an `s_waitcnt vmcnt(0)` in front of the first fragment read that reuses the register — a full drain
+// of the staging DMA in EVERY K-tile (found in the 128 x 512 ping-pong kernel's ISA).
+template <int BM, bool WIDE, int BN = (BM == 256 ? 256 : 512), int MT = 8, bool RES = false>      // MT: accumulator row tiles per wave (wave rows = 16 MT)
+__device__ __forceinline__ void pers_epilogue_impl(const GemmH16Args& a, f32x4 (&acc)[MT][4], long ctile, int ny, int wm, int wn, int q, int r16) {
     const long tx = ctile / ny;
     const int m0 = (int)(ctile - tx * ny) * BM;
     const long n0 = tx * BN;
@@ -493,14 +497,14 @@ __device__ __forceinline__ void pers_epilogue(const GemmH16Args& a, f32x4 (&acc)
             float s10 = 0.f, s20 = 0.f, s11 = 0.f, s21 = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (a.res16 && j % JB == 0) {
+                if (RES && j % JB == 0) {
 #pragma unroll
                     for (int jj = 0; jj < JB; ++jj) rc[jj] = *(const u32x4*)(a.res16 + nrow[j + jj] + coff);
                 }
                 f32x4 v0 = acc[t0][j], v1 = acc[t1][j];
                 v0[0] += b0.x; v0[1] += b0.y; v0[2] += b0.z; v0[3] += b0.w;
                 v1[0] += b1.x; v1[1] += b1.y; v1[2] += b1.z; v1[3] += b1.w;
-                if (a.res16) {
+                if (RES) {
                     const auto h0 = __builtin_amdgcn_permlane16_swap(rc[j % JB][0], rc[j % JB][2], false, false);
                     const auto h1 = __builtin_amdgcn_permlane16_swap(rc[j % JB][1], rc[j % JB][3], false, false);
                     const f16x4 hx = __builtin_bit_cast(f16x4, u32x2{h0[0], h1[0]}), hy = __builtin_bit_cast(f16x4, u32x2{h0[1], h1[1]});
@@ -555,6 +559,12 @@ __device__ __forceinline__ void pers_epilogue(const GemmH16Args& a, f32x4 (&acc)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[ii][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+}
+
+template <int BM, bool WIDE, int BN = (BM == 256 ? 256 : 512), int MT = 8>
+__device__ __forceinline__ void pers_epilogue(const GemmH16Args& a, f32x4 (&acc)[MT][4], long ctile, int ny, int wm, int wn, int q, int r16) {
+    if (WIDE && a.res16) pers_epilogue_impl<BM, WIDE, BN, MT, true>(a, acc, ctile, ny, wm, wn, q, r16);
+    else pers_epilogue_impl<BM, WIDE, BN, MT, false>(a, acc, ctile, ny, wm, wn, q, r16);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------------
