@@ -657,27 +657,33 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
     // family walks the K-tiles in this order, so a sample's f16 result does not depend on which kernel its batch size selects.
     const h16_t* st_x = a.X;                                         // the cursor slice's input map, row stride and channel offset:
     int st_ld = a.ldx, st_ko = 0;                                    // the second part of a concatenated input (th.cat(dim=1)) from a.ksplit on
+    const h16_t* st_xl = a.X + ch8;
     auto slice_source = [&]() {
         const int kc = st_kq * HK;
         const bool second = a.X2 != nullptr && kc >= a.ksplit;
         st_x = second ? a.X2 : a.X;
         st_ld = second ? a.ldx2 : a.ldx;
         st_ko = second ? kc - a.ksplit : kc;
+        st_xl = st_x + st_ko + ch8;                                  // the lane's chunk of pixel row 0 of this slice: a piece adds one row offset
     };
+    int st_col = 0;                                                  // the staging tap's column (tap % 3)
     auto st_advance = [&]() __attribute__((always_inline)) {         // after the cursor K-tile's last half-tile (A1) has been issued
         --st_left;
         st_lds = lds0 + ((st_lds - lds0) ^ BUFB);
-        if (++st_tap == a.taps) {
-            st_tap = 0;
+        if (++st_tap == a.taps) {                                    // next slice (or tile): the addresses from scratch
+            st_tap = 0; st_col = 0;
             if (++st_kq == steps_per_tap) {
                 st_kq = 0;
                 stile += G8;
                 if (st_left > 0) tile_rows(stile);
             }
+            st_toff = a.taps == 9 ? -a.W - 1 : 0;
+            st_a = Ab + (size_t)st_kq * 128;
+            slice_source();
+        } else {                                                     // next tap of the slice: increments only (this runs in every load part)
+            st_a += a_tap;
+            if (++st_col == 3) { st_col = 0; st_toff += a.W - 2; } else ++st_toff;
         }
-        st_toff = a.taps == 9 ? (st_tap / 3 - 1) * a.W + st_tap % 3 - 1 : 0;
-        st_a = Ab + (size_t)st_tap * a_tap + (size_t)st_kq * 128;
-        slice_source();
     };
     const h16_t* zrow = g_zero_page_big + (lane & 7) * 8;
     auto stageA = [&](int h) {                                       // weights: wave-uniform base + one lane offset
@@ -692,7 +698,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
         for (int p = 0; p < BPW; ++p) {
             const int k = h * BPW + p;
             const bool ok = (xmask[k] >> st_tap) & 1u;
-            const h16_t* src = ok ? st_x + (unsigned)(xflat[k] + st_toff) * (unsigned)st_ld + ch8 + st_ko : zrow;      // (N * ldx < 2^31: launcher)
+            const h16_t* src = ok ? st_xl + (unsigned)(xflat[k] + st_toff) * (unsigned)st_ld : zrow;      // (N * ldx < 2^31: launcher)
 #if PP_ABLATE == 2 || PP_ABLATE == 5
             src = ok ? zrow + 64 : zrow;
 #elif PP_ABLATE == 7
