@@ -609,14 +609,18 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
     const int steps_per_tap = a.K / HK, nsteps = a.taps * steps_per_tap;
     const int l8 = lane >> 3, ch8 = ((lane & 7) ^ (((wv & 1) * 4 + (l8 >> 1)) & 7)) * 8;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
-    const unsigned voffA = (unsigned)((l8 * a.K + ch8) * 2);
-    const size_t a_tap = (size_t)a.M * a.K * 2, a_row = (size_t)a.K * 2;
+    unsigned voffAp[APW][2];                                         // weight piece (p, h): its rows' byte offset + the lane's (one register each:
+#pragma unroll                                                        //  the scalar form of these sums lived in spilled SGPRs, three v_readlane per piece)
+    for (int p = 0; p < APW; ++p)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) voffAp[p][h] = (unsigned)(((p * 128 + h * 64 + wv * 8 + l8) * a.K + ch8) * 2);
+    const size_t a_tap = (size_t)a.M * a.K * 2;
     const int st = a.stride > 1 ? a.stride : 1;
     const int Wo = (a.W - 1) / st + 1, Ho = (a.H - 1) / st + 1, hw = Ho * Wo;
     // ---- staging cursor: tile, tap, K-tile inside the tap; per-lane pixel rows of the staging tile ---------------------------
     long stile = ctile;
     int st_tap = 0, st_kq = 0, st_left = my_tiles * nsteps;         // K-tiles not completely staged yet
-    unsigned st_lds = lds0;                                          // the cursor K-tile's buffer
+    unsigned st_lds = lds0 + wv * 1024;                              // the cursor K-tile's buffer, at this wave's 1-KiB piece of a 64-row group
     // per staged pixel row of the lane, [h * BPW + p]: flat input pixel of tap (0, 0) and the taps that fall inside the image (nine
     // bits; 0: row past N) — a piece's address is then one select and one multiply-add (the load parts are this kernel's critical path)
     int xflat[2 * BPW];
@@ -669,7 +673,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
     int st_col = 0;                                                  // the staging tap's column (tap % 3)
     auto st_advance = [&]() __attribute__((always_inline)) {         // after the cursor K-tile's last half-tile (A1) has been issued
         --st_left;
-        st_lds = lds0 + ((st_lds - lds0) ^ BUFB);
+        st_lds = lds0 + ((st_lds - lds0) ^ BUFB);                    // (the wave's 1-KiB offset lies below BUFB's bits)
         if (++st_tap == a.taps) {                                    // next slice (or tile): the addresses from scratch
             st_tap = 0; st_col = 0;
             if (++st_kq == steps_per_tap) {
@@ -690,7 +694,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
 #if PP_ABLATE != 1
 #pragma unroll
         for (int p = 0; p < APW; ++p)
-            dma16s((PP_ABLATE == 2 ? Ab : st_a) + (size_t)(p * 128 + h * 64 + wv * 8) * a_row, voffA, st_lds + h * AHB + (p * 64 + wv * 8) * 128);
+            dma16s(PP_ABLATE == 2 ? Ab : st_a, voffAp[p][h], st_lds + h * AHB + p * 8192);
 #endif
     };
     auto stageB = [&](int h) {                                       // gathered pixel rows (a tap outside the image: the zero page)
@@ -705,7 +709,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_pp_kernel(GemmH16Args a, int 
             src = ok ? st_x + (long)(l8 + 8 * (wv & 3)) * st_ld + ch8 + st_ko : zrow;      // 32 real (non-zero) rows: cache-resident, same operand statistics
 #endif
 #if PP_ABLATE != 1
-            dma16v(src, st_lds + 2 * AHB + h * BHB + (p * 64 + wv * 8) * 128);
+            dma16v(src, st_lds + 2 * AHB + h * BHB + p * 8192);
 #else
             asm volatile("" ::"v"(src));
 #endif
@@ -904,18 +908,23 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
     const int nslices = a.K / HK, nsteps = 9 * nslices;
     const int l8 = lane >> 3;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
-    const unsigned voffA = (unsigned)((l8 * a.K + ((lane & 7) ^ (((wv & 1) * 4 + (l8 >> 1)) & 7)) * 8) * 2);
-    const size_t a_tap = (size_t)a.M * a.K * 2, a_row = (size_t)a.K * 2;
+    unsigned voffAp[2][2];                                           // weight piece (p, h): its rows' byte offset + the lane's (one register each)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            voffAp[p][h] = (unsigned)(((p * 128 + h * 64 + wv * 8 + l8) * a.K + ((lane & 7) ^ (((wv & 1) * 4 + (l8 >> 1)) & 7)) * 8) * 2);
+    const size_t a_tap = (size_t)a.M * a.K * 2;
     const int W = a.W, hw = a.H * a.W, halo = W + 1;
     const int xpieces = (BN + 2 * halo + 7) >> 3;                    // 1-KiB pieces of a slice (41 at W = 32)
     for (int i = tid; i < 64; i += 512) ((unsigned*)(smem + SR_ARING + (i >> 5) * SR_XB + SR_XROWS * 128))[i & 31] = 0u;      // the two zero rows
     // ---- weight cursor (K-tiles, 1.5 ahead of the compute cursor) ----------------------------------------------------------------
     long atile = ctile;
     int a_tapi = 0, a_kq = 0, a_left = my_tiles * nsteps;           // K-tiles whose weights are not completely staged yet
-    unsigned a_lds = lds0;
+    unsigned a_lds = lds0 + wv * 1024;
     const char* Ab = (const char*)(a.A + (size_t)(ctile % ny) * BM * a.K);
     const char* st_a = Ab;
-    auto a_advance = [&]() {
+    auto a_advance = [&]() __attribute__((always_inline)) {
         --a_left;
         a_lds = lds0 + ((a_lds - lds0) ^ ABUF);
         if (++a_tapi == 9) {
@@ -925,12 +934,14 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
                 atile += G8;
                 Ab = (const char*)(a.A + (size_t)(atile % ny) * BM * a.K);
             }
+            st_a = Ab + (size_t)a_kq * 128;
+        } else {
+            st_a += a_tap;                                           // (the per-K-tile path: one add)
         }
-        st_a = Ab + (size_t)a_tapi * a_tap + (size_t)a_kq * 128;
     };
     auto stageA = [&](int h) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) dma16s(st_a + (size_t)(p * 128 + h * 64 + wv * 8) * a_row, voffA, a_lds + h * AHB + (p * 64 + wv * 8) * 128);
+        for (int p = 0; p < 2; ++p) dma16s(st_a, voffAp[p][h], a_lds + h * AHB + p * 8192);
     };
     // ---- slice cursor (one slice ahead of the compute cursor) ----------------------------------------------------------------
     long xtile = ctile;
@@ -1044,7 +1055,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
     if (a_left > 0) { stageA(0); GH_WAIT_BARRIER(2); } else { GH_WAIT_BARRIER(0); }
     if (grp == 1) PP_BARRIER();                                      // the second group runs half a phase behind
     const int total = my_tiles * nsteps;
-    int s = 0, tap = 0, toff = -W - 1;                               // K-tile inside the compute tile, its tap and the tap's row offset
+    int s = 0, tap = 0, tcol = 0, toff = -W - 1;                     // K-tile inside the compute tile, its tap (and tap % 3) and the tap's row offset
     const char* xbuf = smem + SR_ARING;
     for (int g = 0; g < total; ++g) {
         const char* cur = smem + (g & 1) * ABUF;
@@ -1078,11 +1089,16 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
         PP_QUAD2(B1, 1, 1, B0, 1, 0);
         PP_BARRIER();
         if (++tap == 9) {                                            // the slice is complete: the next one (staged during taps 0-5) becomes current
-            tap = 0;
+            tap = 0; tcol = 0;
+            toff = -W - 1;
             if (x_left > 0) x_advance();
             xbuf = smem + SR_ARING + ((xbuf - smem - SR_ARING) ^ SR_XB);
+        } else if (++tcol == 3) {
+            tcol = 0;
+            toff += W - 2;
+        } else {
+            ++toff;
         }
-        toff = (tap / 3 - 1) * W + tap % 3 - 1;
         if (s != nsteps - 1) { ++s; continue; }
         // ---- the tile is complete: both groups run the epilogue at the same time -------------------------------------------------
         if (grp == 0) PP_BARRIER();
