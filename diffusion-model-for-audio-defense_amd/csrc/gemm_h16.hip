@@ -946,7 +946,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
     // ---- slice cursor (one slice ahead of the compute cursor) ----------------------------------------------------------------
     long xtile = ctile;
     int x_kq = 0, x_left = my_tiles * nslices;                      // slices not staged yet
-    unsigned x_lds = lds0 + SR_ARING;
+    unsigned x_lds = lds0 + SR_ARING + wv * 1024;
     const h16_t* x_src = a.X;
     int x_ld = a.ldx, x_ko = 0;
     long x_n0 = (ctile / ny) * BN - halo;                            // flat pixel of slice row 0
@@ -961,7 +961,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
     };
     auto x_advance = [&]() {                                         // after the slice's last piece has been issued
         --x_left;
-        x_lds = lds0 + SR_ARING + ((x_lds - lds0 - SR_ARING) ^ SR_XB);
+        x_lds = x_lds == lds0 + SR_ARING + wv * 1024 ? x_lds + SR_XB : x_lds - SR_XB;        // (SR_XB shares bits with the wave offset: no XOR here)
         if (++x_kq == nslices) {
             x_kq = 0;
             xtile += G8;
@@ -974,7 +974,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
         if (z < xpieces) {
             const unsigned n = (unsigned)((int)x_n0 + z * 8 + l8);           // (N * ldx < 2^31, launcher; a row before the tensor wraps to a huge value)
             const h16_t* src = n < (unsigned)a.N ? x_src + n * (unsigned)x_ld + x_ko + xch : zrow;
-            dma16v(src, x_lds + z * 1024);
+            dma16v(src, x_lds + i * 8192);
         }
     };
     // ---- the compute tile's pixels: slice row of tap (0, 0) and the nine validity bits, per accumulator column of the lane ----------
