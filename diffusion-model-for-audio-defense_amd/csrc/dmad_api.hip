@@ -1015,10 +1015,16 @@ bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, 
         H /= 2;
         Hout = H;
     } else if (o.kind == 4) {               // Upsample: nearest x2 + conv 3x3, unet.py:49-79
-        launch_upsample2x_nhwc_h16(in.h, e->un_uph, B, H, H, o.cin, s);
         H *= 2;
         Hout = H;
-        launch_gemm_h16(un_h16_args(o.w1h, o.b1, e->un_uph, nullptr, outh, o.cout, o.cin, 9, B, H, 1, nullptr, outst), s);
+        GemmH16Args g = un_h16_args(o.w1h, o.b1, in.h, nullptr, outh, o.cout, o.cin, 9, B, H, 1, nullptr, outst);
+        g.up2 = 1;                              // the conv reads the half-resolution map through the upsampling where the kernel can
+        if (!gemm_h16_fuses_up2(g)) {
+            launch_upsample2x_nhwc_h16(in.h, e->un_uph, B, H / 2, H / 2, o.cin, s);
+            g.up2 = 0;
+            g.X = e->un_uph;
+        }
+        launch_gemm_h16(g, s);
     } else {                                // input conv 1 -> 128 (direct kernel, fp32 arithmetic): the f16 map and its statistics only
         if (launch_conv1ch_3x3(in.f, o.w1, o.b1, nullptr, B, o.cout, s, outh, (o.cout & 3) ? nullptr : outst)) { fail(DMAD_ERR_STATE, "input conv: %d output channels > 128", o.cout); return false; }
         if (o.cout & 3) outst = nullptr;

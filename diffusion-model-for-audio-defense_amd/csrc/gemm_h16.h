@@ -26,10 +26,15 @@ struct GemmH16Args {
     int relu;             // 1: max(., 0) after bias and residual (NaN stays NaN, like torch.relu) — ResNeXt's BN-folded convs
     int groups;           // 0/1 = dense; g > 1: grouped conv (resnext.py:36-37), M and K are PER GROUP: group z reads channels
                           //   [z K, (z+1) K) of X (pixel pitch ldx), weights A + z * taps * M * K, writes channels [z M, (z+1) M) (pitch ldc)
+    int up2;              // 1: X is the HALF-resolution map [B][H/2][W/2][ldx] and the conv reads its nearest-neighbour x2 upsampling
+                          //   (F.interpolate(scale_factor=2) + conv of the UNet's Upsample, unet.py:72-79) without materialising it.  Served by the
+                          //   slice-resident form only: ask gemm_h16_fuses_up2() first
 };
 
 // 0, or -1 for an argument block the kernel does not serve (nothing is launched; counted for gemm_h16_take_bad_shapes)
 int launch_gemm_h16(const GemmH16Args& a, hipStream_t s);
+// true if launch_gemm_h16 would serve this block WITH up2 = 1 (a: the block for the upsampled geometry, X = the half-resolution map)
+bool gemm_h16_fuses_up2(const GemmH16Args& a);
 int gemm_h16_take_bad_shapes();
 int gemm_h16_configure();     // per device, from dmad_create: dynamic-LDS attribute (0 or a hipError_t)
 

@@ -917,6 +917,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
     const size_t a_tap = (size_t)a.M * a.K * 2;
     const int W = a.W, hw = a.H * a.W, halo = W + 1;
     const int xpieces = (BN + 2 * halo + 7) >> 3;                    // 1-KiB pieces of a slice (41 at W = 32)
+    const int up_wsh = __builtin_ctz((unsigned)W), up_hwsh = __builtin_ctz((unsigned)hw);      // (up2: log2 of the upsampled map's width / pixel count)
     for (int i = tid; i < 64; i += 512) ((unsigned*)(smem + SR_ARING + (i >> 5) * SR_XB + SR_XROWS * 128))[i & 31] = 0u;      // the two zero rows
     // ---- weight cursor (K-tiles, 1.5 ahead of the compute cursor) ----------------------------------------------------------------
     long atile = ctile;
@@ -973,7 +974,10 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_sr_kernel(GemmH16Args a, int 
         const int z = wv + 8 * i;
         if (z < xpieces) {
             const unsigned n = (unsigned)((int)x_n0 + z * 8 + l8);           // (N * ldx < 2^31, launcher; a row before the tensor wraps to a huge value)
-            const h16_t* src = n < (unsigned)a.N ? x_src + n * (unsigned)x_ld + x_ko + xch : zrow;
+            unsigned src_px = n;
+            if (a.up2)                                                   // the pixel of the half-resolution map under upsampled pixel n (power-of-two maps: launcher)
+                src_px = ((n >> up_hwsh) << (up_hwsh - 2)) + ((((n >> up_wsh) & (unsigned)(a.H - 1)) >> 1) << (up_wsh - 1)) + ((n & (unsigned)(W - 1)) >> 1);
+            const h16_t* src = n < (unsigned)a.N ? x_src + src_px * (unsigned)x_ld + x_ko + xch : zrow;
             dma16v(src, x_lds + i * 8192);
         }
     };
@@ -1148,9 +1152,31 @@ int gemm_h16_configure() {
 
 int gemm_h16_take_bad_shapes() { const int n = g_bad; g_bad = 0; return n; }
 
+namespace {
+// does this block go to the slice-resident form?  (the routing of launch_gemm_h16, in one place)
+bool routes_to_sr(const GemmH16Args& a) {
+    static const bool pers_on = []() { const char* v = getenv("DMAD_H16_PERS"); return !(v && v[0] == '0'); }();
+    static const bool big_on = []() { const char* v = getenv("DMAD_H16_BIG"); return !(v && v[0] == '0'); }();
+    static const bool sr_on = []() { const char* v = getenv("DMAD_H16_SR"); return !(v && v[0] == '0'); }();
+    const bool two = a.X2 != nullptr, st16 = a.stats && a.stats_px == 16;
+    if (!(pers_on && big_on && sr_on) || a.groups > 1 || st16 || a.K > BIG_KMAX || a.H >= 32768 || a.W >= 32768) return false;
+    if (a.N * (long)a.ldx >= (1l << 31) || (two && a.N * (long)a.ldx2 >= (1l << 31)) || a.N * (long)a.ldc >= (1l << 31)) return false;
+    if (a.M % 256 || a.taps != 9 || a.stride > 1 || a.W > 32 || a.W < 1) return false;
+    const long nxp = (a.N + 255) / 256, tiles = nxp * (a.M / 256);
+    return tiles >= g_h16_cus && nxp < (1l << 31);
+}
+}  // namespace
+
+bool gemm_h16_fuses_up2(const GemmH16Args& a) {
+    const auto pow2 = [](long v) { return v > 0 && (v & (v - 1)) == 0; };
+    static const bool up2_on = []() { const char* v = getenv("DMAD_H16_UP2"); return !(v && v[0] == '0'); }();      // A/B switch
+    return up2_on && !a.X2 && a.H >= 2 && a.W >= 2 && pow2(a.W) && pow2((long)a.H * a.W) && routes_to_sr(a);
+}
+
 int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
     const bool two = a.X2 != nullptr;
     const int ng = a.groups > 1 ? a.groups : 1;
+    if (a.up2 && !gemm_h16_fuses_up2(a)) { ++g_bad; return -1; }        // only the slice-resident form reads through the upsampling
     if (ng > 1 && (two || (long)ng * a.K > a.ldx || (long)ng * a.M > a.ldc || ng > 65535)) { ++g_bad; return -1; }
     if ((a.taps != 9 && a.taps != 1) || (a.K % HK) || a.K < HK || (a.M % 128) || (a.ldc & 3) || a.N < 1 || (!a.C && !a.C16) ||
         (a.res && a.res16) || (a.ldx & 7) || (two && ((a.ksplit % HK) || a.ksplit <= 0 || a.ksplit >= a.K || (a.ldx2 & 7)))) {
