@@ -5,7 +5,8 @@ package (DiffWave, MelSpectrogramDB, VGG) or any callables the caller passes.
 
 `query(x, repeats)` is the batched entry of the gradient-free attack drivers (EOT / NES): every clip evaluated
 `repeats` times with fresh purification noise.  When the three stages are this package's HIP stages on one engine it is
-ONE C-ABI call (dmad_query_logits: repeat -> DDPM purify -> mel dB -> classifier -> arg-max); otherwise it loops over
+ONE C-ABI call — dmad_query_logits for defense_type 'wave' (repeat -> DDPM purify -> mel dB -> classifier -> arg-max),
+dmad_spec_query_logits for 'spec' (repeat -> mel dB -> spec-domain purifier -> classifier -> arg-max); otherwise it loops over
 forward()."""
 import torch
 
@@ -45,7 +46,7 @@ class AcousticSystem(torch.nn.Module):
         from dmad_hip.transforms import MelSpectrogramDB
         cls, tr, den = self.classifier, self.transform, self.defender
         eng = getattr(cls, 'engine', None) if 'engine' in getattr(cls, '__dict__', {}) else None
-        if eng is None or not eng.has_classifier or self.defense_type != 'wave':
+        if eng is None or not eng.has_classifier:
             return None, 0
         mel = isinstance(tr, MelSpectrogramDB) and tr.engine is eng
         if not mel:
@@ -54,6 +55,9 @@ class AcousticSystem(torch.nn.Module):
             return None, 0
         if not (defend == True and den is not None):                  # noqa: E712
             return eng, 0
+        if self.defense_type == 'spec':                               # sampler 3: the spec-domain chain (dmad_spec_query_logits)
+            from diffusion_models.improved_diffusion_ddpm import SpecPurifier
+            return (eng, 3) if (type(den) is SpecPurifier and den.engine is eng) else (None, 0)
         if type(den) is DiffWave and den.noise_source == 'device' and den.engine is eng and eng.has_wavenet:
             return eng, 1
         return None, 0
@@ -73,6 +77,12 @@ class AcousticSystem(torch.nn.Module):
                 den = self.defender
                 ts, c_a, c_b, c_eps, c_div, c_sig = den.purify_coefficients()
                 logits, dec = eng.query_logits(x, repeats, 1, ts, c_a, c_b, c_eps, c_div, c_sig, seed=den.seed, sample0=den._draws)
+                den._draws += repeats * B
+            elif sampler == 3:
+                from diffusion_models.Improved_Diffusion_Unconditional.improved_diffusion.sc09_spectrogram_dataset import MEL_LOWER_BOUND, MEL_UPPER_BOUND
+                den = self.defender
+                logits, dec = eng.spec_query_logits(x, repeats, *den.purifier.purify_coefficients(), MEL_LOWER_BOUND, MEL_UPPER_BOUND,
+                                                    seed=den.seed, sample0=den._draws)
                 den._draws += repeats * B
             else:
                 logits, dec = eng.query_logits(x, repeats, 0)

@@ -1303,6 +1303,7 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     e->tau2 = 1e-3f;                        // the same for the split-f16 tier (dmad_set_recheck_margin2)
     e->un_h16 = cfg->precision != DMAD_FP32;    // engines with a 16-bit side also get the UNet's f16 tier (once UNet weights are loaded)
     e->rx_h16 = cfg->precision != DMAD_FP32;    // ... and ResNeXt29's (once its weights are loaded)
+    if (const char* v = getenv("DMAD_RX_H16")) if (v[0] == '0') e->rx_h16 = false;      // A/B switch: ResNeXt29 on the fp32 matrix cores in every tier
     e->tau_spec = 0.5f;                     // spec-domain vote loop: measured logit-difference error of the f16 UNet chain x headroom (see dmad.h)
     const bool wn = cfg->with_wavenet != 0;
     if (e->bf16 && !wn_final_p_supported(cfg->num_res_layers)) {
@@ -1585,6 +1586,21 @@ int dmad_conv_h16(const uint16_t* x, const uint16_t* x2, int32_t ksplit, const u
     return 0;
 }
 
+int dmad_conv_h16_up2(const uint16_t* x_half, const uint16_t* w, const float* bias, const uint16_t* res16, int32_t B, int32_t H, int32_t M, int32_t K,
+                      float* out32, uint16_t* out16, float* stats, dmad_stream s) {
+    if (!x_half || !w || (!out32 && !out16)) return fail(DMAD_ERR_INVALID, "null argument");
+    if (B < 1 || H < 2 || (H & 1) || M < 1 || K < 1) return fail(DMAD_ERR_INVALID, "bad geometry");
+    if (int r = gemm_h16_configure()) return fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS, f16 conv GEMM) failed: %d", r);
+    GemmH16Args g{};
+    g.A = w; g.X = x_half; g.C = out32; g.C16 = out16; g.shift = bias; g.res16 = res16; g.M = M; g.K = K; g.taps = 9; g.ldc = M;
+    g.N = (long)B * H * H; g.H = H; g.W = H; g.ldx = K; g.stride = 1; g.up2 = 1;
+    if (stats) { g.stats = stats; g.stats_px = 64; }
+    if (!gemm_h16_fuses_up2(g)) return fail(DMAD_ERR_STATE, "this shape is not served by the form that fuses the upsampling (the caller materialises the x2 map)");
+    launch_gemm_h16(g, (hipStream_t)s);
+    LASTCHK();
+    return 0;
+}
+
 int dmad_conv_h16_stats(const uint16_t* x, const uint16_t* w, const float* bias, const uint16_t* res16, int32_t B, int32_t H, int32_t M, int32_t K,
                         int32_t taps, int32_t stride, uint16_t* out16, float* stats, dmad_stream s) {
     if (!x || !w || !out16 || !stats) return fail(DMAD_ERR_INVALID, "null argument");
@@ -1830,10 +1846,9 @@ struct SpecJob {
 // One batch of the spec-domain chain (include/dmad.h, dmad_spec_smooth_votes): rows are samples s0 + b, or idx[b] when an index
 // list is given (the recheck pass).  h16: -1 the mode's UNet tier, 0 exact fp32, 1 the 16-bit tier.  The purified dB spectrograms
 // land in sp, the logits in lg.
-int spec_chain(dmad_engine* e, const SpecJob& j, uint64_t s0, const long long* idx, int B, int h16, float* sp, float* lg, hipStream_t st) {
-    const int L = e->L;
-    if (idx) launch_mc_noise_scale_idx(j.clip, nullptr, j.sigma, 1.f, j.seed, 0, idx, e->xt, B, L, st);
-    else launch_mc_noise_scale(j.clip, nullptr, j.sigma, 1.f, j.seed, s0, e->xt, B, L, st);      // no wave denoiser: no sqrt(alpha_bar*) scale
+// the chain behind its noisy waveforms: e->xt [B][L] -> purified dB spectrograms sp, logits lg.  cls16: the classifier tier (vote loops' first
+// pass: the 16-bit tier where one is resident; every other caller: fp32)
+int spec_chain_from_xt(dmad_engine* e, const SpecJob& j, uint64_t s0, const long long* idx, int B, int h16, int cls16, float* sp, float* lg, hipStream_t st) {
     CHK(mel_db(e, e->xt, B, e->spec, st));
     launch_philox_normal(j.seed, s0, 0x5BECu, e->znoise, B, 1024, st, idx);
     float* x = e->x0;                                                                   // [B][32][32] chain state
@@ -1845,8 +1860,15 @@ int spec_chain(dmad_engine* e, const SpecJob& j, uint64_t s0, const long long* i
         launch_unet_p_sample(x, e->un_eps, sig != 0.f ? e->znoise : nullptr, j.c_a[t], j.c_b[t], j.c_1[t], j.c_2[t], sig, x, nullptr, (long)B * 1024, st);
     }
     launch_spec_unstandardize(x, j.mel_lo, j.mel_hi, sp, (long)B * 1024, st);
-    CHK(classify(e, sp, B, lg, st, h16 == 0 ? 0 : cls_tier(e)));
+    CHK(classify(e, sp, B, lg, st, cls16));
     return 0;
+}
+
+int spec_chain(dmad_engine* e, const SpecJob& j, uint64_t s0, const long long* idx, int B, int h16, float* sp, float* lg, hipStream_t st) {
+    const int L = e->L;
+    if (idx) launch_mc_noise_scale_idx(j.clip, nullptr, j.sigma, 1.f, j.seed, 0, idx, e->xt, B, L, st);
+    else launch_mc_noise_scale(j.clip, nullptr, j.sigma, 1.f, j.seed, s0, e->xt, B, L, st);      // no wave denoiser: no sqrt(alpha_bar*) scale
+    return spec_chain_from_xt(e, j, s0, idx, B, h16, h16 == 0 ? 0 : cls_tier(e), sp, lg, st);
 }
 
 }  // namespace
@@ -1967,6 +1989,30 @@ int dmad_query_logits(dmad_engine* e, const float* x, int32_t B, int32_t repeats
         }
         CHK(mel_db(e, pur, nb, e->spec, st));
         CHK(classify(e, e->spec, nb, logits + r0 * C, st));       // the fp32 classifier, like AcousticSystem.forward's own call
+        if (decisions) launch_vote(logits + r0 * C, nb, C, nullptr, decisions + r0, st);
+    }
+    LASTCHK();
+    return 0;
+}
+
+int dmad_spec_query_logits(dmad_engine* e, const float* x, int32_t B, int32_t repeats, int32_t t_star, float q_a, float q_b, const float* c_a,
+                           const float* c_b, const float* c_1, const float* c_2, const float* c_sig, float mel_lo, float mel_hi, uint64_t seed,
+                           uint64_t sample0, float* logits, int32_t* decisions, dmad_stream s) {
+    if (!e || !x || !logits || !c_a || !c_b || !c_1 || !c_2 || !c_sig) return fail(DMAD_ERR_INVALID, "null argument");
+    if (B < 1 || repeats < 1) return fail(DMAD_ERR_INVALID, "B and repeats must be >= 1");
+    if (!e->cfg.with_classifier || !e->cls_final) return fail(DMAD_ERR_STATE, "the spec-domain query needs the mel front-end and a finalised classifier");
+    if (!e->un_final) return fail(DMAD_ERR_STATE, "UNet weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
+    if (t_star < 0 || !(mel_hi > mel_lo)) return fail(DMAD_ERR_INVALID, "bad argument");
+    hipStream_t st = (hipStream_t)s;
+    const int L = e->L, C = e->cfg.num_classes;
+    const SpecJob job{nullptr, 0.f, t_star, q_a, q_b, c_a, c_b, c_1, c_2, c_sig, mel_lo, mel_hi, seed};
+    const long rows = (long)B * repeats;
+    for (long r0 = 0; r0 < rows; r0 += e->maxB) {
+        const int nb = (int)(rows - r0 < e->maxB ? rows - r0 : e->maxB);
+        launch_repeat_rows(x, e->xt, B, r0, nb, L, st);
+        // the UNet tier of the map-returning surfaces (exact fp32 unless the engine is in its fast mode), the fp32 classifier: like
+        // dmad_query_logits, a query hands logits back and has no recheck
+        CHK(spec_chain_from_xt(e, job, sample0 + (uint64_t)r0, nullptr, nb, -1, 0, e->spec, logits + r0 * C, st));
         if (decisions) launch_vote(logits + r0 * C, nb, C, nullptr, decisions + r0, st);
     }
     LASTCHK();

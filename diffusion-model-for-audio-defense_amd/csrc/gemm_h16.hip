@@ -1189,21 +1189,21 @@ int launch_gemm_h16(const GemmH16Args& a, hipStream_t s) {
     // 384-row kernel.  DMAD_H16_PERS=0 / DMAD_H16_SR=0 / DMAD_H16_BIG=0 switch a form off for A/B runs.
     static const bool big_on = []() { const char* v = getenv("DMAD_H16_BIG"); return !(v && v[0] == '0'); }();
     static const bool pers_on = []() { const char* v = getenv("DMAD_H16_PERS"); return !(v && v[0] == '0'); }();
-    static const bool sr_on = []() { const char* v = getenv("DMAD_H16_SR"); return !(v && v[0] == '0'); }();
     const bool st16 = a.stats && a.stats_px == 16;           // 16-pixel statistics blocks: the 384-row kernel only
     if (a.stats && a.stats_px != 0 && a.stats_px != 16 && a.stats_px != 64) { ++g_bad; return -1; }
+    const bool wide = a.C16 && !a.C && !a.res && !(a.ldc & 7);
+    if (routes_to_sr(a)) {                                    // (the one predicate gemm_h16_fuses_up2 asks, too)
+        const int nxp = (int)((a.N + 255) / 256);
+        if (wide) hipLaunchKernelGGL((gemm_h16_sr_kernel<true>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, nxp);
+        else hipLaunchKernelGGL((gemm_h16_sr_kernel<false>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, nxp);
+        return 0;
+    }
     if (pers_on && big_on && ng == 1 && (!two || a.N * (long)a.ldx2 < (1l << 31)) && !st16 && a.K <= BIG_KMAX && a.H < 32768 && a.W < 32768 &&
         a.N * (long)a.ldx < (1l << 31)) {
         const int bm = a.M % 256 == 0 ? 256 : (a.M == 128 ? 128 : 0);
         if (bm) {
             const long nxp = (a.N + (bm == 256 ? 255 : 511)) / (bm == 256 ? 256 : 512), tiles = nxp * (a.M / bm);
             if (tiles >= g_h16_cus && nxp < (1l << 31) && a.N * (long)a.ldc < (1l << 31)) {
-                const bool wide = a.C16 && !a.C && !a.res && !(a.ldc & 7);
-                if (sr_on && bm == 256 && a.taps == 9 && a.stride <= 1 && a.W <= 32 && a.W >= 1) {
-                    if (wide) hipLaunchKernelGGL((gemm_h16_sr_kernel<true>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, (int)nxp);
-                    else hipLaunchKernelGGL((gemm_h16_sr_kernel<false>), dim3(g_h16_cus), dim3(512), SR_LDS, s, a, (int)nxp);
-                    return 0;
-                }
                 if (bm == 256 && wide) hipLaunchKernelGGL((gemm_h16_pp_kernel<256, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
                 else if (bm == 256) hipLaunchKernelGGL((gemm_h16_pp_kernel<256, false>), dim3(g_h16_cus), dim3(512), BIG_LDS_256, s, a, (int)nxp);
                 else if (wide) hipLaunchKernelGGL((gemm_h16_pp_kernel<128, true>), dim3(g_h16_cus), dim3(512), BIG_LDS_128, s, a, (int)nxp);

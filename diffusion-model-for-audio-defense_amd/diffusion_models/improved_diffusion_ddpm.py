@@ -66,6 +66,37 @@ class SpecDefense(torch.nn.Module):
         return self.purifier(melspec_standardize(self.mel(x)))
 
 
+class SpecPurifier(torch.nn.Module):
+    """The spec-domain `defender` of AcousticSystem(classifier, transform, defender, defense_type='spec') (acoustic_system.py:40-49):
+    mel-dB spectrograms [B,1,32,32] in, purified mel-dB spectrograms out — standardise, q_sample(t*), the t* + 1 p_sample steps, map
+    back.  Every draw of row b is Philox-keyed (seed, draws so far + b) with the streams of dmad_spec_smooth_votes (include/dmad.h), so
+    `AcousticSystem.query` can run the same rows as ONE engine call (dmad_spec_query_logits) and a row's result does not depend on how
+    the rows were batched."""
+    noise_source = 'device'
+
+    def __init__(self, purifier: ImprovedDiffusion, seed: int = 0):
+        super().__init__()
+        self.purifier, self.seed, self._draws = purifier, seed, 0
+
+    @property
+    def engine(self):
+        return getattr(self.purifier.model, 'engine', None)
+
+    @torch.no_grad()
+    def forward(self, spec_db):
+        pur, eng = self.purifier, self.engine
+        if eng is None:
+            raise RuntimeError('SpecPurifier needs a UNet bound to a dmad engine (create_improved_diffusion(..., engine=...))')
+        B, ts, s0 = spec_db.shape[0], pur.reverse_timestep, self._draws
+        x0 = melspec_standardize(spec_db.float())
+        zq = eng.philox_normal(self.seed, s0, 0x5BEC, B)[:, :1024].reshape(B, 1, 32, 32)
+        x = pur.diffusion.q_sample(x0, torch.full((B,), ts, dtype=torch.long, device=x0.device), noise=zq)
+        for t in range(ts, -1, -1):
+            x = pur.diffusion.p_sample(pur.model, x, torch.full((B,), t), seed=self.seed, sample0=s0)['sample']
+        self._draws += B
+        return melspec_inv_standardize(x)
+
+
 def create_improved_diffusion(model_path, reverse_timestep=25, state_dict=None, engine=None):
     """reference l.64-93: image_size 32, 128 channels, 3 ResBlocks, fixed sigma, 1000 linear steps."""
     args = model_and_diffusion_defaults()

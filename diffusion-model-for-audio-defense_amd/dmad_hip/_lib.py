@@ -52,6 +52,7 @@ _SIGNATURES = {
     'dmad_classify_tier': (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     'dmad_conv_h16': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_int32, _P, _P, _P]),
+    'dmad_conv_h16_up2': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     'dmad_conv_h16_stats': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     'dmad_groupnorm16_apply': (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     'dmad_smooth_votes': (C.c_int, [_P, _P, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_int64, C.c_int32,
@@ -67,6 +68,8 @@ _SIGNATURES = {
     'dmad_debug_rounding': (C.c_int, [_P, C.POINTER(C.c_int32)]),
     'dmad_query_logits': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P,
                                     C.c_uint64, C.c_uint64, _P, _P, _P]),
+    'dmad_spec_query_logits': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, _P, C.c_float, C.c_float,
+                                         C.c_uint64, C.c_uint64, _P, _P, _P]),
     'dmad_spec_smooth_votes': (C.c_int, [_P, _P, C.c_float, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, _P, C.c_float, C.c_float,
                                          C.c_int64, C.c_int32, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
     'dmad_spec_eval_samples': (C.c_int, [_P, _P, C.c_float, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, _P, C.c_float, C.c_float,

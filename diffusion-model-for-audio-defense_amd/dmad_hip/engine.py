@@ -643,6 +643,20 @@ class Engine:
                                          arrs[0], arrs[1], arrs[2], int(seed), int(sample0), _ptr(logits), _ptr(dec), _stream()))
         return logits, dec
 
+    def spec_query_logits(self, x: torch.Tensor, repeats: int, t_star: int, q_a: float, q_b: float, c_a, c_b, c_1, c_2, c_sig,
+                          mel_lo: float, mel_hi: float, seed: int = 0, sample0: int = 0):
+        """dmad_spec_query_logits: x [B,1,L] -> (logits [repeats*B, C], decisions int32 [repeats*B]) through the spec-domain chain
+        (mel dB -> standardise -> q_sample(t*) -> p_sample steps -> un-standardise -> classifier); row r*B+b is clip b."""
+        xw = self._wave(x)
+        B = xw.shape[0]
+        logits = torch.empty((repeats * B, self.num_classes), device=xw.device, dtype=torch.float32)
+        dec = torch.empty((repeats * B,), device=xw.device, dtype=torch.int32)
+        arrs = [(C.c_float * (t_star + 1))(*[float(v) for v in a]) for a in (c_a, c_b, c_1, c_2, c_sig)]
+        check(self.lib.dmad_spec_query_logits(self._h, _ptr(xw), B, int(repeats), int(t_star), float(q_a), float(q_b), arrs[0], arrs[1], arrs[2],
+                                              arrs[3], arrs[4], float(mel_lo), float(mel_hi), int(seed), int(sample0), _ptr(logits), _ptr(dec),
+                                              _stream()))
+        return logits, dec
+
     def philox_raw(self, seed: int, sample: int, stream: int, nblocks: int) -> torch.Tensor:
         out = torch.empty(nblocks * 4, dtype=torch.int32, device=self.device)
         check(self.lib.dmad_philox_raw(self._h, int(seed), int(sample), int(stream), int(nblocks), _ptr(out), _stream()))
@@ -708,6 +722,28 @@ def conv_h16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = No
     check(lib.dmad_conv_h16(_ptr(x), _ptr(x2), int(ksplit), _ptr(w), _ptr(bias), _ptr(res), B, H, M, K, taps, int(stride), int(groups),
                             1 if relu else 0, _ptr(out32), _ptr(out16), _stream()))
     return out32, out16
+
+
+def conv_h16_up2(x_half: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, want_stats: bool = False):
+    """dmad_conv_h16_up2 — nearest x2 upsampling + 3x3 conv in one launch (test hook of GemmH16Args::up2).  x_half: f16 NHWC
+    [B,H/2,H/2,K]; w: f16 [1,9,M,K]; res: optional f16 [B,H,H,M].  Returns (out32, out16, stats | None); raises DmadError when the shape
+    is not served by the fusing form."""
+    lib = _lib.load()
+    assert x_half.is_cuda and x_half.dtype == torch.float16 and w.dtype == torch.float16 and w.shape[0] == 1 and w.shape[1] == 9
+    x_half, w = x_half.contiguous(), w.contiguous()
+    B, Hh, _, K = x_half.shape
+    M, H = w.shape[2], 2 * Hh
+    assert w.shape[3] == K
+    out32 = torch.empty((B, H, H, M), device=x_half.device, dtype=torch.float32)
+    out16 = torch.empty((B, H, H, M), device=x_half.device, dtype=torch.float16)
+    stats = torch.zeros((B * H * H // 64, M // 4, 2), device=x_half.device, dtype=torch.float32) if want_stats else None
+    if bias is not None:
+        bias = bias.detach().contiguous().float()
+    if res is not None:
+        assert res.dtype == torch.float16 and tuple(res.shape) == (B, H, H, M)
+        res = res.contiguous()
+    check(lib.dmad_conv_h16_up2(_ptr(x_half), _ptr(w), _ptr(bias), _ptr(res), B, H, M, K, _ptr(out32), _ptr(out16), _ptr(stats), _stream()))
+    return out32, out16, stats
 
 
 def conv_h16_stats(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, res: Optional[torch.Tensor] = None):

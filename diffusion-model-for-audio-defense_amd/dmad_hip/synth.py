@@ -111,13 +111,20 @@ def vgg19_bn_state_dict(seed: int = 4321, num_classes: int = 10, in_channels: in
         sd['classifier.%d.weight' % i] = _f32(rng.standard_normal((o, k)) * np.sqrt(2.0 / k))
         sd['classifier.%d.bias' % i] = _f32(rng.standard_normal(o) * 0.1)
     if calibrated and seed == 4321:
-        import os
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'vgg19_bn_calib_seed4321.npz')
-        with np.load(path) as z:
-            for k in z.files:
-                assert sd[k].shape == z[k].shape
-                sd[k] = _f32(z[k])
+        # calibrated == 'c5': the statistics measured on the spectrograms the SPEC-domain chain (BASELINE C5) hands the classifier
+        _load_calibration(sd, 'vgg19_bn_calib_c5_seed4321.npz' if calibrated == 'c5' else 'vgg19_bn_calib_seed4321.npz')
     return sd
+
+
+def _load_calibration(sd, name):
+    """Overwrites entries of `sd` with the committed calibration data dmad_hip/data/<name> (BatchNorm running statistics, and for
+    ResNeXt29 the centred / scaled head): tests/golden/make_vgg_calib.py, tests/golden/make_classifier_calib.py."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', name)
+    with np.load(path) as z:
+        for k in z.files:
+            assert sd[k].shape == z[k].shape, k
+            sd[k] = _f32(z[k])
 
 
 def synthetic_clip(seed: int = 0, length: int = 16000) -> np.ndarray:
@@ -137,10 +144,16 @@ def synthetic_clip(seed: int = 0, length: int = 16000) -> np.ndarray:
     return _f32(x[None, :])
 
 
-def resnext29_state_dict(seed: int = 2929, num_classes: int = 10, in_channels: int = 1):
+def resnext29_state_dict(seed: int = 2929, num_classes: int = 10, in_channels: int = 1, calibrated: bool = True):
     """fp32 numpy state dict for models/resnext.py CifarResNeXt(nlabels=10, cardinality=8, depth=29, base_width=64,
     widen_factor=4, in_channels=1): kaiming (fan_out) conv weights, BatchNorm affine/statistics drawn so that the
-    29-layer stack stays O(1) on dB-scaled mel images (first BN sized for inputs around -20 dB +- 12, like the VGG's)."""
+    29-layer stack stays O(1) on dB-scaled mel images (first BN sized for inputs around -20 dB +- 12, like the VGG's).
+
+    With `calibrated` (and seed 2929) the BatchNorm running statistics and the linear head come from the committed data file
+    dmad_hip/data/resnext29_calib_seed2929.npz (one calibration pass over mel spectrograms of purified noisy synthetic clips,
+    head centred on the calibration set and scaled to the VGG headline's logit spread: tests/golden/make_classifier_calib.py), so
+    that the Monte Carlo votes spread over several classes with margins of order one, like a trained checkpoint's — the random
+    statistics alone vote one class on every sample, which exercises no recheck tier."""
     rng = np.random.default_rng(seed)
     sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
 
@@ -179,6 +192,8 @@ def resnext29_state_dict(seed: int = 2929, num_classes: int = 10, in_channels: i
                 bn(p + 'shortcut.shortcut_bn', cout, gamma=(0.5, 0.9), var=rng.uniform(0.5, 1.5, size=cout) * (2.0 * cin / cout))
     sd['classifier.weight'] = _f32(rng.standard_normal((num_classes, 1024)) * np.sqrt(2.0 / 1024))
     sd['classifier.bias'] = _f32(rng.standard_normal(num_classes) * 0.1)
+    if calibrated and seed == 2929 and num_classes == 10 and in_channels == 1:
+        _load_calibration(sd, 'resnext29_calib_seed2929.npz')
     return sd
 
 

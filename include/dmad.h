@@ -287,6 +287,17 @@ int dmad_query_logits(dmad_engine* e, const float* x, int32_t B, int32_t repeats
                       const float* c_eps, const float* c_div, const float* c_sig, uint64_t seed, uint64_t sample0, float* logits,
                       int32_t* decisions, dmad_stream s);
 
+/* The same batched query for AcousticSystem(defense_type = 'spec') (acoustic_system.py:40-49: transform, THEN the defender on the
+ * spectrogram): row i = r * B + b is clip x[b] through  mel dB -> standardise -> q_sample(t_star) -> t_star + 1 p_sample steps ->
+ * un-standardise -> classifier  — the chain of dmad_spec_smooth_votes without the smoothing noise, every draw of row i Philox-keyed
+ * (seed, sample0 + i) (q_sample: stream 0x5BEC, p_sample at t: stream 0x0E70 + t), so a row's logits do not depend on how the rows are
+ * batched.  The UNet runs the tier of the map-returning surfaces (exact fp32 unless the engine is in DMAD_MODE_FAST), the classifier the
+ * fp32 one: a query hands logits back and has no recheck.  Coefficients as for dmad_spec_smooth_votes (HOST arrays of t_star + 1
+ * entries).  logits: [repeats * B][num_classes]; decisions: optional int32 [repeats * B]. */
+int dmad_spec_query_logits(dmad_engine* e, const float* x, int32_t B, int32_t repeats, int32_t t_star, float q_a, float q_b, const float* c_a,
+                           const float* c_b, const float* c_1, const float* c_2, const float* c_sig, float mel_lo, float mel_hi, uint64_t seed,
+                           uint64_t sample0, float* logits, int32_t* decisions, dmad_stream s);
+
 /* counts[argmax_c logits[b][c]] += 1 (first maximum wins) — certified_robust.py:59-65. */
 int dmad_vote(dmad_engine* e, const float* logits, int32_t B, int64_t* counts, dmad_stream s);
 
@@ -319,6 +330,12 @@ int dmad_profile_read_final(dmad_engine* e, float* total_ms, int32_t* launches);
 int dmad_conv_h16(const uint16_t* x, const uint16_t* x2, int32_t ksplit, const uint16_t* w, const float* bias, const uint16_t* res16,
                   int32_t B, int32_t H, int32_t M, int32_t K, int32_t taps, int32_t stride, int32_t groups, int32_t relu,
                   float* out32, uint16_t* out16, dmad_stream s);
+/* The UNet's Upsample (F.interpolate(scale_factor=2, mode="nearest") + 3x3 conv, unet.py:72-79) as ONE launch of the family's
+ * slice-resident form: x_half is the HALF-resolution f16 map [B][H/2][H/2][K], the conv output is [B][H][H][M] (H even; stats: optional
+ * GroupNorm statistics slab as below).  DMAD_ERR_STATE when the shape is not served by that form (fewer tiles than CUs, M % 256, maps wider
+ * than 32 pixels ...: the product then materialises the x2 map and calls the plain conv).  Test hook like dmad_conv_h16. */
+int dmad_conv_h16_up2(const uint16_t* x_half, const uint16_t* w, const float* bias, const uint16_t* res16, int32_t B, int32_t H, int32_t M, int32_t K,
+                      float* out32, uint16_t* out16, float* stats, dmad_stream s);
 /* The same with the consumer's GroupNorm statistics accumulated in the epilogue: stats [N / blk][groups * M / 4][2] fp32 = (sum, sum of
  * squares) of the f16-rounded outputs per block of blk = 64 pixels (16 when Ho * Ho == 16) and 4-channel quad — and the one-pass
  * GroupNorm32 + SiLU (+ scale-shift) that consumes them (nn.py:15-17, unet.py:186-199 on the 16-bit tier):

@@ -375,6 +375,41 @@ def test_robust_certificate_m5_generic_path(engines, golden_dir, tmp_path):
     assert counts.tolist() == z['m5_counts'].tolist()
 
 
+def test_config1_composite_m5_behind_ddpm_purifier(engines, golden_dir):
+    """BASELINE C1 as ONE composition: AcousticSystem(M5 (bundled k=160 weights), transform=None, defender=DiffWave(t*=3)) — the
+    HIP DDPM purifier on the reference's CPU noise stream in front of the caller's torch classifier — against the logits /
+    purified waveform of the imported reference's own AcousticSystem on the same seed (fixture c1_composite.npz,
+    tests/golden/make_golden_c1.py; reference acoustic_system.py:27-51, diffwave_ddpm.py:36-104, M5Net.py:21-38); also the
+    undefended call and the int16-range rescale branch."""
+    import M5Net
+    from acoustic_system import AcousticSystem
+    from diffusion_models.diffwave_ddpm import DiffWave, WaveNetHIP
+    from diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    z = G(golden_dir, 'c1_composite.npz')
+    m5 = M5Net.M5(n_input=1, first_kernel_size=160, n_output=10, stride=16, n_channel=32)
+    m5.load_state_dict({k: torch.from_numpy(v) for k, v in G(golden_dir, 'm5_k160_state.npz').items()})
+    m5 = m5.float().eval().cuda()
+    x = torch.from_numpy(z['x']).cuda()
+    for name, tol_w, tol_l in (('fp32', 5e-5, 2e-3), ('bf16', BF16_MAX_TOL, 0.5)):
+        den = DiffWave(WaveNetHIP(engines[name]), calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG), reverse_timestep=int(z['t_star']),
+                       noise_source='torch_cpu')
+        system = AcousticSystem(classifier=m5, transform=None, defender=den, defense_type='wave').eval()
+        with torch.no_grad():
+            torch.manual_seed(int(z['seed']))
+            pur = den(x)
+            torch.manual_seed(int(z['seed']))
+            logp = system(x)
+            plain = system(x, defend=False)
+            torch.manual_seed(int(z['seed']))
+            logp_i = system(torch.from_numpy(z['x_int16']).cuda())
+        assert relmax(pur.cpu().numpy(), z['purified']) < tol_w, name
+        assert logp.shape == (1, 10) and float(np.abs(logp.cpu().numpy() - z['logp']).max()) < tol_l, name
+        assert float(np.abs(plain.cpu().numpy() - z['logp_undefended']).max()) < 1e-4
+        assert float(np.abs(logp_i.cpu().numpy() - z['logp_int16']).max()) < max(tol_l, 5e-3), name
+        if name == 'fp32':
+            assert logp.argmax(1).tolist() == z['logp'].argmax(1).tolist()
+
+
 def test_certify_end_to_end_fused(engines, golden_dir):
     """certify() through the fused HIP loop with the reference's CPU noise -> same (y_pred, radius)."""
     z = G(golden_dir, 'smooth_predict.npz')
@@ -780,6 +815,41 @@ def test_gemm_h16_family_vs_torch_conv(case):
     assert worst16 < 2e-2, worst16
     assert torch.equal(o16, o32.half())                     # the f16 twin IS the rounded fp32 output
 
+
+
+@pytest.mark.parametrize('case', [(64, 32, 256, 256, False), (260, 16, 256, 256, True), (1027, 8, 256, 512, False), (4100, 4, 128, 256, True)],
+                         ids=lambda c: 'B%d_H%d_%dto%d_r%d' % tuple(int(v) for v in c))
+def test_gemm_h16_fused_upsample_vs_torch(case):
+    """GemmH16Args::up2 — the UNet's Upsample (F.interpolate(scale_factor=2, mode='nearest') + 3x3 conv, improved_diffusion/unet.py:72-79)
+    read through the upsampling by the slice-resident form — through its own hook dmad_conv_h16_up2, against torch's interpolate +
+    fp32 conv of the same f16-rounded operands: output maps 32, 16, 8 and 4 pixels wide (a tile = 1/4, 1, 4, 16 images), an N tail,
+    with and without residual; the result equals the plain conv of the materialised x2 map bit for bit (the family's K order), and a
+    shape the form does not serve is refused, not mis-served."""
+    from dmad_hip import engine as E
+    from dmad_hip._lib import DmadError
+    B, H, cin, cout, with_res = case
+    g = torch.Generator().manual_seed(4000 + B + H)
+    xh = (torch.rand(B, H // 2, H // 2, cin, generator=g) * 2 - 1).half().cuda()
+    w = ((torch.rand(1, 9, cout, cin, generator=g) * 2 - 1) * 0.1).half().cuda()
+    bias = (torch.rand(cout, generator=g) * 2 - 1).cuda()
+    res = (torch.rand(B, H, H, cout, generator=g) * 2 - 1).half().cuda() if with_res else None
+    o32, o16, st = E.conv_h16_up2(xh, w, bias, res=res, want_stats=True)
+    up = xh.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)               # nearest x2, NHWC
+    worst = 0.0
+    for b0 in range(0, B, 256):
+        sl = slice(b0, min(B, b0 + 256))
+        xr = torch.nn.functional.interpolate(xh[sl].float().permute(0, 3, 1, 2), scale_factor=2, mode='nearest').permute(0, 2, 3, 1)
+        assert torch.equal(xr.half(), up[sl])
+        ref = _conv_ref(xr, None, w, bias, None if res is None else res[sl], 1, 1, False)
+        worst = max(worst, float((o32[sl] - ref).abs().max()))
+    assert worst < 2e-3, worst
+    assert torch.equal(o16, o32.half())
+    p32, p16 = E.conv_h16(up, w, bias, res=res)                                    # the materialised map through the plain conv
+    assert torch.equal(p32, o32) and torch.equal(p16, o16)
+    blocks = o16.float().reshape(B * H * H // 64, 64, cout // 4, 4)               # statistics of the f16-rounded outputs, per 64-pixel block
+    assert float((st[..., 0] - blocks.sum((1, 3))).abs().max()) < 2e-2 and float((st[..., 1] - (blocks ** 2).sum((1, 3))).abs().max()) < 0.5
+    with pytest.raises(DmadError):
+        E.conv_h16_up2(xh[:1], w, bias)                                            # one image: fewer tiles than CUs, not the fusing form
 
 
 @pytest.mark.parametrize('case', [(3, 32, 128, 128, 0), (130, 32, 128, 128, 0), (2, 16, 256, 256, 128), (260, 16, 256, 256, 0), (5, 8, 128, 384, 256), (7, 4, 256, 256, 0),
@@ -1302,6 +1372,52 @@ def test_query_logits_is_one_call_and_row_keyed(engines):
     from dmad_hip._lib import DmadError
     with pytest.raises(DmadError):
         eng.query_logits(x, 2, sampler=1, t_star=0, c_eps=[], c_div=[], c_sig=[])
+
+
+def test_spec_defense_query_is_one_call_and_row_keyed():
+    """AcousticSystem(defense_type='spec') (acoustic_system.py:40-49: transform, then the defender on the spectrogram) behind the
+    EOT / NES query path: with the HIP mel front-end, a SpecPurifier on the engine's UNet and the HIP classifier, `query` is ONE
+    dmad_spec_query_logits call whose row (r, b) carries the key draws + r*B + b — equal to the same rows through
+    AcousticSystem.forward (mel -> SpecPurifier.forward -> classifier, composed from the separately pinned q_sample / p_sample /
+    classifier surfaces), for any chunking; a defender the engine does not know falls back to the forward loop."""
+    from acoustic_system import AcousticSystem
+    from diffusion_models.improved_diffusion_ddpm import SpecPurifier, create_improved_diffusion
+    from dmad_hip import engine as E
+    from dmad_hip.transforms import MelSpectrogramDB
+    eng = E.Engine(max_batch=4, precision=E.FP32, with_wavenet=False)
+    pur = create_improved_diffusion(None, reverse_timestep=3, state_dict=synth.unet_state_dict(31), engine=eng)
+    net = synth_vgg(calibrated='c5').bind_engine(eng)
+    mel = MelSpectrogramDB(eng)
+    den = SpecPurifier(pur, seed=23)
+    model = AcousticSystem(classifier=net, transform=mel, defender=den, defense_type='spec')
+    assert model._engine_chain(True) == (eng, 3) and model._engine_chain(False) == (eng, 0)
+    x = torch.from_numpy(np.stack([synth.synthetic_clip(1), synth.synthetic_clip(7), synth.synthetic_clip(9)])).cuda()
+    den._draws = 40
+    logits, dec = model.query(x, repeats=3)                      # 9 rows > max_batch 4: chunked inside the call
+    assert logits.shape == (3, 3, 10) and dec.shape == (3, 3) and den._draws == 49
+    assert torch.equal(dec, logits.argmax(-1)) and bool(torch.isfinite(logits).all())
+    den._draws = 40
+    ref = torch.cat([model(x.repeat(3, 1, 1)[i:i + 4]) for i in (0, 4, 8)]).view(3, 3, 10)      # the reference's call pattern, in engine-sized calls
+    assert float((ref - logits).abs().max()) < 2e-3 and ref.argmax(-1).tolist() == dec.tolist()
+    den._draws = 40 + 3 * 1 + 2
+    assert float((model(x[2:3]) - logits[1, 2:3]).abs().max()) < 2e-3          # row (1, 2) alone, by its key
+    den._draws = 40
+    again, _ = model.query(x[:2], repeats=2)                     # other B, same keys for rows 0..3 of the key range -> other clips: only shape / keying
+    assert again.shape == (2, 2, 10) and den._draws == 44
+    assert torch.equal(again[0, 0], logits[0, 0])                # row 0 = clip 0 with key 40 in both calls
+    plain, _ = model.query(x, repeats=2, defend=False)
+    assert torch.equal(plain[0], plain[1]) and torch.equal(plain[0], net(mel(x)))
+    # a spec defender that is not the engine's chain: the forward loop, same result type
+    other = AcousticSystem(classifier=net, transform=mel, defender=torch.nn.Identity(), defense_type='spec')
+    assert other._engine_chain(True) == (None, 0)
+    lo, do = other.query(x, repeats=2)
+    assert lo.shape == (2, 3, 10) and torch.equal(lo[0], plain[0]) and torch.equal(do, lo.argmax(-1))
+    from dmad_hip._lib import DmadError
+    bare = E.Engine(max_batch=2, precision=E.FP32, with_wavenet=False)
+    with pytest.raises(DmadError):
+        bare.spec_query_logits(x[:1], 1, *pur.purify_coefficients(), -100.0, 38.22)      # no UNet / classifier loaded
+    bare.close()
+    eng.close()
 
 
 def test_randsmooth_with_device_noise_and_second_classifier(engines):

@@ -128,6 +128,32 @@ def test_classifiers(golden_dir):
     np.testing.assert_allclose(got, z['vgg_logits'], rtol=1e-4, atol=1e-4)
 
 
+def test_config1_composite_acoustic_system_m5_ddpm(golden_dir):
+    """BASELINE C1 as one composition: AcousticSystem(M5, transform=None, defender=DiffWave(t*=3)) of the imported reference on
+    its own CPU noise stream (fixture c1_composite.npz, tests/golden/make_golden_c1.py) against the oracle's restatement of the
+    same chain (acoustic_system.py:27-51, diffwave_ddpm.py:36-104, M5Net.py:21-38), including the int16-range rescale branch."""
+    z = _load(golden_dir, 'c1_composite.npz')
+    w = orc.folded_weights(synth.wavenet_state_dict(1234))
+    hp = orc.calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    den = orc.DiffWaveOracle(w, hp, reverse_timestep=int(z['t_star']))
+    m5 = dict(_load(golden_dir, 'm5_k160_state.npz'))
+
+    def system(x, defend=True):
+        if 0.9 * x.max() > 1 and 0.9 * x.min() < -1:
+            x = x / (2 ** 15)
+        return orc.m5_forward(m5, den.forward(x) if defend else x)
+    with torch.no_grad():
+        torch.manual_seed(int(z['seed']))
+        pur = den.forward(torch.from_numpy(z['x']))
+        np.testing.assert_allclose(pur.numpy(), z['purified'], rtol=0, atol=2e-5 * float(np.abs(z['purified']).max()))
+        torch.manual_seed(int(z['seed']))
+        np.testing.assert_allclose(system(torch.from_numpy(z['x'])).numpy(), z['logp'], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(system(torch.from_numpy(z['x']), False).numpy(), z['logp_undefended'], rtol=1e-4, atol=1e-4)
+        torch.manual_seed(int(z['seed']))
+        np.testing.assert_allclose(system(torch.from_numpy(z['x_int16'])).numpy(), z['logp_int16'], rtol=1e-4, atol=1e-4)
+    assert not np.allclose(z['logp'], z['logp_undefended'], atol=1e-2)          # the defender really acts
+
+
 def test_clopper_pearson_known_answers(golden_dir):
     from scipy.stats import norm
     ka = json.load(open(os.path.join(golden_dir, 'clopper_pearson.json')))

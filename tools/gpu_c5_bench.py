@@ -19,7 +19,7 @@ N, TSTAR, B = int(os.environ.get('N', 10000)), int(os.environ.get('TSTAR', 25)),
 MODE = os.environ.get('MODE', 'exact')
 eng = E.Engine(max_batch=B, precision=E.EXACT, recheck_batch=0, with_wavenet=False)
 eng.set_mode({'exact': E.MODE_EXACT_VOTES, 'fast': E.MODE_FAST, 'fp32': E.MODE_FP32}[MODE])
-eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321))
+eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321, calibrated='c5'))
 pur = create_improved_diffusion(None, reverse_timestep=TSTAR, state_dict=synth.unet_state_dict(31), engine=eng)
 ts, q_a, q_b, c_a, c_b, c_1, c_2, c_sig = pur.purify_coefficients()
 clip = torch.from_numpy(synth.synthetic_clip(0)).cuda()

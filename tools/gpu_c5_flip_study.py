@@ -23,12 +23,12 @@ N = int(os.environ.get('N', 2048))
 CLIPS = [int(c) for c in os.environ.get('CLIPS', '0,1,2').split(',')]
 SIGMAS = [float(s) for s in os.environ.get('SIGMAS', '0.5').split(',')]
 T = int(os.environ.get('T', 25))
-BATCH = int(os.environ.get('BATCH', 512))
+BATCH = int(os.environ.get('BATCH', 2048))         # the engine batch of bench.py's C5 leg
 OUT = os.path.join(ROOT, 'gpurun_out')
 os.makedirs(OUT, exist_ok=True)
 
 eng = E.Engine(max_batch=BATCH, precision=E.EXACT, recheck_batch=0, with_wavenet=False)
-eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321))
+eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321, calibrated='c5'))
 pur = create_improved_diffusion(None, reverse_timestep=T, state_dict=synth.unet_state_dict(31), engine=eng)
 coef = tuple(pur.purify_coefficients())
 report, raw = [], {}

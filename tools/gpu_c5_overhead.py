@@ -9,7 +9,7 @@ from dmad_hip import engine as E, synth
 from diffusion_models.improved_diffusion_ddpm import create_improved_diffusion
 N, B = int(os.environ.get('N', 10000)), int(os.environ.get('B', 2048))
 eng = E.Engine(max_batch=B, precision=E.EXACT, recheck_batch=0, with_wavenet=False)
-eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321))
+eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321, calibrated='c5'))
 pur = create_improved_diffusion(None, reverse_timestep=25, state_dict=synth.unet_state_dict(31), engine=eng)
 args = (torch.from_numpy(synth.synthetic_clip(0)).cuda(), 0.5) + tuple(pur.purify_coefficients()) + (-100.0, 38.22)
 eng.spec_smooth_votes(*args, B, seed=1)
