@@ -238,6 +238,7 @@ struct dmad_engine {
         float *embw = nullptr, *embb = nullptr, *gn2w = nullptr, *gn2b = nullptr, *w2 = nullptr, *b2 = nullptr;   // res: emb, out_layers; attn: proj_out
         float *skw = nullptr, *skb = nullptr;                                       // res: 1x1 skip_connection
         h16_t *w1h = nullptr, *w2h = nullptr, *skwh = nullptr;                      // f16 images of w1 / w2 / skw (16-bit tier)
+        float *w1x = nullptr, *w2x = nullptr, *skwx = nullptr;                      // the same weights in the split-f16 storage format (middle tier)
         size_t ss_off = 0;                 // res: offset of its (scale, shift) row [2 * cout] inside a step's row of un_ss_table
     };
     std::vector<std::vector<UnOp>> un_in, un_out;
@@ -261,6 +262,7 @@ struct dmad_engine {
     // 16-bit tier of the UNet (gemm_h16: f16 operands, fp32 accumulate; GroupNorm / softmax / residual sums stay fp32): f16 twins of
     // the block outputs (the maps a GEMM reads without a GroupNorm in between), f16-only GroupNorm / upsample / attention outputs
     bool un_h16 = false;
+    bool un_x3 = false;                    // exact-vote engines: the UNet's middle tier (fp32 pipeline on split-f16 operands, gemm_x3_kernel) is resident
     h16_t* un_buf16[3] = {nullptr};
     std::vector<h16_t*> un_hs16;
     h16_t *un_t1h = nullptr, *un_t2h = nullptr, *un_uph = nullptr, *un_atth = nullptr, *un_qkvh = nullptr;
@@ -269,7 +271,8 @@ struct dmad_engine {
     float* un_st_t2 = nullptr;
     std::vector<float*> un_st_hs;
     float tau_spec = 0.f;                  // recheck bound of the spec-domain vote loop's 16-bit tier (dmad_set_spec_recheck_margin)
-    int64_t st_spec_samples = 0, st_spec_rechecked = 0;
+    float tau_spec2 = 0.f;                 // ... and of its split-f16 tier (dmad_set_spec_recheck_margin2; < 0: no middle tier)
+    int64_t st_spec_samples = 0, st_spec_rechecked = 0, st_spec_rechecked2 = 0;
 
     template <typename T>
     int alloc(T** p, size_t n, bool zero = false) {
@@ -732,7 +735,13 @@ int upload_h16(dmad_engine* e, const std::vector<float>& A, h16_t** wh) {
     return e->upload_bf(wh, H);
 }
 
-int un_conv3(dmad_engine* e, const std::string& name, int cout, int cin, float** w, float** b, h16_t** wh = nullptr) {
+int upload_split(dmad_engine* e, const std::vector<float>& A, float** wx) {
+    std::vector<float> t(A.size());
+    split_rows(A.data(), A.size(), t.data());
+    return e->upload(wx, t);
+}
+
+int un_conv3(dmad_engine* e, const std::string& name, int cout, int cin, float** w, float** b, h16_t** wh = nullptr, float** wx = nullptr) {
     const HostW* h = e->get(name + ".weight", {cout, cin, 3, 3}); if (!h) return DMAD_ERR_STATE;
     std::vector<float> A((size_t)9 * cout * cin);
     for (int co = 0; co < cout; ++co)
@@ -740,14 +749,16 @@ int un_conv3(dmad_engine* e, const std::string& name, int cout, int cin, float**
             for (int t = 0; t < 9; ++t) A[((size_t)t * cout + co) * cin + ci] = h->v[((size_t)co * cin + ci) * 9 + t];
     CHK(e->upload(w, A));
     if (wh && e->un_h16) CHK(upload_h16(e, A, wh));
+    if (wx && e->un_x3) CHK(upload_split(e, A, wx));
     h = e->get(name + ".bias", {cout}); if (!h) return DMAD_ERR_STATE;
     CHK(e->upload(b, h->v));
     return 0;
 }
-int un_dense(dmad_engine* e, const std::string& name, int out, int in, float** w, float** b, h16_t** wh = nullptr) {
+int un_dense(dmad_engine* e, const std::string& name, int out, int in, float** w, float** b, h16_t** wh = nullptr, float** wx = nullptr) {
     const HostW* h = e->get(name + ".weight", {out, in}); if (!h) return DMAD_ERR_STATE;
     CHK(e->upload(w, h->v));
     if (wh && e->un_h16) CHK(upload_h16(e, h->v, wh));
+    if (wx && e->un_x3) CHK(upload_split(e, h->v, wx));
     h = e->get(name + ".bias", {out}); if (!h) return DMAD_ERR_STATE;
     CHK(e->upload(b, h->v));
     return 0;
@@ -760,21 +771,21 @@ int un_load_op(dmad_engine* e, const std::string& p, dmad_engine::UnOp& o) {
         CHK(e->upload(&o.b1, h->v));
     } else if (o.kind == 1) {
         CHK(un_dense(e, p + ".in_layers.0", o.cin, 1, &o.gn1w, &o.gn1b));
-        CHK(un_conv3(e, p + ".in_layers.2", o.cout, o.cin, &o.w1, &o.b1, &o.w1h));
+        CHK(un_conv3(e, p + ".in_layers.2", o.cout, o.cin, &o.w1, &o.b1, &o.w1h, &o.w1x));
         CHK(un_dense(e, p + ".emb_layers.1", 2 * o.cout, kUnTE, &o.embw, &o.embb));
         CHK(un_dense(e, p + ".out_layers.0", o.cout, 1, &o.gn2w, &o.gn2b));
-        CHK(un_conv3(e, p + ".out_layers.3", o.cout, o.cout, &o.w2, &o.b2, &o.w2h));
-        if (o.cin != o.cout) CHK(un_dense(e, p + ".skip_connection", o.cout, o.cin, &o.skw, &o.skb, &o.skwh));
+        CHK(un_conv3(e, p + ".out_layers.3", o.cout, o.cout, &o.w2, &o.b2, &o.w2h, &o.w2x));
+        if (o.cin != o.cout) CHK(un_dense(e, p + ".skip_connection", o.cout, o.cin, &o.skw, &o.skb, &o.skwh, &o.skwx));
         o.ss_off = e->un_ss_total;
         e->un_ss_total += (size_t)2 * o.cout;
     } else if (o.kind == 2) {
         CHK(un_dense(e, p + ".norm", o.cin, 1, &o.gn1w, &o.gn1b));
-        CHK(un_dense(e, p + ".qkv", 3 * o.cin, o.cin, &o.w1, &o.b1, &o.w1h));
-        CHK(un_dense(e, p + ".proj_out", o.cin, o.cin, &o.w2, &o.b2, &o.w2h));
+        CHK(un_dense(e, p + ".qkv", 3 * o.cin, o.cin, &o.w1, &o.b1, &o.w1h, &o.w1x));
+        CHK(un_dense(e, p + ".proj_out", o.cin, o.cin, &o.w2, &o.b2, &o.w2h, &o.w2x));
     } else if (o.kind == 3) {
-        CHK(un_conv3(e, p + ".op", o.cout, o.cin, &o.w1, &o.b1, &o.w1h));
+        CHK(un_conv3(e, p + ".op", o.cout, o.cin, &o.w1, &o.b1, &o.w1h, &o.w1x));
     } else {
-        CHK(un_conv3(e, p + ".conv", o.cout, o.cin, &o.w1, &o.b1, &o.w1h));
+        CHK(un_conv3(e, p + ".conv", o.cout, o.cin, &o.w1, &o.b1, &o.w1h, &o.w1x));
     }
     return 0;
 }
@@ -852,6 +863,7 @@ int finalize_unet(dmad_engine* e) {
         CHK(e->alloc(&e->un_qkvh, B * 256 * 768));
         if (int r = gemm_h16_configure()) return fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS, f16 conv GEMM) failed: %d", r);
     }
+    if (e->un_x3) if (int r = gemm_x3_configure()) return fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS, split-f16 tier) failed: %d", r);
     CHK(e->alloc(&e->un_ss_table, (size_t)(kUnSsSteps + 1) * e->un_ss_total));
     e->un_ss_have.assign(kUnSsSteps, 0);
     e->un_t = -1;
@@ -901,46 +913,72 @@ GemmF32Args un_conv_args(const float* A, const float* bias, const float* X, floa
     return g;
 }
 
+// a dense layer over NHWC rows as a 1x1 conv (mode 2: the form both the fp32 and the split-f16 launch paths serve for any M % 128 == 0)
+GemmF32Args plain_conv1x1(const float* A, const float* bias, const float* X, float* C, int M, int K, long N) {
+    GemmF32Args g{};
+    g.A = A; g.X = X; g.C = C; g.shift = bias; g.M = M; g.K = K; g.taps = 1; g.ldc = M; g.N = N; g.mode = 2; g.H = 1; g.W = 1; g.Cin = K; g.ldx = K; g.stride = 1;
+    return g;
+}
+
 const float* gn_fail(int HW, int C) { fail(DMAD_ERR_STATE, "GroupNorm: no kernel for a %d-pixel x %d-channel map", HW, C); return nullptr; }
 
 // applies one module; `in` [B][H*H][cin] -> returns the buffer holding [B][Ho*Ho][cout].  `dst`: where the result must
 // land (a saved-skip buffer) or nullptr (take a rotating work buffer).
 // `in2` != nullptr (ResBlocks of the output path only): the module's input is th.cat([in, in2], dim=1) (unet.py:473), `in` holding
 // c1 channels and `in2` the rest — GroupNorm and the 1x1 skip conv read the two parts in place, nothing is concatenated.
+// x3: the MIDDLE tier — the same fp32 pipeline (fp32 maps, GroupNorm, softmax, residual sums) with every conv / 1x1 on split-f16 operands
+// (three f16 MFMAs per product, ~22 significant bits, gemm_x3_kernel): GroupNorm writes its output in the split format, the maps a GEMM
+// reads without a GroupNorm in between (the block input of a 1x1 skip conv, of a Downsample / Upsample conv, the attention output) are
+// converted by one elementwise pass.
 const float* unet_apply(dmad_engine* e, const dmad_engine::UnOp& o, const float* in, int B, int& H, float* dst, int& rot, hipStream_t s,
-                        const float* in2 = nullptr, int c1 = 0) {
+                        const float* in2 = nullptr, int c1 = 0, bool x3 = false) {
     float *T1 = e->un_buf[3], *T2 = e->un_buf[4], *SK = e->un_buf[5], *QKV = e->un_buf[6], *ATT = e->un_buf[7];
     auto next = [&]() { float* p = e->un_buf[rot]; rot = (rot + 1) % 3; if (p == in) { p = e->un_buf[rot]; rot = (rot + 1) % 3; } return p; };
     float* out = dst ? dst : next();
     const long nref = (long)e->maxB * H * H;
+    auto gemm = [&](GemmF32Args g, const float* wx, long nr) {             // one conv / 1x1 on this pass's tier
+        if (x3) { g.A = wx; g.x3 = 1; launch_gemm_f32(g, s); }
+        else launch_gemm_f32(g, s, e->slab, e->slab_floats, nr);
+    };
     if (o.kind == 1) {                      // ResBlock._forward, unet.py:186-199
         if (in2 && o.cin == o.cout) { fail(DMAD_ERR_STATE, "a concatenated input needs the ResBlock's skip conv"); return nullptr; }
-        if (launch_groupnorm_nhwc(in, o.gn1w, o.gn1b, nullptr, 1, T1, B, H * H, o.cin, s, in2, c1)) return gn_fail(H * H, o.cin);
-        launch_gemm_f32(un_conv_args(o.w1, o.b1, T1, T2, o.cout, o.cin, 9, B, H, 1, nullptr), s, e->slab, e->slab_floats, nref);
-        if (launch_groupnorm_nhwc(T2, o.gn2w, o.gn2b, e->un_ss_cur + o.ss_off, 1, T1, B, H * H, o.cout, s)) return gn_fail(H * H, o.cout);
+        if (launch_groupnorm_nhwc(in, o.gn1w, o.gn1b, nullptr, 1, T1, B, H * H, o.cin, s, in2, c1, nullptr, nullptr, nullptr, x3)) return gn_fail(H * H, o.cin);
+        gemm(un_conv_args(o.w1, o.b1, T1, T2, o.cout, o.cin, 9, B, H, 1, nullptr), o.w1x, nref);
+        if (launch_groupnorm_nhwc(T2, o.gn2w, o.gn2b, e->un_ss_cur + o.ss_off, 1, T1, B, H * H, o.cout, s, nullptr, 0, nullptr, nullptr, nullptr, x3)) return gn_fail(H * H, o.cout);
         const float* skip = in;
         if (o.cin != o.cout) {
-            GemmF32Args g = un_conv_args(o.skw, o.skb, in, SK, o.cout, o.cin, 1, B, H, 1, nullptr);
-            if (in2) { g.ldx = c1; g.X2 = in2; g.ksplit = c1; g.ldx2 = o.cin - c1; }
-            launch_gemm_f32(g, s, e->slab, e->slab_floats, nref);
+            const float *sin = in, *sin2 = in2;
+            if (x3) {                       // the block input(s) as split-format operands (QKV / ATT are free inside a ResBlock)
+                const int ca = in2 ? c1 : o.cin;
+                launch_scale(in, 1.f, QKV, (long)B * H * H * ca, s, true);
+                sin = QKV;
+                if (in2) { launch_scale(in2, 1.f, ATT, (long)B * H * H * (o.cin - c1), s, true); sin2 = ATT; }
+            }
+            GemmF32Args g = un_conv_args(o.skw, o.skb, sin, SK, o.cout, o.cin, 1, B, H, 1, nullptr);
+            if (in2) { g.ldx = c1; g.X2 = sin2; g.ksplit = c1; g.ldx2 = o.cin - c1; }
+            gemm(g, o.skwx, nref);
             skip = SK;
         }
-        launch_gemm_f32(un_conv_args(o.w2, o.b2, T1, out, o.cout, o.cout, 9, B, H, 1, skip), s, e->slab, e->slab_floats, nref);
+        gemm(un_conv_args(o.w2, o.b2, T1, out, o.cout, o.cout, 9, B, H, 1, skip), o.w2x, nref);
     } else if (o.kind == 2) {               // AttentionBlock._forward + QKVAttention, unet.py:225-258
         const int C = o.cin, T = H * H;
-        if (launch_groupnorm_nhwc(in, o.gn1w, o.gn1b, nullptr, 0, T1, B, T, C, s)) return gn_fail(T, C);
-        launch_gemm_f32(plain_gemm(o.w1, T1, QKV, nullptr, o.b1, 3 * C, C, (long)B * T, 3 * C, C, 0), s, e->slab, e->slab_floats, nref);
+        if (launch_groupnorm_nhwc(in, o.gn1w, o.gn1b, nullptr, 0, T1, B, T, C, s, nullptr, 0, nullptr, nullptr, nullptr, x3)) return gn_fail(T, C);
+        gemm(x3 ? plain_conv1x1(o.w1, o.b1, T1, QKV, 3 * C, C, (long)B * T) : plain_gemm(o.w1, T1, QKV, nullptr, o.b1, 3 * C, C, (long)B * T, 3 * C, C, 0), o.w1x, nref);
         if (int rc = launch_qkv_attention(QKV, ATT, B, T, kUnHeads, s)) { fail(rc > 0 ? DMAD_ERR_HIP : DMAD_ERR_STATE, "UNet attention (T = %d): %s", T, rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported map size"); return nullptr; }
-        GemmF32Args g = plain_gemm(o.w2, ATT, out, nullptr, o.b2, C, C, (long)B * T, C, C, 0);
+        if (x3) launch_scale(ATT, 1.f, ATT, (long)B * T * C, s, true);             // in place: a thread rewrites the 16 bytes it read
+        GemmF32Args g = x3 ? plain_conv1x1(o.w2, o.b2, ATT, out, C, C, (long)B * T) : plain_gemm(o.w2, ATT, out, nullptr, o.b2, C, C, (long)B * T, C, C, 0);
         g.res = in;
-        launch_gemm_f32(g, s, e->slab, e->slab_floats, nref);
+        gemm(g, o.w2x, nref);
     } else if (o.kind == 3) {               // Downsample: conv 3x3 stride 2, unet.py:82-111
-        launch_gemm_f32(un_conv_args(o.w1, o.b1, in, out, o.cout, o.cin, 9, B, H, 2, nullptr), s, e->slab, e->slab_floats, nref / 4);
+        const float* xin = in;
+        if (x3) { launch_scale(in, 1.f, T1, (long)B * H * H * o.cin, s, true); xin = T1; }
+        gemm(un_conv_args(o.w1, o.b1, xin, out, o.cout, o.cin, 9, B, H, 2, nullptr), o.w1x, nref / 4);
         H /= 2;
     } else if (o.kind == 4) {               // Upsample: nearest x2 + conv 3x3, unet.py:49-79
         launch_upsample2x_nhwc(in, T1, B, H, H, o.cin, s);
         H *= 2;
-        launch_gemm_f32(un_conv_args(o.w1, o.b1, T1, out, o.cout, o.cin, 9, B, H, 1, nullptr), s, e->slab, e->slab_floats, nref * 4);
+        if (x3) launch_scale(T1, 1.f, T1, (long)B * H * H * o.cin, s, true);
+        gemm(un_conv_args(o.w1, o.b1, T1, out, o.cout, o.cin, 9, B, H, 1, nullptr), o.w1x, nref * 4);
     } else {
         if (launch_conv1ch_3x3(in, o.w1, o.b1, out, B, o.cout, s)) { fail(DMAD_ERR_STATE, "input conv: %d output channels > 128", o.cout); return nullptr; }
     }
@@ -1034,6 +1072,7 @@ bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, 
 }
 
 // eps = UNetModel.forward(x, t * ones)  (unet.py:453-477): x, eps [B][32][32]
+// h16 = 2: the split-f16 middle tier (fp32 pipeline, every conv on split-f16 operands: fp32-grade at several times the fp32 matrix rate).
 // h16 < 0: the tier of the map-returning entry points (dmad_unet_eps / dmad_unet_p_sample): the 16-bit tier in DMAD_MODE_FAST (and in
 // DMAD_MODE_EXACT_VOTES when dmad_set_waveform_tier chose the 16-bit tier), the exact-fp32 UNet otherwise — only the spec-domain vote
 // loop has a recheck, so it alone runs the 16-bit tier by default (it passes h16 = 1); 0 / 1: explicit
@@ -1043,8 +1082,8 @@ int unet_eps(dmad_engine* e, const float* x, int t, int B, float* eps, hipStream
     if (t < 0) return fail(DMAD_ERR_INVALID, "diffusion step %d < 0", t);
     CHK(unet_prepare_step(e, t, s));
     if (h16 < 0) h16 = (e->un_h16 && (e->mode == DMAD_MODE_FAST || (e->mode == DMAD_MODE_EXACT_VOTES && e->wave_tier == PATH_DEFAULT))) ? 1 : 0;
-    if (h16 && !e->un_h16) return fail(DMAD_ERR_STATE, "this engine has no 16-bit UNet tier (DMAD_FP32 precision)");
-    if (h16) {
+    if (h16 == 1 && !e->un_h16) return fail(DMAD_ERR_STATE, "this engine has no 16-bit UNet tier (DMAD_FP32 precision)");
+    if (h16 == 1) {
         int H = 32, rot = 0;
         UMap h{x, nullptr, nullptr};
         std::vector<const float*> hs_st(e->un_hs.size(), nullptr);      // the statistics slab each saved map ended up with (none for conv_in's / the 4x4 maps)
@@ -1070,25 +1109,27 @@ int unet_eps(dmad_engine* e, const float* x, int t, int B, float* eps, hipStream
         LASTCHK();
         return 0;
     }
+    const bool x3 = h16 == 2;
+    if (x3 && !e->un_x3) return fail(DMAD_ERR_STATE, "this engine has no split-f16 UNet tier (it needs DMAD_EXACT precision)");
     int H = 32, rot = 0;
     const float* h = x;
     for (size_t i = 0; i < e->un_in.size(); ++i)
         for (size_t j = 0; j < e->un_in[i].size(); ++j)
-            if (!(h = unet_apply(e, e->un_in[i][j], h, B, H, j + 1 == e->un_in[i].size() ? e->un_hs[i] : nullptr, rot, s))) return DMAD_ERR_STATE;
-    for (auto& o : e->un_mid) if (!(h = unet_apply(e, o, h, B, H, nullptr, rot, s))) return DMAD_ERR_STATE;
+            if (!(h = unet_apply(e, e->un_in[i][j], h, B, H, j + 1 == e->un_in[i].size() ? e->un_hs[i] : nullptr, rot, s, nullptr, 0, x3))) return DMAD_ERR_STATE;
+    for (auto& o : e->un_mid) if (!(h = unet_apply(e, o, h, B, H, nullptr, rot, s, nullptr, 0, x3))) return DMAD_ERR_STATE;
     size_t top = e->un_hs.size();
     for (auto& blk : e->un_out) {
         --top;
         const int c1 = blk[0].cin - e->un_hs_ch[top];          // th.cat([h, hs.pop()], dim=1): h carries c1 channels, the saved map the rest
         const float* hs = e->un_hs[top];
         for (size_t j = 0; j < blk.size(); ++j) {
-            h = j == 0 ? unet_apply(e, blk[0], h, B, H, nullptr, rot, s, hs, c1) : unet_apply(e, blk[j], h, B, H, nullptr, rot, s);
+            h = j == 0 ? unet_apply(e, blk[0], h, B, H, nullptr, rot, s, hs, c1, x3) : unet_apply(e, blk[j], h, B, H, nullptr, rot, s, nullptr, 0, x3);
             if (!h) return DMAD_ERR_STATE;
         }
     }
     if (launch_groupnorm_nhwc(h, e->un_outgw, e->un_outgb, nullptr, 1, e->un_buf[3], B, 1024, kUnMC, s)) { gn_fail(1024, kUnMC); return DMAD_ERR_STATE; }
     static_assert(kUnMC == 128, "launch_conv3x3_c128_to1 is the 128-channel output layer");
-    launch_conv3x3_c128_to1(e->un_buf[3], e->un_outw, e->un_outb, eps, B, s);
+    launch_conv3x3_c128_to1(e->un_buf[3], e->un_outw, e->un_outb, eps, B, s);       // (the 128 -> 1 output conv: exact fp32 on every tier but the 16-bit one)
     LASTCHK();
     return 0;
 }
@@ -1257,8 +1298,11 @@ inline int wave_path(const dmad_engine* e) {
     return e->wave_tier;
 }
 
-// the classifier tier of a vote loop's FIRST pass (and of the mode-default paths): 16-bit unless the engine is in DMAD_MODE_FP32
-inline int cls_tier(const dmad_engine* e) { return (e->rx_h16 && e->mode != DMAD_MODE_FP32) ? 1 : 0; }
+// the classifier tier of a vote loop's FIRST pass (and of the mode-default paths): the 16-bit tier (ResNeXt29) in DMAD_MODE_FAST only.
+// Round 5, measured on the calibrated stand-in (profiles/r05b_resnext29_error_attribution.json): the f16 classifier's leader-difference
+// error is 0.08-0.16 against 0.016-0.030 for the f16 WaveNet in front of the fp32 classifier — a bound that covered it would send a
+// quarter of the samples to the recheck tiers, so the exact-vote mode keeps the classifier on the fp32 matrix cores in every tier.
+inline int cls_tier(const dmad_engine* e) { return (e->rx_h16 && e->mode == DMAD_MODE_FAST) ? 1 : 0; }
 
 }  // namespace
 
@@ -1304,7 +1348,9 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     e->un_h16 = cfg->precision != DMAD_FP32;    // engines with a 16-bit side also get the UNet's f16 tier (once UNet weights are loaded)
     e->rx_h16 = cfg->precision != DMAD_FP32;    // ... and ResNeXt29's (once its weights are loaded)
     if (const char* v = getenv("DMAD_RX_H16")) if (v[0] == '0') e->rx_h16 = false;      // A/B switch: ResNeXt29 on the fp32 matrix cores in every tier
-    e->tau_spec = 0.5f;                     // spec-domain vote loop: measured logit-difference error of the f16 UNet chain x headroom (see dmad.h)
+    e->tau_spec = 0.13f;                    // spec-domain vote loop: measured logit-difference error of the f16 UNet chain x headroom (see dmad.h)
+    e->tau_spec2 = 5e-4f;                   // ... of the chain on the split-f16 tier (measured 2.3e-4)
+    e->un_x3 = cfg->precision == DMAD_EXACT;    // exact-vote engines also hold the UNet's split-f16 middle tier
     const bool wn = cfg->with_wavenet != 0;
     if (e->bf16 && !wn_final_p_supported(cfg->num_res_layers)) {
         delete e;
@@ -1515,6 +1561,12 @@ int dmad_unet_eps(dmad_engine* e, const float* x_t, int32_t t, int32_t B, float*
     return unet_eps(e, x_t, t, B, eps, (hipStream_t)s);
 }
 
+int dmad_unet_eps_tier(dmad_engine* e, const float* x_t, int32_t t, int32_t B, int32_t tier, float* eps, dmad_stream s) {
+    if (!e || !x_t || !eps) return fail(DMAD_ERR_INVALID, "null argument");
+    if (tier != 0 && tier != 1 && tier != 2) return fail(DMAD_ERR_INVALID, "unknown UNet tier %d (0 exact fp32, 1 16-bit, 2 split-f16)", tier);
+    return unet_eps(e, x_t, t, B, eps, (hipStream_t)s, tier);
+}
+
 int dmad_unet_p_sample(dmad_engine* e, float* x, int32_t t, float c_a, float c_b, float c_1, float c_2, float c_sig, const float* z,
                        uint64_t seed, uint64_t sample0, int32_t B, float* x0_out, dmad_stream s) {
     if (!e || !x) return fail(DMAD_ERR_INVALID, "null argument");
@@ -1597,6 +1649,28 @@ int dmad_conv_h16_up2(const uint16_t* x_half, const uint16_t* w, const float* bi
     if (stats) { g.stats = stats; g.stats_px = 64; }
     if (!gemm_h16_fuses_up2(g)) return fail(DMAD_ERR_STATE, "this shape is not served by the form that fuses the upsampling (the caller materialises the x2 map)");
     launch_gemm_h16(g, (hipStream_t)s);
+    LASTCHK();
+    return 0;
+}
+
+int dmad_split_f16(const float* x, int64_t n, float* y, dmad_stream s) {
+    if (!x || !y || n < 0 || (n & 3)) return fail(DMAD_ERR_INVALID, "bad argument (n must be a multiple of 4)");
+    if (n) launch_scale(x, 1.f, y, (long)n, (hipStream_t)s, true);
+    LASTCHK();
+    return 0;
+}
+
+int dmad_conv_x3(const float* x, const float* x2, int32_t ksplit, const float* w, const float* bias, const float* res, int32_t B, int32_t H,
+                 int32_t M, int32_t K, int32_t taps, int32_t stride, int32_t relu, int32_t out_split, float* out, dmad_stream s) {
+    if (!x || !w || !out) return fail(DMAD_ERR_INVALID, "null argument");
+    if (B < 1 || H < 1 || M < 1 || K < 1 || (stride != 1 && stride != 2)) return fail(DMAD_ERR_INVALID, "bad geometry");
+    if (int r = gemm_x3_configure()) return fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS, split-f16 tier) failed: %d", r);
+    const int Ho = (H - 1) / stride + 1;
+    GemmF32Args g{};
+    g.A = w; g.X = x; g.C = out; g.shift = bias; g.res = res; g.M = M; g.K = K; g.taps = taps; g.ldc = M; g.relu = relu; g.N = (long)B * Ho * Ho;
+    g.mode = 2; g.H = H; g.W = H; g.Cin = K; g.ldx = x2 ? ksplit : K; g.stride = stride; g.x3 = 1; g.out_split = out_split;
+    if (x2) { g.X2 = x2; g.ksplit = ksplit; g.ldx2 = K - ksplit; }
+    launch_gemm_f32(g, (hipStream_t)s);
     LASTCHK();
     return 0;
 }
@@ -1868,7 +1942,7 @@ int spec_chain(dmad_engine* e, const SpecJob& j, uint64_t s0, const long long* i
     const int L = e->L;
     if (idx) launch_mc_noise_scale_idx(j.clip, nullptr, j.sigma, 1.f, j.seed, 0, idx, e->xt, B, L, st);
     else launch_mc_noise_scale(j.clip, nullptr, j.sigma, 1.f, j.seed, s0, e->xt, B, L, st);      // no wave denoiser: no sqrt(alpha_bar*) scale
-    return spec_chain_from_xt(e, j, s0, idx, B, h16, h16 == 0 ? 0 : cls_tier(e), sp, lg, st);
+    return spec_chain_from_xt(e, j, s0, idx, B, h16, h16 == 1 ? cls_tier(e) : 0, sp, lg, st);      // the recheck tiers: the fp32 classifier
 }
 
 }  // namespace
@@ -1891,18 +1965,37 @@ int dmad_spec_smooth_votes(dmad_engine* e, const float* clip, float sigma, int32
     // tau_spec is queued and its WHOLE chain is re-run on the exact-fp32 UNet from the same Philox keys
     const bool recheck = e->bf16 && e->f32 && e->un_h16 && e->mode == DMAD_MODE_EXACT_VOTES;
     if (recheck) HIPCHK(hipMemsetAsync(e->rc_n, 0, sizeof(unsigned long long), st));
+    // The queued samples: tier 2 = the whole chain again on the UNet's split-f16 tier (fp32-grade at several times the fp32 matrix rate)
+    // settles every sample whose margin exceeds ITS bound tau_spec2; what is left goes to tier 3, the exact-fp32 UNet.  Every pass runs
+    // its samples in batches of up to max_batch from the same Philox keys; a re-evaluated row of logits_out / spec_out carries the last
+    // tier's result.
+    auto pass = [&](const long long* list, long nq, int tier, float tau, long long* next) -> int {
+        for (long done = 0; done < nq; done += e->maxB) {
+            const int B = (int)(nq - done < e->maxB ? nq - done : e->maxB);
+            const long long* idx = list + done;
+            CHK(spec_chain(e, job, 0, idx, B, tier, e->spec, e->logits, st));
+            if (spec_out) launch_scatter_rows(e->spec, idx, (long long)sample0, spec_out, B, 1024, st);
+            if (logits_out) launch_scatter_rows(e->logits, idx, (long long)sample0, logits_out, B, C, st);
+            if (tau >= 0.f) launch_vote_margin(e->logits, B, C, (unsigned long long*)counts, tau, 0, idx, next, e->rc_n, e->rc_cap, nullptr, st);
+            else launch_vote(e->logits, B, C, (unsigned long long*)counts, nullptr, st);
+        }
+        return 0;
+    };
     auto drain = [&]() -> int {
         int rc = 0;
         const long nq = read_queue_length(e, st, &rc);
         if (rc) return rc;
         e->st_spec_rechecked += nq;
-        for (long done = 0; done < nq; done += e->maxB) {
-            const int B = (int)(nq - done < e->maxB ? nq - done : e->maxB);
-            const long long* idx = e->rc_list + done;
-            CHK(spec_chain(e, job, 0, idx, B, 0, e->spec, e->logits, st));
-            if (spec_out) launch_scatter_rows(e->spec, idx, (long long)sample0, spec_out, B, 1024, st);
-            if (logits_out) launch_scatter_rows(e->logits, idx, (long long)sample0, logits_out, B, C, st);
-            launch_vote(e->logits, B, C, (unsigned long long*)counts, nullptr, st);
+        if (nq == 0) return 0;
+        if (e->un_x3 && e->tau_spec2 >= 0.f) {
+            CHK(pass(e->rc_list, nq, 2, e->tau_spec2, e->rc_list2));
+            const long n2 = read_queue_length(e, st, &rc);
+            if (rc) return rc;
+            e->st_spec_rechecked2 += n2;
+            if (n2) CHK(pass(e->rc_list2, n2, 0, -1.f, nullptr));
+        } else {
+            e->st_spec_rechecked2 += nq;
+            CHK(pass(e->rc_list, nq, 0, -1.f, nullptr));
         }
         return 0;
     };
@@ -1933,8 +2026,9 @@ int dmad_spec_eval_samples(dmad_engine* e, const float* clip, float sigma, int32
     if (!e->cfg.with_classifier || !e->cls_final) return fail(DMAD_ERR_STATE, "the spec-domain chain needs the mel front-end and a finalised classifier");
     if (!e->un_final) return fail(DMAD_ERR_STATE, "UNet weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
     if (n < 0 || t_star < 0 || !(mel_hi > mel_lo)) return fail(DMAD_ERR_INVALID, "bad argument");
-    if (tier != 0 && tier != 1) return fail(DMAD_ERR_INVALID, "unknown UNet tier %d (0 exact fp32, 1 16-bit)", tier);
+    if (tier != 0 && tier != 1 && tier != 2) return fail(DMAD_ERR_INVALID, "unknown UNet tier %d (0 exact fp32, 1 16-bit, 2 split-f16)", tier);
     if (tier == 1 && !e->un_h16) return fail(DMAD_ERR_STATE, "this engine has no 16-bit UNet tier (DMAD_FP32 precision)");
+    if (tier == 2 && !e->un_x3) return fail(DMAD_ERR_STATE, "this engine has no split-f16 UNet tier (it needs DMAD_EXACT precision)");
     hipStream_t st = (hipStream_t)s;
     const int C = e->cfg.num_classes;
     const SpecJob job{clip, sigma, t_star, q_a, q_b, c_a, c_b, c_1, c_2, c_sig, mel_lo, mel_hi, seed};
@@ -1959,8 +2053,21 @@ int dmad_spec_recheck_stats(dmad_engine* e, int64_t* samples, int64_t* rechecked
     if (!e) return fail(DMAD_ERR_INVALID, "null engine");
     if (samples) *samples = e->st_spec_samples;
     if (rechecked) *rechecked = e->st_spec_rechecked;
-    if (reset) e->st_spec_samples = e->st_spec_rechecked = 0;
+    if (reset) e->st_spec_samples = e->st_spec_rechecked = e->st_spec_rechecked2 = 0;
     return 0;
+}
+
+int dmad_set_spec_recheck_margin2(dmad_engine* e, float tau2) {
+    if (!e) return fail(DMAD_ERR_INVALID, "null engine");
+    if (tau2 != tau2) return fail(DMAD_ERR_INVALID, "recheck margin is NaN");
+    e->tau_spec2 = tau2;                     // < 0: no middle tier, the queued samples go straight to the exact-fp32 UNet
+    return 0;
+}
+
+int dmad_spec_recheck_stats2(dmad_engine* e, int64_t* samples, int64_t* rechecked, int64_t* rechecked_fp32, int32_t reset) {
+    if (!e) return fail(DMAD_ERR_INVALID, "null engine");
+    if (rechecked_fp32) *rechecked_fp32 = e->st_spec_rechecked2;
+    return dmad_spec_recheck_stats(e, samples, rechecked, reset);
 }
 
 int dmad_query_logits(dmad_engine* e, const float* x, int32_t B, int32_t repeats, int32_t sampler, int32_t t_star, float c_a, float c_b,

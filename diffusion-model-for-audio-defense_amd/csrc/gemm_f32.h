@@ -38,10 +38,13 @@ struct GemmF32Args {
     float* hout;
     float* skip;
     const float* emb_next;
-    // x3 != 0 (mode 0, M a multiple of 128, an even number of k-steps, no split-K): both operands are in the split-f16
-    // storage format (dmad_common.h) and every product is three v_mfma_f32_16x16x32_f16; outputs that feed another GEMM
-    // (epi 1: the gate, epi 2: hout) are written in that format, everything else (plain C, the skip sum) stays fp32.
+    // x3 != 0 (K a multiple of 32, no split-K, no groups): both operands are in the split-f16 storage format (dmad_common.h) and every
+    // product is three v_mfma_f32_16x16x32_f16.  mode 0 (the WaveNet's GEMMs; M a multiple of 256): outputs that feed another GEMM
+    // (epi 1: the gate, epi 2: hout) are written in that format, everything else (plain C, the skip sum) stays fp32.  mode 2 (NHWC convs:
+    // 3x3 / 1x1, stride, two-part input; M a multiple of 128): plain epilogue with shift or scale / shift, fp32 residual, ReLU; fp32 out,
+    // or the split format with out_split.
     int x3;
+    int out_split;        // x3, plain epilogue: C is written in the split format (the consumer is another GEMM of the tier)
     int diag;             // x3 only, error-attribution builds: bit 0 weights = f16(w), bit 1 the MFMA eats f16(x), bit 2 split-format outputs keep hi only
     int splits;           // > 1: split-K over grid.z; partial sums go to `slab` [splits][N][ldc] (fixed-order reduce)
     float* slab;

@@ -42,6 +42,12 @@ __device__ __attribute__((aligned(64))) float g_zero_page[16];                 /
 __device__ __forceinline__ void x3_dma16(const void* sbase, unsigned voff, unsigned lds) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
+// ... and in its vaddr form (a 64-bit address per lane): the NHWC conv gathers of the split-f16 kernel, whose out-of-image taps read a
+// zero page that may lie anywhere relative to the map
+__device__ __forceinline__ void x3_dma16v(const void* vaddr, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds) : "memory");
+}
+__device__ __attribute__((aligned(128))) float g_zero_page128[32];             // 128 B of zeros: one staged row of the split-f16 kernel
 }  // namespace
 
 // s_waitcnt vmcnt(PIECES * stages) + lgkmcnt(0) + barrier for a run-time number of stages in flight (the deep ring's tail; the deep
@@ -354,53 +360,112 @@ constexpr int X3_BM = 256, X3_PAIR = 384 * 128, X3_LDS = 3 * X3_PAIR;
 // XOR-swizzled by (row >> 1) & 7 (conflict-free ds_read_b128 under the hardware's lane groups, tools/lds_bank_check.py); lane
 // (row, q) reads chunks q and q + 4: 8 hi and 8 lo halves = one K = 32 fragment of each part, as before.
 // The X3A_* hooks are the identity in the product build: gemm_x3_ablate.h (ablation / stamp builds of tools/x3_ablation.sh only).
-template <bool DIAG>
+// Round 5: the kernel also serves NHWC convolutions (CONV: GemmF32Args::mode 2 — 3x3 with zero padding / 1x1, stride 2, two-part input;
+// the UNet's convs on the split-f16 tier) and 128-row layers: WM = waves along M (4: tile 256 x 128 as before; 2: tile 128 x 256; the
+// same 48 KiB pair = WM weight pieces + 6 - WM activation pieces of 8 KiB, the same wave tile 64 x 64, the same phases).  A conv's
+// activation pieces take a 64-bit address per lane (x3_dma16v): input pixel of (output pixel, tap) or the zero page; a thread's two / four
+// staging rows, their nine validity bits and base pointers are fixed for the whole launch.
+template <bool DIAG, int WM, bool CONV>
 __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
     constexpr int MT = 4;
+    constexpr int WN = 8 / WM, XBM = WM * 64, XBN = WN * 64;     // waves along N; tile rows (M) and columns (N)
+    static_assert(WM == 4 || WM == 2, "wave layouts 4 x 2 and 2 x 4");
     const bool drop_alo = DIAG && (a.diag & 1), drop_blo = DIAG && (a.diag & 2), hi_only = DIAG && (a.diag & 4);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wv >> 1, wn = wv & 1, q = lane >> 4, r16 = lane & 15;
-    // Workgroup -> tile: workgroups go round-robin over the 8 XCDs (id % 8), each with its own L2.  The M / 256 row blocks of one
+    const int wm = wv / WN, wn = wv % WN, q = lane >> 4, r16 = lane & 15;
+    // Workgroup -> tile: workgroups go round-robin over the 8 XCDs (id % 8), each with its own L2.  The M / XBM row blocks of one
     // column tile are consecutive on ONE XCD, so the second block's X rows (the same rows) are L2 hits instead of a second HBM read.
-    const unsigned ny = (unsigned)(a.M / X3_BM), jx = blockIdx.x >> 3;
+    const unsigned ny = (unsigned)(a.M / XBM), jx = blockIdx.x >> 3;
     const unsigned tile_x = (jx / ny) * 8u + (blockIdx.x & 7u);
-    if ((long)tile_x * BN >= a.N) return;                    // the grid is padded to 8 * ny * ceil(nx / 8)
-    const long n0 = (long)tile_x * BN;
-    const int m0 = (int)(jx % ny) * X3_BM;
+    if ((long)tile_x * XBN >= a.N) return;                   // the grid is padded to 8 * ny * ceil(nx / 8)
+    const long n0 = (long)tile_x * XBN;
+    const int m0 = (int)(jx % ny) * XBM;
     const int pairs_per_tap = a.K / 32, npairs = a.taps * pairs_per_tap;
-    // staging: six 64-row pieces of 8 KiB per pair (A rows 0-255, X rows 0-127); this thread's row of a piece: wave * 8 + lane / 8,
-    // its LDS slot lane & 7 holds chunk (lane & 7) ^ ((row >> 1) & 7) of that row (4 values = one split-format chunk).
+    // staging: six 64-row pieces of 8 KiB per pair (A rows 0 .. XBM-1, then X rows 0 .. XBN-1); this thread's row of a piece: wave * 8 +
+    // lane / 8, its LDS slot lane & 7 holds chunk (lane & 7) ^ ((row >> 1) & 7) of that row (4 values = one split-format chunk).
     // Source address = wave-uniform base (SGPR pair: operand + tap + k offset + piece) + one 32-bit lane offset per operand row.
     const int rloc = wv * 8 + (lane >> 3), chunk4 = ((lane & 7) ^ ((rloc >> 1) & 7)) * 4;
-    const char* Ab = (const char*)(a.A + (size_t)m0 * a.K);                       // M is a multiple of 256 (launcher)
+    const char* Ab = (const char*)(a.A + (size_t)m0 * a.K);                       // M is a multiple of XBM (launcher)
     const unsigned voffA = (unsigned)((rloc * a.K + chunk4) * 4);
     const size_t a_piece = (size_t)64 * a.K * 4, a_tap = (size_t)a.M * a.K * 4;
     auto rowoff = [&](long n) { const long xb = n / a.rows_per_batch; return xb * a.batch_stride + (n - xb * a.rows_per_batch) * a.row_stride; };
-    const long off0 = rowoff(n0);
-    const char* Xb = (const char*)(a.X + off0 - (long)(a.taps >> 1) * a.tap_stride);          // row n0 of tap 0
-    unsigned voffX[2];
+    // mode 0: rows addressed as base + lane offset
+    const char* Xb = nullptr;
+    unsigned voffX[WN];
+    // CONV: per staging row the input pixel of tap (0, 0) in X (and in X2), and the taps that fall inside the image
+    const char* xrow[WN];
+    const char* xrow2[WN];
+    unsigned vmask[WN];
+    if constexpr (!CONV) {
+        const long off0 = rowoff(n0);
+        Xb = (const char*)(a.X + off0 - (long)(a.taps >> 1) * a.tap_stride);          // row n0 of tap 0
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {            // columns past N read row N-1 (valid memory; their results are never stored)
-        long n = n0 + p * 64 + rloc;
-        if (n >= a.N) n = a.N - 1;
-        voffX[p] = (unsigned)((rowoff(n) - off0 + chunk4) * 4);
+        for (int p = 0; p < WN; ++p) {       // columns past N read row N-1 (valid memory; their results are never stored)
+            long n = n0 + p * 64 + rloc;
+            if (n >= a.N) n = a.N - 1;
+            voffX[p] = (unsigned)((rowoff(n) - off0 + chunk4) * 4);
+        }
+    } else {
+        const int st = a.stride > 1 ? a.stride : 1;
+        const int Ho = (a.H - 1) / st + 1, Wo = (a.W - 1) / st + 1, hw = Ho * Wo;
+        const long ldx = a.ldx ? a.ldx : a.Cin;
+#pragma unroll
+        for (int p = 0; p < WN; ++p) {
+            const long n = n0 + p * 64 + rloc;
+            xrow[p] = xrow2[p] = (const char*)g_zero_page128;
+            vmask[p] = 0u;
+            if (n < a.N) {
+                const long b = n / hw;
+                const int pix = (int)(n - b * hw), y0 = (pix / Wo) * st, x0 = (pix % Wo) * st;
+                const long ipix = (b * a.H + y0) * a.W + x0;
+                xrow[p] = (const char*)(a.X + ipix * ldx + chunk4);
+                if (a.X2) xrow2[p] = (const char*)(a.X2 + ipix * a.ldx2 + chunk4);
+                if (a.taps == 9) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+                        if ((unsigned)(y0 + t / 3 - 1) < (unsigned)a.H && (unsigned)(x0 + t % 3 - 1) < (unsigned)a.W) vmask[p] |= 1u << t;
+                } else {
+                    vmask[p] = 1u;
+                }
+            }
+        }
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
     bool x3_steady = false;            // false during the prologue (ablation builds that drop one operand's pieces still stage both there)
     (void)x3_steady;
     int st_tap = 0, st_kq = 0;               // staging cursor: the next pair to stage is (tap st_tap, k-pair st_kq)
     const char *st_a = Ab, *st_x = Xb;
+    long st_xoff = 0;                        // CONV: byte offset of the cursor's (tap, k-pair) from a row's tap-(0,0) pixel
+    bool st_second = false;                  // CONV, two-part input: the cursor's channels come from X2
+    auto st_update = [&]() {
+        st_a = Ab + (size_t)st_tap * a_tap + (size_t)st_kq * 128;
+        if constexpr (!CONV) {
+            st_x = Xb + ((long)st_tap * a.tap_stride + (long)st_kq * 32) * 4;
+        } else {
+            const int dy = a.taps == 9 ? st_tap / 3 - 1 : 0, dx = a.taps == 9 ? st_tap % 3 - 1 : 0, kk = st_kq * 32;
+            st_second = a.X2 && kk >= a.ksplit;
+            const long pitch = st_second ? a.ldx2 : (a.ldx ? a.ldx : a.Cin);
+            st_xoff = ((long)(dy * a.W + dx) * pitch + (st_second ? kk - a.ksplit : kk)) * 4;
+        }
+    };
+    st_update();
     auto st_advance = [&]() {
         if (++st_kq == pairs_per_tap) { st_kq = 0; ++st_tap; }
-        st_a = Ab + (size_t)st_tap * a_tap + (size_t)st_kq * 128;
-        st_x = Xb + ((long)st_tap * a.tap_stride + (long)st_kq * 32) * 4;
+        st_update();
     };
     auto piece = [&](int k, unsigned slot_lds) {          // one of the six 8 KiB DMA pieces of the cursor's pair
         if (X3A_SKIP_PIECE(k, x3_steady)) return;
-        if (k < 4) x3_dma16(st_a + (size_t)k * a_piece, voffA, slot_lds + k * 8192 + wv * 1024);
-        else x3_dma16(st_x, voffX[k - 4], slot_lds + 32768 + (k - 4) * 8192 + wv * 1024);
+        if (k < WM) {
+            x3_dma16(st_a + (size_t)k * a_piece, voffA, slot_lds + k * 8192 + wv * 1024);
+        } else if constexpr (!CONV) {
+            x3_dma16(st_x, voffX[k - WM], slot_lds + k * 8192 + wv * 1024);
+        } else {
+            const int p = k - WM;
+            const char* src = ((vmask[p] >> st_tap) & 1u) ? (st_second ? xrow2[p] : xrow[p]) + st_xoff : (const char*)g_zero_page128 + chunk4 * 4;
+            x3_dma16v(src, slot_lds + k * 8192 + wv * 1024);
+        }
     };
     f32x4 acc[MT][4], cor[MT][4];
 #pragma unroll
@@ -409,7 +474,7 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
         for (int j = 0; j < 4; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; cor[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const int sw = (r16 >> 1) & 7;
     const int f0 = r16 * 128 + ((q ^ sw) * 16), f1 = r16 * 128 + (((4 + q) ^ sw) * 16);
-    const int aoff = wm * 8192, boff = 32768 + wn * 8192;
+    const int aoff = wm * 8192, boff = WM * 8192 + wn * 8192;
 
     // Fragment registers: operand halves A0 / A1 (accumulator rows i = 0,1 / 2,3) and B0 / B1 (columns j = 0,1 / 2,3), each two
     // 16-row tiles x (hi, lo) = 16 registers.  A tile's two chunks c0 = [hi0-3 | lo0-3], c1 = [hi4-7 | lo4-7] are read straight
@@ -582,19 +647,59 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
         }
         return;
     }
+    if constexpr (!CONV) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {           // plain: fp32 out, bias, optional ReLU (final_conv.0)
+        for (int i = 0; i < MT; ++i) {           // plain: fp32 out, bias, optional ReLU (final_conv.0)
+            const int m = m0 + wm * 64 + i * 16 + q * 4;
+            const float4 b4 = a.shift ? *(const float4*)(a.shift + m) : float4{0.f, 0.f, 0.f, 0.f};
+            const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long n = n0 + wn * 64 + j * 16 + r16;
+                if (n >= a.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float t = acc[i][j][r] + ba[r]; v[r] = a.relu ? relu_nan(t) : t; }
+                *(float4*)(a.C + n * a.ldc + m) = float4{v[0], v[1], v[2], v[3]};
+            }
+        }
+        return;
+    }
+    // plain: bias (or folded BatchNorm scale / shift), optional fp32 residual, optional ReLU; fp32 out, or the split format when the
+    // consumer is another GEMM of this tier (GemmF32Args::out_split).  A row tile's residual chunks are loaded ahead of its stores (the
+    // compiler cannot know that `res` and `C` do not overlap).
+    long nrow[4];
+    bool nok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long n = n0 + wn * 64 + j * 16 + r16;
+        nok[j] = n < a.N;
+        nrow[j] = (nok[j] ? n : a.N - 1) * a.ldc;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
         const int m = m0 + wm * 64 + i * 16 + q * 4;
         const float4 b4 = a.shift ? *(const float4*)(a.shift + m) : float4{0.f, 0.f, 0.f, 0.f};
-        const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+        const float4 s4 = a.scale ? *(const float4*)(a.scale + m) : float4{1.f, 1.f, 1.f, 1.f};
+        const float ba[4] = {b4.x, b4.y, b4.z, b4.w}, sa[4] = {s4.x, s4.y, s4.z, s4.w};
+        float4 rr[4];
+        if (a.res) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rr[j] = *(const float4*)(a.res + nrow[j] + m);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const long n = n0 + wn * 64 + j * 16 + r16;
-            if (n >= a.N) continue;
+            if (!nok[j]) continue;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float t = acc[i][j][r] + ba[r]; v[r] = a.relu ? relu_nan(t) : t; }
-            *(float4*)(a.C + n * a.ldc + m) = float4{v[0], v[1], v[2], v[3]};
+            for (int r = 0; r < 4; ++r) v[r] = a.scale ? acc[i][j][r] * sa[r] + ba[r] : acc[i][j][r] + ba[r];
+            if (a.res) { v[0] += rr[j].x; v[1] += rr[j].y; v[2] += rr[j].z; v[3] += rr[j].w; }
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = relu_nan(v[r]);
+            }
+            if (a.out_split) *(u32x4_t*)(a.C + nrow[j] + m) = split4(v[0], v[1], v[2], v[3]);
+            else *(float4*)(a.C + nrow[j] + m) = float4{v[0], v[1], v[2], v[3]};
         }
     }
 }
@@ -618,9 +723,13 @@ int gemm_take_bad_shapes() { const int n = g_bad_shapes; g_bad_shapes = 0; retur
 
 // once per device a process uses (dmad_create): the x3 tier's 144 KiB of dynamic LDS
 int gemm_x3_configure() {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_x3_kernel<false, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
     if (e != hipSuccess) return (int)e;
-    return (int)hipFuncSetAttribute((const void*)gemm_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+    e = hipFuncSetAttribute((const void*)gemm_x3_kernel<true, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_x3_kernel<false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipFuncSetAttribute((const void*)gemm_x3_kernel<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
 }
 
 namespace {
@@ -634,14 +743,28 @@ int launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab
     GemmF32Args a = a0;
     // the update epilogue indexes positions in 32 bits and serves M = 256 residual rows (the skip convs are one GEMM of their own)
     if (a.epi == 2 && (a.N >= (1l << 31) || a.L < 1 || a.M != 256 || a.res_rows != a.M || !a.hin || !a.hout || !a.emb_next)) { ++g_bad_shapes; return kGemmBadShape; }
-    if (a.x3) {                                   // split-f16 operands: WaveNet shapes only (checked here, not in the kernel)
-        if (a.mode != 0 || (a.M % X3_BM) || (a.K % 32) || a.scale || a.res || a.groups > 1 || (a.ldc & 3)) { ++g_bad_shapes; return kGemmBadShape; }
+    if (a.x3) {                                   // split-f16 operands (shapes checked here, not in the kernel)
         a.splits = 1; a.slab = nullptr;
-        const long nx = (a.N + BN - 1) / BN;
-        if (((nx + 7) / 8) * 8 * (a.M / X3_BM) > 0x7fffffffl) { ++g_bad_shapes; return kGemmBadShape; }
-        const dim3 grid((unsigned)(((nx + 7) / 8) * 8 * (a.M / X3_BM)));
-        if (a.diag) hipLaunchKernelGGL(gemm_x3_kernel<true>, grid, dim3(512), X3_LDS, s, a);
-        else hipLaunchKernelGGL(gemm_x3_kernel<false>, grid, dim3(512), X3_LDS, s, a);
+        if ((a.K % 32) || a.groups > 1 || (a.ldc & 3) || a.K < 32) { ++g_bad_shapes; return kGemmBadShape; }
+        if (a.mode == 0) {                        // the WaveNet's row-gather GEMMs: tile 256 x 128
+            if ((a.M % X3_BM) || a.scale || a.res || a.out_split || a.X2) { ++g_bad_shapes; return kGemmBadShape; }
+            const long nx = (a.N + BN - 1) / BN;
+            if (((nx + 7) / 8) * 8 * (a.M / X3_BM) > 0x7fffffffl) { ++g_bad_shapes; return kGemmBadShape; }
+            const dim3 grid((unsigned)(((nx + 7) / 8) * 8 * (a.M / X3_BM)));
+            if (a.diag) hipLaunchKernelGGL((gemm_x3_kernel<true, 4, false>), grid, dim3(512), X3_LDS, s, a);
+            else hipLaunchKernelGGL((gemm_x3_kernel<false, 4, false>), grid, dim3(512), X3_LDS, s, a);
+            return 0;
+        }
+        // NHWC convs (3x3 zero padding 1 / 1x1, stride 1 or 2, optional two-part input): rows of 16-byte chunks, no fused epilogue
+        const long ldx = a.ldx ? a.ldx : a.Cin;
+        if (a.mode != 2 || a.epi || a.diag || (a.M % 128) || (a.taps != 9 && a.taps != 1) || (ldx & 3) || a.H < 1 || a.W < 1 ||
+            (a.X2 && ((a.ksplit % 32) || a.ksplit <= 0 || a.ksplit >= a.K || (a.ldx2 & 3))) || (a.res && a.res == a.C)) { ++g_bad_shapes; return kGemmBadShape; }
+        const bool big = a.M % 256 == 0;
+        const long nx = (a.N + (big ? 127 : 255)) / (big ? 128 : 256), ny = a.M / (big ? 256 : 128);
+        if (((nx + 7) / 8) * 8 * ny > 0x7fffffffl) { ++g_bad_shapes; return kGemmBadShape; }
+        const dim3 grid((unsigned)(((nx + 7) / 8) * 8 * ny));
+        if (big) hipLaunchKernelGGL((gemm_x3_kernel<false, 4, true>), grid, dim3(512), X3_LDS, s, a);
+        else hipLaunchKernelGGL((gemm_x3_kernel<false, 2, true>), grid, dim3(512), X3_LDS, s, a);
         return 0;
     }
     if (a.X2 && (a.mode != 2 || a.groups > 1 || a.M <= 64 || (a.ksplit % BK) || a.ksplit <= 0 || a.ksplit >= a.K)) { ++g_bad_shapes; return kGemmBadShape; }   // two-part input: plain NHWC convs only

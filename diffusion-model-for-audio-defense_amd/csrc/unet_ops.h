@@ -21,7 +21,8 @@ void launch_conv3x3_c128_to1_h16(const h16_t* in, const float* w, const float* b
 // read from its two parts; y is always one map of C channels.
 int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* ss, int silu, float* y, int B, int HW,
                           int C, hipStream_t s, const float* x2 = nullptr, int c1 = 0, h16_t* y16 = nullptr,      // y16 != nullptr: the result is written as f16 there (y unused)
-                          const h16_t* x16 = nullptr, const h16_t* x2_16 = nullptr);   // x16 != nullptr: the input is read from f16 map(s) x16 (/ x2_16) instead of x (/ x2)
+                          const h16_t* x16 = nullptr, const h16_t* x2_16 = nullptr,    // x16 != nullptr: the input is read from f16 map(s) x16 (/ x2_16) instead of x (/ x2)
+                          int split = 0);             // split: y (fp32 input form only) is written in the split-f16 storage format of dmad_common.h
 // The 16-bit tier's GroupNorm as one streaming pass over an f16 map (or the two parts x [c1 channels] | x2 of a concatenated input)
 // whose statistics the producing GEMMs left in st / st2 (GemmH16Args::stats: [B * HW / 64][channels / 4][2] floats per map):
 // y = SiLU?((x - mean) * rstd * gamma + beta [* (1 + ss[c]) + ss[C + c]]) as f16 (y16) or fp32 (y32).  HW a multiple of 64, or 16 (the

@@ -143,6 +143,8 @@ __global__ void __launch_bounds__(1024) groupnorm_nhwc_kernel(const float* __res
                                                               const float* __restrict__ x2, int c1, h16_t* __restrict__ y16) {
     __shared__ float part[1024];
     __shared__ float gsum[8];
+    const bool split_out = (silu & 2) != 0;                    // flags: bit 0 SiLU, bit 1 the fp32 output in the split-f16 storage format
+    silu &= 1;
     const int NT = blockDim.x, t = threadIdx.x, lane = t & 63, wv = t >> 6, nwaves = NT >> 6;
     const int c4 = C >> 7, R = G * c4, upb = 32 / G;          // upb: workgroups per sample
     const int b = blockIdx.x / upb, g0 = (blockIdx.x % upb) * G;
@@ -209,6 +211,7 @@ __global__ void __launch_bounds__(1024) groupnorm_nhwc_kernel(const float* __res
             o[r] = u;
         }
         if (y16) *(f16x4*)(y16 + base + (long)pix * C) = f16x4{(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+        else if (split_out) *(u32x4_t*)(y + base + (long)pix * C) = split4(o[0], o[1], o[2], o[3]);      // operand of a split-f16 GEMM (same 16 bytes)
         else *(float4*)(y + base + (long)pix * C) = float4{o[0], o[1], o[2], o[3]};
     }
 }
@@ -628,8 +631,10 @@ void launch_conv3x3_c128_to1_h16(const h16_t* in, const float* w, const float* b
     hipLaunchKernelGGL(conv3x3_c128_to1_h16_kernel, dim3((unsigned)B), dim3(256), 0, s, in, w, bias, out);
 }
 int launch_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* ss, int silu, float* y, int B, int HW,
-                          int C, hipStream_t s, const float* x2, int c1, h16_t* y16, const h16_t* x16, const h16_t* x2_16) {
+                          int C, hipStream_t s, const float* x2, int c1, h16_t* y16, const h16_t* x16, const h16_t* x2_16, int split) {
     const bool in16 = x16 != nullptr;
+    if (split && (in16 || y16)) return -1;          // the split-format output belongs to the fp32-input kernel
+    silu = (silu ? 1 : 0) | (split ? 2 : 0);        // the kernel's flag word
     if (in16) { x = (const float*)x16; x2 = (const float*)x2_16; }      // the kernel reinterprets them (IN16)
     const int c4 = C >> 7;
     if (C % 128 || c4 < 1 || c4 > 4 || B < 1 || HW < 1) return -1;

@@ -43,6 +43,7 @@ _SIGNATURES = {
     'dmad_diffuse': (C.c_int, [_P, _P, C.c_float, C.c_float, _P, C.c_uint64, C.c_uint64, C.c_int32, _P, _P]),
     'dmad_ddpm_purify': (C.c_int, [_P, _P, C.c_int32, C.c_float, C.c_float, _P, _P, _P, C.c_uint64, C.c_uint64, C.c_int32, _P, _P]),
     'dmad_unet_eps': (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
+    'dmad_unet_eps_tier': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     'dmad_unet_p_sample': (C.c_int, [_P, _P, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_uint64, C.c_uint64,
                                      C.c_int32, _P, _P]),
     'dmad_mel_db': (C.c_int, [_P, _P, C.c_int32, _P, _P]),
@@ -53,6 +54,8 @@ _SIGNATURES = {
     'dmad_conv_h16': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_int32, _P, _P, _P]),
     'dmad_conv_h16_up2': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    'dmad_split_f16': (C.c_int, [_P, C.c_int64, _P, _P]),
+    'dmad_conv_x3': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     'dmad_conv_h16_stats': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     'dmad_groupnorm16_apply': (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     'dmad_smooth_votes': (C.c_int, [_P, _P, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_int64, C.c_int32,
@@ -76,6 +79,8 @@ _SIGNATURES = {
                                          C.c_uint64, _P, C.c_int64, C.c_int32, _P, _P, _P]),
     'dmad_set_spec_recheck_margin': (C.c_int, [_P, C.c_float]),
     'dmad_spec_recheck_stats': (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
+    'dmad_set_spec_recheck_margin2': (C.c_int, [_P, C.c_float]),
+    'dmad_spec_recheck_stats2': (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
     'dmad_vote': (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     'dmad_philox_raw': (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _P, _P]),
     'dmad_philox_normal': (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int32, _P, _P]),

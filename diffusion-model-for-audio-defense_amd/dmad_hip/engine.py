@@ -28,13 +28,20 @@ WAVE_16BIT, WAVE_FP32, WAVE_SPLIT = 0, 1, 2       # dmad_set_waveform_tier: Wave
 # profiles/r02_flip_study.md): f16 operands E = 0.0244 (0.0287 over all pairs i, j; 35 flips, the largest at margin 0.011),
 # bf16 operands 0.207 (0.221; 261 flips) -> bounds with ~1.4x headroom.  Overridable: DMAD_RECHECK_MARGIN / recheck_margin=.
 DEFAULT_RECHECK_MARGIN = {1: 0.034, 0: 0.30}          # by dmad_half_type: HALF_F16, HALF_BF16
+# The error a given eps error turns into is a property of the classifier.  With the calibrated synthetic ResNeXt29 (fp32 classifier in
+# every tier of the exact-vote mode; tools/gpu_flip_study.py with CLASSIFIER=resnext29, profiles/r05b_flip_study_resnext29_fp32cls.json,
+# 18 432 samples): E = 0.0300, Gaussian scale 0.0065 -> 1.5 x E = 0.045 >= 5.4 scales.  load_resnext29 widens the bound to this floor.
+DEFAULT_RECHECK_MARGIN_RESNEXT29 = {1: 0.045, 0: 0.40}
 # The queued samples first go through the split-f16 tier (fp32 pipeline, three f16 MFMAs per product, ~22 significant bits);
 # only those whose margin is inside ITS error bound reach the exact-fp32 path.
 DEFAULT_RECHECK_MARGIN2 = 1e-3
 # Spec-domain vote loop (BASELINE C5): the UNet's 16-bit tier runs the whole 26-evaluation chain on f16 operands; a sample whose
 # top-2 logit margin is below this bound re-runs its chain on the exact-fp32 UNet.  Measured with tools/gpu_c5_flip_study.py
 # (profiles/r03_c5_flip_study.md): the same leader-difference statistic as DEFAULT_RECHECK_MARGIN, x headroom.
-DEFAULT_SPEC_RECHECK_MARGIN = 0.5
+DEFAULT_SPEC_RECHECK_MARGIN = 0.13
+# ... and the samples it queues first re-run their chain on the UNet's split-f16 tier (fp32 pipeline, three f16 MFMAs per product); only
+# those whose margin is inside THAT tier's error bound reach the exact-fp32 UNet (dmad_set_spec_recheck_margin2; < 0: no middle tier).
+DEFAULT_SPEC_RECHECK_MARGIN2 = 5e-4          # 2.2 x the largest leader-difference error (2.3e-4) of the split-f16 chain on 6 144 samples (profiles/r05c_c5_flip_study.json)
 # Tail rule shared by the committed default and calibrate_recheck (tools/fit_recheck_tail.py): with s the
 # Gaussian scale of the per-sample leader-difference error, a bound of TAIL_Z * s keeps the modelled miss probability per
 # sample (error beyond the bound AND an exact margin small enough to be overturned) at or below 1e-9.
@@ -200,6 +207,7 @@ class Engine:
         # what calibrations may never go below: the committed defaults, or a wider bound the caller chose (constructor / environment /
         # a direct set_recheck_margin call)
         self.floor1, self.floor2, self.floor_spec = DEFAULT_RECHECK_MARGIN[half_type], DEFAULT_RECHECK_MARGIN2, DEFAULT_SPEC_RECHECK_MARGIN
+        self.floor_spec2 = DEFAULT_SPEC_RECHECK_MARGIN2
         self.spec_calibration = None
         if precision == EXACT:
             wt = os.environ.get('DMAD_WAVEFORM_TIER')
@@ -210,6 +218,7 @@ class Engine:
             self.set_recheck_margin(recheck_margin)
             self.set_recheck_margin2(float(os.environ.get('DMAD_RECHECK_MARGIN2', DEFAULT_RECHECK_MARGIN2)))
             self.set_spec_recheck_margin(float(os.environ.get('DMAD_SPEC_RECHECK_MARGIN', DEFAULT_SPEC_RECHECK_MARGIN)))
+            self.set_spec_recheck_margin2(float(os.environ.get('DMAD_SPEC_RECHECK_MARGIN2', DEFAULT_SPEC_RECHECK_MARGIN2)))
 
     def close(self):
         if getattr(self, '_h', None):
@@ -278,7 +287,12 @@ class Engine:
         check(self.lib.dmad_set_recheck_margin(self._h, float(tau)))
         self.recheck_margin = float(tau)
         if not calibrated:
-            self.floor1 = max(DEFAULT_RECHECK_MARGIN[self.half_type], float(tau))
+            self.floor1 = max(self._committed_margin1(), float(tau))
+
+    def _committed_margin1(self) -> float:
+        """the committed tier-1 bound for this engine's operand format and resident classifier kind"""
+        table = DEFAULT_RECHECK_MARGIN_RESNEXT29 if getattr(self, 'classifier_kind', None) == 'resnext29' else DEFAULT_RECHECK_MARGIN
+        return table[self.half_type]
 
     def set_recheck_margin2(self, tau2: float, calibrated: bool = False):
         """bound of the split-f16 middle tier (< 0: tier off, queued samples go straight to the fp32 path)."""
@@ -294,11 +308,19 @@ class Engine:
         if not calibrated:
             self.floor_spec = max(DEFAULT_SPEC_RECHECK_MARGIN, float(tau))
 
-    def spec_recheck_stats(self, reset: bool = False):
-        """-> (samples voted by spec_smooth_votes, samples whose chain was re-run on the exact-fp32 UNet) since the last reset."""
-        a, b = C.c_int64(0), C.c_int64(0)
-        check(self.lib.dmad_spec_recheck_stats(self._h, C.byref(a), C.byref(b), 1 if reset else 0))
-        return int(a.value), int(b.value)
+    def set_spec_recheck_margin2(self, tau2: float, calibrated: bool = False):
+        """bound of the spec-domain loop's split-f16 UNet tier (dmad_set_spec_recheck_margin2); < 0: queued samples go straight to fp32."""
+        check(self.lib.dmad_set_spec_recheck_margin2(self._h, float(tau2)))
+        self.spec_recheck_margin2 = float(tau2)
+        if not calibrated:
+            self.floor_spec2 = max(DEFAULT_SPEC_RECHECK_MARGIN2, float(tau2))
+
+    def spec_recheck_stats(self, reset: bool = False, detail: bool = False):
+        """-> (samples voted by spec_smooth_votes, samples whose chain left the 16-bit tier) since the last reset; detail: + the samples
+        that reached the exact-fp32 UNet."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(self.lib.dmad_spec_recheck_stats2(self._h, C.byref(a), C.byref(b), C.byref(c), 1 if reset else 0))
+        return (int(a.value), int(b.value), int(c.value)) if detail else (int(a.value), int(b.value))
 
     def recheck_stats(self, reset: bool = False, detail: bool = False):
         """-> (samples voted, samples that left the 16-bit pass) since the last reset; detail: + samples that reached fp32."""
@@ -366,7 +388,7 @@ class Engine:
     def spec_eval_samples(self, clip: torch.Tensor, sigma: float, t_star: int, q_a: float, q_b: float, c_a, c_b, c_1, c_2, c_sig,
                           mel_lo: float, mel_hi: float, idx: torch.Tensor, tier: int, seed: int = 0, want_spec: bool = False):
         """dmad_spec_eval_samples: logits [len(idx), C] (and the purified dB spectrograms when asked) of the spec-domain chain for
-        the Monte Carlo samples with GLOBAL indices `idx` on UNet tier 0 (exact fp32) / 1 (16-bit).  Nothing votes."""
+        the Monte Carlo samples with GLOBAL indices `idx` on UNet tier 0 (exact fp32) / 1 (16-bit) / 2 (split-f16).  Nothing votes."""
         clip = clip.detach().reshape(-1).contiguous().float()
         assert clip.is_cuda and clip.numel() == self.L
         idx = idx.detach().to(device=clip.device, dtype=torch.int64).contiguous()
@@ -379,34 +401,44 @@ class Engine:
                                               _ptr(logits), _ptr(spec), _stream()))
         return (logits, spec) if want_spec else logits
 
-    def calibrate_spec_recheck(self, clip, sigma: float, chain_args: tuple, n: int = 256, headroom: float = 1.5, seed: int = 0x5BECCA1):
+    def calibrate_spec_recheck(self, clip, sigma: float, chain_args: tuple, n: int = 256, headroom: float = 1.5, seed: int = 0x5BECCA1,
+                               n_fp32: Optional[int] = None):
         """The spec-domain counterpart of calibrate_recheck: for THE RESIDENT WEIGHTS and this (sigma, t*), run n Monte Carlo samples'
-        whole chains per clip on the UNet's 16-bit tier and on its exact-fp32 tier from the same Philox keys, take the leader-difference
-        error statistic (see DEFAULT_RECHECK_MARGIN) and set
-            tau_spec = max(floor, headroom * e, TAIL_Z * s)
-        with e its largest value and s its Gaussian scale (q90 / q99 points), floor = the committed default (or a wider bound the
+        whole chains per clip on the UNet's 16-bit tier and on its split-f16 tier, and the first n_fp32 (default n / 2) of them on the
+        exact-fp32 tier, from the same Philox keys; take the leader-difference error statistic (see DEFAULT_RECHECK_MARGIN) and set
+            tau_spec2 = max(floor2, headroom * e2)                                    (split-f16 tier against fp32)
+            tau_spec  = max(floor, headroom * e + tau_spec2, TAIL_Z * s + tau_spec2)  (16-bit tier against the split-f16 tier)
+        with e its largest value and s its Gaussian scale (q90 / q99 points), floors = the committed defaults (or wider bounds the
         caller put in force): widen-only.  chain_args = (t_star, q_a, q_b, c_a, c_b, c_1, c_2, c_sig, mel_lo, mel_hi) as for
-        spec_smooth_votes.  Returns (tau_spec, e, s); the record is kept in self.spec_calibration."""
+        spec_smooth_votes.  Returns (tau_spec, e, s); the full record is kept in self.spec_calibration."""
         if self.precision != EXACT:
             raise DmadError('calibrate_spec_recheck needs an EXACT engine')
         clips = list(clip) if isinstance(clip, (list, tuple)) else [clip]
-        e = s = 0.0
+        n_fp32 = max(1, min(n, n // 2 if n_fp32 is None else n_fp32))
+        e = s = e2 = 0.0
         zs = {0.9: 2.5392, 0.99: 3.2608}                  # 18 Q(z) = 1 - q (the maximum of 9 |normal differences|)
+
+        def lead_err(a, ref):
+            d = a - ref
+            return (d - d.gather(1, ref.argmax(1, keepdim=True))).abs().max(1).values
         for ci, x in enumerate(clips):
             idx = torch.arange(n, dtype=torch.int64, device=self.device)
             lo = self.spec_eval_samples(x, sigma, *chain_args, idx, tier=1, seed=seed + ci).double()
-            ref = self.spec_eval_samples(x, sigma, *chain_args, idx, tier=0, seed=seed + ci).double()
-            if not (bool(torch.isfinite(lo).all()) and bool(torch.isfinite(ref).all())):
+            mid = self.spec_eval_samples(x, sigma, *chain_args, idx, tier=2, seed=seed + ci).double()
+            ref = self.spec_eval_samples(x, sigma, *chain_args, idx[:n_fp32], tier=0, seed=seed + ci).double()
+            if not (bool(torch.isfinite(lo).all()) and bool(torch.isfinite(mid).all()) and bool(torch.isfinite(ref).all())):
                 raise DmadError('calibrate_spec_recheck: non-finite logits')
-            d = lo - ref
-            le = (d - d.gather(1, ref.argmax(1, keepdim=True))).abs().max(1).values
+            le = lead_err(lo, mid)
             e = max(e, float(le.max()))
             s = max(s, max(float(torch.quantile(le, q)) / z for q, z in zs.items()))
-        previous, floor = self.spec_recheck_margin, self.floor_spec
-        new = max(floor, headroom * e, TAIL_Z * s)
-        self.set_spec_recheck_margin(new, calibrated=True)
-        self.spec_calibration = {'e': e, 's': s, 'tau_spec': new, 'n': n, 'clips': len(clips), 'headroom': headroom, 'floor': floor,
-                                 'previous': previous, 'sigma': sigma, 't_star': int(chain_args[0])}
+            e2 = max(e2, float(lead_err(mid[:n_fp32], ref).max()))
+        previous, floor, floor2 = (self.spec_recheck_margin, self.spec_recheck_margin2), self.floor_spec, self.floor_spec2
+        new2 = max(floor2, headroom * e2)
+        new = max(floor, headroom * e + new2, TAIL_Z * s + new2)
+        self.set_spec_recheck_margin(new, calibrated=True); self.set_spec_recheck_margin2(new2, calibrated=True)
+        self.spec_calibration = {'e': e, 's': s, 'e2': e2, 'tau_spec': new, 'tau_spec2': new2, 'n': n, 'n_fp32': n_fp32, 'clips': len(clips),
+                                 'headroom': headroom, 'floor': floor, 'floor2': floor2, 'previous': previous, 'sigma': sigma,
+                                 't_star': int(chain_args[0])}
         return new, e, s
 
     def eval_samples(self, clip: torch.Tensor, sigma: float, sqrt_abar_star: float, t: int, c_a: float, c_b: float,
@@ -456,6 +488,10 @@ class Engine:
         self._load(fold_resnext29_state_dict(state_dict))
         self.has_classifier = True
         self.classifier_owner, self.classifier_kind = state_fingerprint(state_dict), 'resnext29'
+        if self.precision == EXACT:            # the committed bound for this classifier kind (widen-only, like a calibration)
+            self.floor1 = max(self.floor1, self._committed_margin1())
+            if self.recheck_margin < self.floor1:
+                self.set_recheck_margin(self.floor1, calibrated=True)
 
     # ------------------------------------------------------------------ helpers
     def _wave(self, x: torch.Tensor) -> torch.Tensor:
@@ -526,12 +562,16 @@ class Engine:
         assert x.dim() == 3 and tuple(x.shape[1:]) == (32, 32), 'expected [B,32,32], got %s' % (tuple(x.shape),)
         return x.contiguous().float()
 
-    def unet_eps(self, x_t: torch.Tensor, t: int) -> torch.Tensor:
-        """eps = UNetModel(x_t, t * ones): [B,1,32,32] or [B,32,32] -> [B,32,32]."""
+    def unet_eps(self, x_t: torch.Tensor, t: int, tier: Optional[int] = None) -> torch.Tensor:
+        """eps = UNetModel(x_t, t * ones): [B,1,32,32] or [B,32,32] -> [B,32,32].  tier: None = the mode's tier of the map-returning
+        surfaces (dmad_unet_eps); 0 exact fp32 / 1 16-bit / 2 split-f16 explicitly (dmad_unet_eps_tier)."""
         x = self._spec(x_t)
         out = torch.empty_like(x)
         for s, e in self._chunks(x.shape[0]):
-            check(self.lib.dmad_unet_eps(self._h, _ptr(x[s:e]), int(t), e - s, _ptr(out[s:e]), _stream()))
+            if tier is None:
+                check(self.lib.dmad_unet_eps(self._h, _ptr(x[s:e]), int(t), e - s, _ptr(out[s:e]), _stream()))
+            else:
+                check(self.lib.dmad_unet_eps_tier(self._h, _ptr(x[s:e]), int(t), e - s, int(tier), _ptr(out[s:e]), _stream()))
         return out
 
     def unet_p_sample(self, x: torch.Tensor, t: int, c_a: float, c_b: float, c_1: float, c_2: float, c_sig: float,
@@ -744,6 +784,45 @@ def conv_h16_up2(x_half: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Ten
         res = res.contiguous()
     check(lib.dmad_conv_h16_up2(_ptr(x_half), _ptr(w), _ptr(bias), _ptr(res), B, H, M, K, _ptr(out32), _ptr(out16), _ptr(stats), _stream()))
     return out32, out16, stats
+
+
+def split_f16(x: torch.Tensor) -> torch.Tensor:
+    """dmad_split_f16: the split-f16 storage form (hi / lo f16 pairs in the bytes of the floats) of an fp32 CUDA tensor whose last dimension is a
+    multiple of 4; returned as a float32 tensor of the same shape (its bits are NOT floats)."""
+    lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(lib.dmad_split_f16(_ptr(x), x.numel(), _ptr(y), _stream()))
+    return y
+
+
+def conv_x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, relu: bool = False,
+            res: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None, out_split: bool = False) -> torch.Tensor:
+    """dmad_conv_x3 — the split-f16 conv GEMM as a standalone op (test hook).  x: fp32 NHWC [B,H,H,Cx], x2: optional second map whose
+    channels follow x's; w: fp32 [taps, M, K]; bias fp32 [M]; res fp32 [B,Ho,Ho,M].  Operands are converted with split_f16 here."""
+    lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float32 and w.is_cuda and w.dtype == torch.float32 and x.dim() == 4 and w.dim() == 3
+    B, H, W_, cx = x.shape
+    assert H == W_
+    taps, M, K = w.shape
+    xs, ws = split_f16(x), split_f16(w)
+    x2s, ksplit = None, 0
+    if x2 is not None:
+        assert x2.shape[:3] == x.shape[:3] and cx + x2.shape[3] == K
+        x2s, ksplit = split_f16(x2), cx
+    else:
+        assert cx == K
+    Ho = (H - 1) // stride + 1
+    out = torch.empty((B, Ho, Ho, M), device=x.device, dtype=torch.float32)
+    if bias is not None:
+        bias = bias.detach().contiguous().float()
+    if res is not None:
+        assert tuple(res.shape) == (B, Ho, Ho, M) and res.dtype == torch.float32
+        res = res.contiguous()
+    check(lib.dmad_conv_x3(_ptr(xs), _ptr(x2s), int(ksplit), _ptr(ws), _ptr(bias), _ptr(res), B, H, M, K, taps, int(stride), 1 if relu else 0,
+                           1 if out_split else 0, _ptr(out), _stream()))
+    return out
 
 
 def conv_h16_stats(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, res: Optional[torch.Tensor] = None):

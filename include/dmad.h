@@ -171,10 +171,13 @@ int dmad_classify(dmad_engine* e, const float* spec, int32_t B, float* logits, d
  * reference's certification script (certified_robustness_eval.py:57; models/resnext.py:23-142) — also hold a 16-BIT TIER of it:
  * every conv (1x1 reduce / expand / shortcut, the grouped 3x3) on f16 operands with fp32 accumulation, the eval-mode BatchNorm
  * scale folded into the f16 weights, shift / shortcut add / ReLU in fp32, maps kept as f16 between the convs; average pool and
- * the linear head stay fp32.  Tier 1 of dmad_smooth_votes (and the mode-default path of dmad_eval_samples)
- * runs it unless the engine is in DMAD_MODE_FP32; the recheck tiers, dmad_query_logits and dmad_classify always use the fp32 matrix cores, so a
- * re-evaluated sample's logits are the fp32 path's.  dmad_classify_tier evaluates an explicit tier (0: fp32, 1: 16-bit; VGG19_bn
- * has no 16-bit tier and is served on fp32 either way) — test / measurement hook. */
+ * the linear head stay fp32.  It is the classifier of DMAD_MODE_FAST (the vote loops' pass and the mode-default path of
+ * dmad_eval_samples there).  The exact-vote mode keeps the classifier on the fp32 matrix cores in EVERY tier since round 5: measured
+ * on the calibrated synthetic stand-in, the f16 classifier's leader-difference error is 0.08-0.16 against 0.016-0.030 for the f16
+ * WaveNet in front of the fp32 classifier (profiles/r05b_resnext29_error_attribution.json) — a recheck bound covering it would send
+ * a quarter of the samples to the recheck tiers.  dmad_query_logits and dmad_classify always use the fp32 matrix cores.
+ * dmad_classify_tier evaluates an explicit tier (0: fp32, 1: 16-bit; VGG19_bn has no 16-bit tier and is served on fp32 either way)
+ * — test / measurement hook. */
 int dmad_classify_tier(dmad_engine* e, const float* spec, int32_t B, int32_t tier, float* logits, dmad_stream s);
 
 /* The Monte Carlo loop of RobustCertificate.smooth_predict (+ forward, compute_t_star's result),
@@ -255,18 +258,30 @@ int dmad_spec_smooth_votes(dmad_engine* e, const float* clip, float sigma, int32
                            int32_t batch, uint64_t seed, uint64_t sample0, int64_t* counts, float* logits_out, float* spec_out, dmad_stream s);
 
 /* The UNet's tiers.  Engines of precision DMAD_BF16 / DMAD_EXACT hold, beside the exact-fp32 UNet, a 16-BIT TIER of it: every
- * conv / 1x1 (unet.py:107-252) on f16 operands with fp32 accumulation (v_mfma_f32_16x16x32_f16), GroupNorm, softmax, bias and
- * residual sums and the maps themselves in fp32.  dmad_unet_eps / dmad_unet_p_sample — map-returning surfaces without a recheck —
- * evaluate the exact-fp32 UNet unless the engine is in DMAD_MODE_FAST (or dmad_set_waveform_tier chose the 16-bit tier): the 16-bit
- * tier is opt-in there (DMAD_FP32 engines have only the fp32 one).  In DMAD_MODE_EXACT_VOTES
- * dmad_spec_smooth_votes runs every sample's chain on the 16-bit tier, queues the samples whose top-2 logit margin is below
- * tau_spec (dmad_set_spec_recheck_margin; default 0.5 = 1.66 x the largest leader-difference error (0.30) of the 16-bit chain measured on 6 144 samples) and re-runs their WHOLE chain on the exact-fp32
- * UNet from the same Philox keys — the same empirical guarantee as the waveform loop's (dmad_set_mode).
- * dmad_spec_recheck_stats: samples voted by dmad_spec_smooth_votes, samples whose chain was re-run in fp32. */
+ * conv / 1x1 (unet.py:107-252) on f16 operands with fp32 accumulation (v_mfma_f32_16x16x32_f16); the hidden state exists as f16 maps
+ * only, GroupNorm statistics are sums over the f16-rounded outputs taken in the producing GEMM's epilogue (evaluated as E[x^2] - mean^2
+ * in fp32), softmax, bias and residual sums in fp32 (measured: 4e-3 of max|eps| per evaluation).  DMAD_EXACT engines also hold a
+ * SPLIT-F16 MIDDLE TIER: the fp32 pipeline (fp32 maps, GroupNorm, softmax, residual sums) with every conv / 1x1 on split-f16 operands
+ * (three f16 MFMAs per product, ~22 significant bits: fp32-grade at several times the fp32 matrix rate).
+ * dmad_unet_eps / dmad_unet_p_sample — map-returning surfaces without a recheck — evaluate the exact-fp32 UNet unless the engine is in
+ * DMAD_MODE_FAST (or dmad_set_waveform_tier chose the 16-bit tier): the 16-bit tier is opt-in there (DMAD_FP32 engines have only the
+ * fp32 one).  In DMAD_MODE_EXACT_VOTES dmad_spec_smooth_votes runs every sample's chain on the 16-bit tier, queues the samples whose
+ * top-2 logit margin is below tau_spec (dmad_set_spec_recheck_margin; default 0.13 = 1.5 x the largest leader-difference error (0.084;
+ * Gaussian scale 0.020) of the 16-bit chain measured on 6 144 samples of the calibrated synthetic stand-in) and
+ * re-runs their WHOLE chain from the same Philox keys on the split-f16 tier; a sample whose margin is still below tau_spec2
+ * (dmad_set_spec_recheck_margin2, default 5e-4 = 2.2 x its measured error; < 0: no middle tier) goes on to the exact-fp32 UNet.  An EMPIRICAL guarantee like the
+ * waveform loop's (dmad_set_mode), and like it a property of the WEIGHTS: calibrate (Engine.calibrate_spec_recheck) before certifying
+ * with other checkpoints.  dmad_spec_recheck_stats: samples voted by dmad_spec_smooth_votes, samples whose chain left the 16-bit tier;
+ * dmad_spec_recheck_stats2: + those that reached the exact-fp32 UNet. */
+/* dmad_unet_eps on an explicit tier (0: exact fp32, 1: 16-bit, 2: split-f16) — test / measurement hook (DMAD_ERR_STATE for a tier the
+ * engine's precision does not hold). */
+int dmad_unet_eps_tier(dmad_engine* e, const float* x_t, int32_t t, int32_t B, int32_t tier, float* eps, dmad_stream s);
 int dmad_set_spec_recheck_margin(dmad_engine* e, float tau);
 int dmad_spec_recheck_stats(dmad_engine* e, int64_t* samples, int64_t* rechecked, int32_t reset);
-/* The chain of dmad_spec_smooth_votes for an explicit LIST of Monte Carlo samples on an explicit UNet tier (0: exact fp32, 1: 16-bit;
- * the classifier is the fp32 one on tier 0): row i of logits_out [n][num_classes] / spec_out [n][32][32] (either optional) is sample
+int dmad_set_spec_recheck_margin2(dmad_engine* e, float tau2);
+int dmad_spec_recheck_stats2(dmad_engine* e, int64_t* samples, int64_t* rechecked, int64_t* rechecked_fp32, int32_t reset);
+/* The chain of dmad_spec_smooth_votes for an explicit LIST of Monte Carlo samples on an explicit UNet tier (0: exact fp32, 1: 16-bit,
+ * 2: split-f16; the classifier is the fp32 one on tiers 0 and 2): row i of logits_out [n][num_classes] / spec_out [n][32][32] (either optional) is sample
  * idx[i] (device int64, GLOBAL indices: every draw of the row is Philox-keyed by it).  Nothing votes, no queue is touched — the hook
  * behind the calibration of tau_spec for the resident weights (Engine.calibrate_spec_recheck) and RobustCertificate.certify(audit=k)
  * on the spec-domain loop. */
@@ -346,6 +361,16 @@ int dmad_conv_h16_stats(const uint16_t* x, const uint16_t* w, const float* bias,
 int dmad_groupnorm16_apply(const uint16_t* x, const float* st, const uint16_t* x2, const float* st2, int32_t c1, const float* gamma,
                            const float* beta, const float* ss, int32_t silu, int32_t B, int32_t HW, int32_t C, uint16_t* y16, float* y32,
                            dmad_stream s);
+
+/* Test hooks of the split-f16 conv GEMM (csrc/gemm_f32.hip, gemm_x3_kernel in its NHWC form: the kernel behind the UNet's middle tier),
+ * standalone.  dmad_split_f16: y = the split-f16 storage form of the n fp32 values x (n % 4 == 0; hi = f16(v), lo = f16((v - hi) 2^11), four
+ * values per 16-byte chunk: the bytes of four floats; x == y allowed).  dmad_conv_x3: NHWC convolution of split-format operands — x
+ * [B][H][H][K] (or x | x2 with ksplit channels in x), w [taps][M][K] (taps 9 = 3x3 zero padding 1, or 1), fp32 bias [M], optional fp32
+ * residual [N][M], stride 1 / 2, optional ReLU — every product as three f16 MFMAs; out [N][M] fp32, or in the split format (out_split).
+ * M % 128 == 0, K % 32 == 0 (ksplit % 32 == 0). */
+int dmad_split_f16(const float* x, int64_t n, float* y, dmad_stream s);
+int dmad_conv_x3(const float* x, const float* x2, int32_t ksplit, const float* w, const float* bias, const float* res, int32_t B, int32_t H,
+                 int32_t M, int32_t K, int32_t taps, int32_t stride, int32_t relu, int32_t out_split, float* out, dmad_stream s);
 
 /* Bytes of device memory held by the engine. */
 int64_t dmad_device_bytes(const dmad_engine* e);

@@ -22,6 +22,7 @@ pytestmark = pytest.mark.gpu
 FP32_TOL = 2e-5
 BF16_MAX_TOL, BF16_RMS_TOL = 3e-2, 2.5e-2
 F16_MAX_TOL = 4e-3
+UNET_X3_TOL = 1e-4          # the UNet's split-f16 middle tier vs the reference fixture (fp32 pipeline, ~22-bit products)
 UNET_F16_TOL = 6e-3         # the UNet's 16-bit tier vs the reference fixture (f16 maps between ~180 ops): measured 4.1e-3 / 2.2e-3 of max|eps| at t = 3 / 40 (tools/gpu_unet_tolerance.py)
 UNET_FP32_TOL = 1e-5        # the exact-fp32 UNet tier vs the reference fixture: measured 2.6e-6 / 1.7e-6 at t = 3 / 40 (tools/gpu_unet_tolerance.py)
 SPLIT_TOL = 8e-5            # the split-f16 tier (three f16 MFMAs per product): what an exact-vote engine's waveform surfaces deliver
@@ -698,18 +699,23 @@ def test_resnext29_vs_reference_fixture(golden_dir, orc):
 
 
 def test_resnext29_16bit_tier_and_exact_votes(golden_dir, weights, sched):
-    """The reference script's DEFAULT classifier (certified_robustness_eval.py:57; models/resnext.py:23-142) on its 16-bit tier:
-    (1) dmad_classify_tier(1) — every conv on f16 operands through gemm_h16 (grouped 3x3, stride 2, 1x1 with the BN scale folded
-    into the weights) — within the f16 tolerance of the logits of the imported reference class, batch invariant, and really another
-    arithmetic than the fp32 tier; dmad_classify itself stays the fp32 tier; (2) the exact-vote loop with the f16 classifier in
-    tier 1 and the fp32 classifier in the recheck tiers: counts == the all-fp32 counts, bit for bit, on 3 clips x 3 sigmas x 512
-    = 4 608 samples, re-evaluated rows of logits_out bit-identical to the fp32 path's."""
+    """The reference script's DEFAULT classifier (certified_robustness_eval.py:57; models/resnext.py:23-142) with its calibrated
+    synthetic weights (tests/golden/make_classifier_calib.py: votes spread over many classes, margins of order one).
+    (1) its 16-bit tier, dmad_classify_tier(1) — every conv on f16 operands through gemm_h16 (grouped 3x3, stride 2, 1x1 with the BN
+    scale folded into the weights) — within the f16 tolerance of the logits of the imported reference class, batch invariant, and
+    really another arithmetic than the fp32 tier; dmad_classify itself stays the fp32 tier.
+    (2) the exact-vote loop: counts == the all-fp32 counts, bit for bit, on 3 clips x 3 sigmas x 512 = 4 608 samples, and NOT
+    vacuously: every cell votes at least three classes, no class takes more than 70 %, samples ARE rechecked (on both recheck
+    tiers over the run), the rows that reached fp32 are the fp32 path's bit for bit.  Since round 5 the exact-vote mode keeps the
+    classifier on the fp32 matrix cores in every tier (the f16 classifier's leader-difference error, measured here too, is several
+    times the f16 WaveNet's and does NOT fit under the bound); the fast mode runs the f16 classifier."""
     from dmad_hip import engine as E
     z = G(golden_dir, 'resnext29.npz')
     sd = synth.resnext29_state_dict(int(z['seed']))
     eng = E.Engine(max_batch=64, precision=E.EXACT, recheck_batch=32)
     eng.load_wavenet(weights[0])
     eng.load_resnext29(sd)
+    assert eng.recheck_margin == E.DEFAULT_RECHECK_MARGIN_RESNEXT29[E.HALF_F16]      # the committed bound of this classifier kind
     spec = torch.from_numpy(z['spec_in']).cuda()
     l32, l16 = eng.classify_tier(spec, 0), eng.classify_tier(spec, 1)
     assert torch.equal(l32, eng.classify(spec))                                   # dmad_classify = the fp32 tier
@@ -721,7 +727,7 @@ def test_resnext29_16bit_tier_and_exact_votes(golden_dir, weights, sched):
     assert torch.equal(big[:4], l16) and torch.equal(big[156:], l16)
     hp, coef = sched
     ab = hp['Alpha_bar']
-    N, worst = 512, 0.0
+    N, worst, worst_fast, rechecked, reached_fp32 = 512, 0.0, 0.0, 0, 0
     for ci in (0, 1, 2):
         clip = torch.from_numpy(synth.synthetic_clip(ci)).cuda()
         for sigma in (0.25, 0.5, 1.0):
@@ -732,21 +738,32 @@ def test_resnext29_16bit_tier_and_exact_votes(golden_dir, weights, sched):
                 eng.set_mode(mode)
                 eng.recheck_stats(reset=True)
                 c, l, _ = eng.smooth_votes(clip, sigma, sc, t, *coef(t), N, seed=700 + ci, sample0=9000, want_logits=True)
-                out[mode] = (c.cpu().tolist(), l.cpu().numpy().astype(np.float64), eng.recheck_stats())
+                out[mode] = (c.cpu().tolist(), l.cpu().numpy().astype(np.float64), eng.recheck_stats(detail=True))
             fast, f32, ex = out[E.MODE_FAST], out[E.MODE_FP32], out[E.MODE_EXACT_VOTES]
             assert sum(fast[0]) == sum(f32[0]) == sum(ex[0]) == N
+            assert sum(1 for v in f32[0] if v > 0) >= 3 and max(f32[0]) <= 0.7 * N, f32[0]          # a non-degenerate stand-in
             assert ex[0] == f32[0], (ci, sigma, ex[0], f32[0])
             assert (ex[1].argmax(1) == f32[1].argmax(1)).all()
-            e = fast[1] - f32[1]
-            lead = np.abs(e - e[np.arange(N), f32[1].argmax(1)][:, None]).max()
-            worst = max(worst, float(lead))
-            srt = np.sort(fast[1].astype(np.float32), 1)
+            # tier 1 of the exact-vote mode = f16 WaveNet + fp32 classifier: its rows where nothing was rechecked
+            idx = torch.arange(N, dtype=torch.int64, device='cuda') + 9000
+            eng.set_mode(E.MODE_EXACT_VOTES)
+            t1 = eng.eval_samples(clip, sigma, sc, t, *coef(t), idx, path=0, seed=700 + ci).cpu().numpy().astype(np.float64)
+            e = t1 - f32[1]
+            worst = max(worst, float(np.abs(e - e[np.arange(N), f32[1].argmax(1)][:, None]).max()))
+            ef = fast[1] - f32[1]
+            worst_fast = max(worst_fast, float(np.abs(ef - ef[np.arange(N), f32[1].argmax(1)][:, None]).max()))
+            srt = np.sort(t1.astype(np.float32), 1)
             low = ~((srt[:, -1] - srt[:, -2]) >= np.float32(eng.recheck_margin))
-            assert ex[2] == (N, int(low.sum()))
-            # a rechecked row carries the logits of a higher tier; the rows that reached fp32 are the fp32 path's bit for bit
+            assert ex[2][:2] == (N, int(low.sum()))
+            assert (ex[1][~low] == t1[~low]).all()                                # what voted on tier 1 kept its tier-1 logits
             same = (ex[1] == f32[1]).all(1)
-            assert int(same.sum()) >= eng.recheck_stats(detail=True)[2]
-    assert worst < eng.recheck_margin, (worst, eng.recheck_margin)                # the bound covers tier 1's error WITH the f16 classifier
+            assert int(same.sum()) >= ex[2][2]                                    # the rows that reached fp32 are the fp32 path's bit for bit
+            rechecked += ex[2][1]
+            reached_fp32 += ex[2][2]
+    assert rechecked >= 0.01 * 9 * N, rechecked                                   # the recheck hand-over is exercised ...
+    assert reached_fp32 >= 1                                                      # ... down to the exact-fp32 tier
+    assert worst < eng.recheck_margin, (worst, eng.recheck_margin)                # the bound covers tier 1's error with the fp32 classifier
+    assert worst_fast > eng.recheck_margin, worst_fast                            # ... and would NOT cover the f16 classifier's (why it is FAST-only)
     eng.close()
 
 
@@ -815,6 +832,46 @@ def test_gemm_h16_family_vs_torch_conv(case):
     assert worst16 < 2e-2, worst16
     assert torch.equal(o16, o32.half())                     # the f16 twin IS the rounded fp32 output
 
+
+
+X3_CASES = [   # B, H, cin, cout, taps, stride, c1 (two-part input), residual, relu
+    (2, 32, 128, 128, 9, 1, 0, True, False), (1, 32, 128, 128, 9, 1, 0, False, False),         # the 128 x 256 tile (M = 128), one image
+    (3, 16, 256, 256, 9, 1, 0, False, True), (2, 32, 256, 256, 9, 2, 0, False, False),         # the 256 x 128 tile; stride 2
+    (2, 16, 384, 128, 1, 1, 256, False, False), (5, 8, 512, 256, 9, 1, 256, True, False),      # two-part input: 1x1 skip conv, 3x3 with residual
+    (7, 4, 256, 768, 1, 1, 0, False, False), (65, 32, 384, 128, 9, 1, 256, True, False),       # qkv-like 1x1 on 4x4 maps; many tiles with an N tail
+]
+
+
+@pytest.mark.parametrize('case', X3_CASES, ids=lambda c: 'B%d_H%d_%dto%d_t%d_s%d_c1%d_r%d_relu%d' % tuple(int(v) for v in c))
+def test_gemm_x3_conv_vs_torch(case):
+    """The split-f16 conv GEMM (gemm_x3_kernel in its NHWC form, csrc/gemm_f32.hip: the UNet's middle tier — 3x3 / 1x1, stride 2,
+    two-part input, residual, both tile shapes) through dmad_conv_x3 against a float64 torch convolution of the same fp32 operands
+    (improved_diffusion/unet.py:107-252 are the callers' ops): every product is three f16 MFMAs on hi / lo pairs, ~22 significant
+    bits — the result must be fp32-grade (1e-5 of the output scale; the f16 family's is 2e-3), a sample's result must not depend on
+    its batch, and out_split writes the split form of the same values."""
+    from dmad_hip import engine as E
+    B, H, cin, cout, taps, stride, c1, with_res, relu = case
+    g = torch.Generator().manual_seed(2000 + B + H + cin)
+    x = (torch.rand(B, H, H, cin, generator=g) * 2 - 1).cuda()
+    w = ((torch.rand(taps, cout, cin, generator=g) * 2 - 1) * 0.1).cuda()
+    bias = (torch.rand(cout, generator=g) * 2 - 1).cuda()
+    Ho = (H - 1) // stride + 1
+    res = (torch.rand(B, Ho, Ho, cout, generator=g) * 2 - 1).cuda() if with_res else None
+    xa, xb = (x[..., :c1].contiguous(), x[..., c1:].contiguous()) if c1 else (x, None)
+    out = E.conv_x3(xa, w, bias, stride=stride, relu=bool(relu), res=res, x2=xb)
+    k = 3 if taps == 9 else 1
+    wt = w.double().reshape(k, k, cout, cin).permute(2, 3, 0, 1)
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wt, bias=bias.double(), stride=stride, padding=k // 2).permute(0, 2, 3, 1)
+    if res is not None:
+        ref = ref + res.double()
+    if relu:
+        ref = torch.relu(ref)
+    err = float((out.double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 1e-5, err
+    solo = E.conv_x3(xa[:1], w, bias, stride=stride, relu=bool(relu), res=None if res is None else res[:1], x2=None if xb is None else xb[:1])
+    assert torch.equal(solo, out[:1])                                              # no split-K: batch-invariant bits
+    sp = E.conv_x3(xa, w, bias, stride=stride, relu=bool(relu), res=res, x2=xb, out_split=True)
+    assert torch.equal(sp.view(torch.int32), E.split_f16(out).view(torch.int32))   # the split form of the same fp32 values
 
 
 @pytest.mark.parametrize('case', [(64, 32, 256, 256, False), (260, 16, 256, 256, True), (1027, 8, 256, 512, False), (4100, 4, 128, 256, True)],
@@ -964,12 +1021,23 @@ def test_unet_purifier_vs_reference_fixture(golden_dir):
         assert 1e-5 < relmax(e16.cpu().numpy(), z['eps_t%d' % t]) < UNET_F16_TOL, (t, relmax(e16.cpu().numpy(), z['eps_t%d' % t]))
     solo16 = model(torch.from_numpy(z['x_t3'][1:]).cuda(), torch.tensor([3]))
     assert torch.equal(solo16, model(torch.from_numpy(z['x_t3']).cuda(), torch.tensor([3, 3]))[1:])    # batch invariance holds on this tier too
+    # the split-f16 middle tier (fp32 pipeline, every conv / 1x1 as three f16 MFMAs on hi / lo pairs): the same fixtures, fp32-grade
+    eng.set_mode(E.MODE_EXACT_VOTES)
+    for t in (3, 40):
+        xt = torch.from_numpy(z['x_t%d' % t]).cuda()
+        ex3 = eng.unet_eps(xt, t, tier=2)
+        err3 = relmax(ex3.cpu().numpy(), z['eps_t%d' % t][:, 0])
+        assert 0 < err3 < UNET_X3_TOL, (t, err3)
+        assert torch.equal(eng.unet_eps(xt, t, tier=0), eng.unet_eps(xt, t)) and not torch.equal(ex3, eng.unet_eps(xt, t, tier=0))
+        assert torch.equal(eng.unet_eps(xt[1:], t, tier=2), ex3[1:])                               # batch invariance (no split-K on this tier)
     with pytest.raises(E.DmadError):
         eng.load_wavenet(synth.wavenet_state_dict(1234))       # created with with_wavenet = 0
     eng.close()
     f32 = E.Engine(max_batch=2, precision=E.FP32, with_classifier=False, with_wavenet=False)
     create_improved_diffusion(None, reverse_timestep=3, state_dict=synth.unet_state_dict(int(z['seed'])), engine=f32)
     assert relmax(f32.unet_eps(torch.from_numpy(z['x_t3']).cuda(), 3).cpu().numpy(), z['eps_t3'][:, 0]) < UNET_FP32_TOL      # FP32 engines: the fp32 tier only
+    with pytest.raises(E.DmadError):
+        f32.unet_eps(torch.from_numpy(z['x_t3']).cuda(), 3, tier=2)
     f32.close()
 
 
@@ -1593,17 +1661,25 @@ def test_config5_spec_domain_vote_loop(golden_dir):
 
 
 def test_config5_exact_votes_on_the_16bit_unet_tier():
-    """BASELINE C5 in the exact-vote mode: the whole chain on the UNet's 16-bit tier, every sample whose top-2 margin is below
-    tau_spec re-run on the exact-fp32 UNet from the same Philox keys.  Counts equal the fp32 engine mode's on the same keys (also
-    with every sample forced through the recheck, and across shards), the rechecked rows of logits_out are the fp32 tier's bit
-    for bit, the 16-bit tier alone stays within its error statistic, and the statistics count what was re-run."""
+    """BASELINE C5 in the exact-vote mode: the whole chain on the UNet's 16-bit tier; every sample whose top-2 margin is below
+    tau_spec re-runs its chain from the same Philox keys on the split-f16 tier, and on the exact-fp32 UNet if its margin there is still
+    below tau_spec2.  With the VGG19_bn calibrated for the spec chain's output distribution (tests/golden/make_classifier_calib.py) the
+    check is NOT vacuous: several classes vote, samples ARE rechecked.  Counts equal the fp32 engine mode's on the same keys (also
+    with every sample forced through both recheck tiers, without the middle tier, and across shards), every row of logits_out carries
+    the logits of the tier that settled it, the 16-bit and split-f16 tiers stay within their bounds, and the statistics count what
+    was re-run."""
     from diffusion_models.improved_diffusion_ddpm import create_improved_diffusion
     from dmad_hip import engine as E
     eng = E.Engine(max_batch=64, precision=E.EXACT, with_wavenet=False)
-    eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321))
+    eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321, calibrated='c5'))
+    assert eng.spec_recheck_margin == E.DEFAULT_SPEC_RECHECK_MARGIN and eng.spec_recheck_margin2 == E.DEFAULT_SPEC_RECHECK_MARGIN2
     pur = create_improved_diffusion(None, reverse_timestep=5, state_dict=synth.unet_state_dict(31), engine=eng)
     coef = tuple(pur.purify_coefficients())
-    N = 384
+    N, total_re = 384, 0
+
+    def margin(l):
+        top2 = l.topk(2, dim=1).values
+        return top2[:, 0] - top2[:, 1]
     for ci, sigma in ((4, 0.5), (5, 1.0)):
         clip = torch.from_numpy(synth.synthetic_clip(ci)).cuda()
         args = (clip, sigma) + coef + (-100.0, 38.22)
@@ -1611,27 +1687,45 @@ def test_config5_exact_votes_on_the_16bit_unet_tier():
         c32, l32, _ = eng.spec_smooth_votes(*args, N, seed=11, want_logits=True)
         eng.set_mode(E.MODE_FAST)
         c16, l16, _ = eng.spec_smooth_votes(*args, N, seed=11, want_logits=True)
+        assert sum(1 for v in c32.tolist() if v > 0) >= 3 and max(c32.tolist()) <= 0.8 * N, c32.tolist()      # a non-degenerate stand-in
+        idx = torch.arange(N, dtype=torch.int64, device='cuda')
+        l2 = eng.spec_eval_samples(clip, sigma, *coef, -100.0, 38.22, idx, tier=2, seed=11)                 # every chain on the split-f16 tier
         e = (l16 - l32).double()
         lead = float((e - e.gather(1, l32.argmax(1, keepdim=True))).abs().max())
         assert 1e-5 < lead < eng.spec_recheck_margin, lead                       # the statistic the bound covers, with room
+        e2 = (l2 - l32).double()
+        lead2 = float((e2 - e2.gather(1, l32.argmax(1, keepdim=True))).abs().max())
+        assert 0 < lead2 < eng.spec_recheck_margin2 and lead2 < 0.05 * lead, (lead2, lead)      # fp32-grade: far below the 16-bit tier's
         eng.set_mode(E.MODE_EXACT_VOTES)
         eng.spec_recheck_stats(reset=True)
         cx, lx, _ = eng.spec_smooth_votes(*args, N, seed=11, want_logits=True)
-        voted, re = eng.spec_recheck_stats()
-        assert cx.tolist() == c32.tolist() and voted == N and 0 <= re < N
-        top2 = l16.topk(2, dim=1).values
-        low = (top2[:, 0] - top2[:, 1]) < eng.spec_recheck_margin
-        assert int(low.sum()) == re and torch.equal(lx[low], l32[low]) and torch.equal(lx[~low], l16[~low])
+        voted, re, re32 = eng.spec_recheck_stats(detail=True)
+        assert cx.tolist() == c32.tolist() and voted == N and 0 < re < N
+        low = margin(l16) < eng.spec_recheck_margin
+        low2 = low & (margin(l2) < eng.spec_recheck_margin2)
+        assert int(low.sum()) == re and int(low2.sum()) == re32
+        want = torch.where(low2[:, None], l32, torch.where(low[:, None], l2, l16))
+        assert torch.equal(lx, want)                                             # every row: the logits of the tier that settled it
+        total_re += re
         a, _, _ = eng.spec_smooth_votes(*args, 150, batch=40, seed=11)           # shards of the same index range
         b, _, _ = eng.spec_smooth_votes(*args, N - 150, batch=64, seed=11, sample0=150)
         assert (a + b).tolist() == c32.tolist()
+        eng.set_spec_recheck_margin2(-1.0)                                       # no middle tier: queued samples straight to fp32
+        eng.spec_recheck_stats(reset=True)
+        cn, ln, _ = eng.spec_smooth_votes(*args, N, seed=11, want_logits=True)
+        assert cn.tolist() == c32.tolist() and eng.spec_recheck_stats(detail=True) == (N, re, re)
+        assert torch.equal(ln, torch.where(low[:, None], l32, l16))
+        eng.set_spec_recheck_margin2(E.DEFAULT_SPEC_RECHECK_MARGIN2)
+    assert total_re >= 8, total_re
     old = eng.spec_recheck_margin
-    eng.set_spec_recheck_margin(1e30)                                            # everything through the fp32 re-run
+    eng.set_spec_recheck_margin(1e30)                                            # everything through the recheck tiers ...
+    eng.set_spec_recheck_margin2(1e30)                                           # ... down to fp32
     cz, lz, _ = eng.spec_smooth_votes(*args, 100, batch=32, seed=11, want_logits=True)
     eng.set_spec_recheck_margin(old)
+    eng.set_spec_recheck_margin2(E.DEFAULT_SPEC_RECHECK_MARGIN2)
     assert torch.equal(lz, l32[:100]) and int(cz.sum()) == 100
-    # edge cases: an empty loop votes nothing; a NaN clip gives NaN logits on the 16-bit tier, is queued, re-run on the fp32 tier and
-    # votes as torch.max does (first NaN index), exactly like the fp32 mode
+    # edge cases: an empty loop votes nothing; a NaN clip gives NaN logits on the 16-bit tier, is queued, stays NaN on the split-f16 tier,
+    # reaches the fp32 tier and votes as torch.max does (first NaN index), exactly like the fp32 mode
     c0, _, _ = eng.spec_smooth_votes(*args, 0, seed=11)
     assert c0.tolist() == [0] * 10
     bad = clip.clone()
@@ -1639,7 +1733,7 @@ def test_config5_exact_votes_on_the_16bit_unet_tier():
     bargs = (bad, sigma) + coef + (-100.0, 38.22)
     eng.spec_recheck_stats(reset=True)
     cn, ln, _ = eng.spec_smooth_votes(*bargs, 5, batch=4, seed=1, want_logits=True)
-    assert bool(torch.isnan(ln).all()) and cn.tolist() == [5, 0, 0, 0, 0, 0, 0, 0, 0, 0] and eng.spec_recheck_stats() == (5, 5)
+    assert bool(torch.isnan(ln).all()) and cn.tolist() == [5, 0, 0, 0, 0, 0, 0, 0, 0, 0] and eng.spec_recheck_stats(detail=True) == (5, 5, 5)
     eng.set_mode(E.MODE_FP32)
     assert eng.spec_smooth_votes(*bargs, 5, batch=4, seed=1)[0].tolist() == cn.tolist()
     eng.close()
@@ -1658,7 +1752,7 @@ def test_spec_tier_calibration_and_audit(tmp_path):
     from dmad_hip.transforms import MelSpectrogramDB
     from robustness_eval.certified_robust import RobustCertificate
     eng = E.Engine(max_batch=32, precision=E.EXACT, with_wavenet=False)
-    csd = synth.vgg19_bn_state_dict(4321)
+    csd = synth.vgg19_bn_state_dict(4321, calibrated='c5')
     eng.load_vgg19_bn(csd)
     pur = create_improved_diffusion(None, reverse_timestep=4, state_dict=synth.unet_state_dict(31), engine=eng)
     chain = tuple(pur.purify_coefficients()) + (-100.0, 38.22)
@@ -1672,6 +1766,8 @@ def test_spec_tier_calibration_and_audit(tmp_path):
     idx = torch.tensor([3, 17, 39, 0], device='cuda')
     assert torch.equal(eng.spec_eval_samples(clip, 0.5, *chain, idx, tier=0, seed=5), l32[idx.cpu()])
     assert torch.equal(eng.spec_eval_samples(clip, 0.5, *chain, idx, tier=1, seed=5), l16[idx.cpu()])
+    lmid = eng.spec_eval_samples(clip, 0.5, *chain, idx, tier=2, seed=5)                        # the split-f16 tier: fp32-grade
+    assert float((lmid - l32[idx.cpu()]).abs().max()) < 1e-3 and not torch.equal(lmid, l32[idx.cpu()])
     # map-returning surfaces: fp32 tier by default on an exact-vote engine, the 16-bit tier is opt-in
     x = torch.randn(2, 32, 32, generator=torch.Generator().manual_seed(1)).cuda()
     e_def = eng.unet_eps(x, 3)
@@ -1686,6 +1782,9 @@ def test_spec_tier_calibration_and_audit(tmp_path):
     tau, e, s_ = eng.calibrate_spec_recheck(clip, 0.5, chain, n=96)
     assert tau >= E.DEFAULT_SPEC_RECHECK_MARGIN and 0 < e < tau and s_ > 0 and eng.spec_recheck_margin == tau
     assert eng.spec_calibration['floor'] == E.DEFAULT_SPEC_RECHECK_MARGIN and eng.spec_calibration['t_star'] == 4
+    cal = eng.spec_calibration                                # the split-f16 tier's bound is calibrated with it (against fp32, widen-only)
+    assert 0 < cal['e2'] < cal['tau_spec2'] and cal['tau_spec2'] >= E.DEFAULT_SPEC_RECHECK_MARGIN2 and eng.spec_recheck_margin2 == cal['tau_spec2']
+    assert cal['e2'] < 0.05 * cal['e'] and cal['n_fp32'] == 48
     eng.set_spec_recheck_margin(1.25)                        # a wider bound the caller chose is a floor, too
     assert eng.calibrate_spec_recheck(clip, 0.5, chain, n=32)[0] >= 1.25
     eng.set_spec_recheck_margin(E.DEFAULT_SPEC_RECHECK_MARGIN)

@@ -46,6 +46,11 @@ for ci in CLIPS:
             torch.cuda.synchronize()
             secs[name] = time.time() - t0
             lg[name], cnt[name] = l.cpu().numpy().astype(np.float64), c.cpu().tolist()
+        # the split-f16 middle tier on the same keys (every sample through dmad_spec_eval_samples, tier 2)
+        torch.cuda.synchronize(); t0 = time.time()
+        lx = eng.spec_eval_samples(clip, sigma, *coef, -100.0, 38.22, torch.arange(N, device='cuda'), tier=2, seed=7000 + ci)
+        torch.cuda.synchronize(); secs['x3'] = time.time() - t0
+        lg['x3'] = lx.cpu().numpy().astype(np.float64)
         b, f = lg['h16'], lg['fp32']
         rows = np.arange(N)
         e_ = b - f
@@ -59,6 +64,15 @@ for ci in CLIPS:
                'margin_fp32_median': float(np.median(mf)), 'flip_margins_h16': sorted(float(v) for v in mb[flips]),
                'margin_h16_frac_below': {str(x): float((mb < x).mean()) for x in (0.005, 0.01, 0.02, 0.03, 0.05, 0.1, 0.2, 0.5)},
                'samples_per_s': {k: N / v for k, v in secs.items()}}
+        ex = lg['x3'] - f
+        lex = np.abs(ex - ex[rows, f.argmax(1)][:, None]).max(1)
+        sx = np.sort(lg['x3'], 1)
+        rec['x3'] = {'flips': int((lg['x3'].argmax(1) != f.argmax(1)).sum()), 'logit_err_max': float(np.abs(ex).max()),
+                     'leader_diff_err': {'max': float(lex.max()), 'rms': float(np.sqrt((lex ** 2).mean()))},
+                     'margin_frac_below': {str(x): float(((sx[:, -1] - sx[:, -2]) < x).mean()) for x in (1e-4, 3e-4, 1e-3, 3e-3)}}
+        e1 = b - lg['x3']                  # what calibrate_spec_recheck measures: the 16-bit tier against the split-f16 tier
+        le1 = np.abs(e1 - e1[rows, lg['x3'].argmax(1)][:, None]).max(1)
+        rec['h16_vs_x3_leader_diff_err_max'] = float(le1.max())
         report.append(rec)
         raw['bf16_c%d_s%g' % (ci, sigma)] = b.astype(np.float32)         # key names of tools/fit_recheck_tail.py ('bf16' = the 16-bit tier)
         raw['fp32_c%d_s%g' % (ci, sigma)] = f.astype(np.float32)
@@ -72,7 +86,7 @@ eng.spec_recheck_stats(reset=True)
 torch.cuda.synchronize(); t0 = time.time()
 c, _, _ = eng.spec_smooth_votes(*args, N, seed=7000 + CLIPS[-1])
 torch.cuda.synchronize(); dt = time.time() - t0
-voted, rechecked = eng.spec_recheck_stats()
-print(json.dumps({'exact_vote_mode': {'tau_spec': eng.spec_recheck_margin, 'counts': c.cpu().tolist(), 'equals_fp32': c.cpu().tolist() == report[-1]['counts_fp32'],
+voted, rechecked, re32 = eng.spec_recheck_stats(detail=True)
+print(json.dumps({'exact_vote_mode': {'tau_spec': eng.spec_recheck_margin, 'tau_spec2': eng.spec_recheck_margin2, 'rechecked_fp32': re32, 'counts': c.cpu().tolist(), 'equals_fp32': c.cpu().tolist() == report[-1]['counts_fp32'],
                                       'samples_per_s': N / dt, 'rechecked': rechecked, 'voted': voted}}), flush=True)
 eng.close()

@@ -26,6 +26,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'diffusion-model-for-audio-defense_amd')]
+from dmad_hip import _lib  # noqa: E402
+if os.environ.get('DMAD_LIB'):                   # A/B of two builds on one box (tools/layer_variants.sh)
+    _lib.LIB_PATH = os.environ['DMAD_LIB']
 from dmad_hip import engine as E, synth  # noqa: E402
 
 B = int(os.environ.get('B', 256))

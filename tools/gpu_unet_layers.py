@@ -65,9 +65,12 @@ else:
     if os.environ.get('DMAD_LIB'):               # A/B of two builds on one box: DMAD_LIB=/path/to/other/libdmad_hip.so
         _lib.LIB_PATH = os.environ['DMAD_LIB']
     from dmad_hip import engine as E, synth
-    eng = E.Engine(max_batch=B, precision=E.BF16, with_classifier=False, with_wavenet=False)     # 16-bit tier (DMAD_MODE_FAST), no WaveNet workspace
+    TIER = int(os.environ.get('TIER', 1))          # 1: the 16-bit tier (default), 0: exact fp32, 2: split-f16 (KERNEL=gemm_x3 for --analyse)
+    eng = E.Engine(max_batch=B, precision=E.EXACT if TIER == 2 else E.BF16, with_classifier=False, with_wavenet=False)     # no WaveNet workspace
     eng.load_unet(synth.unet_state_dict(5252))
     x = torch.randn(B, 32, 32, device='cuda') * 0.5
+    _eps = eng.unet_eps
+    eng.unet_eps = lambda xx, t: _eps(xx, t, tier=TIER)
     eng.unet_eps(x, 40); torch.cuda.synchronize()
     eng.unet_eps(x, 40); torch.cuda.synchronize()
     if len(sys.argv) > 1 and sys.argv[1] == '--time':          # wall time of REPS evaluations (alternating steps, as in the sampler)
