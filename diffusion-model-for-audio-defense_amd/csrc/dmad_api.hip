@@ -93,10 +93,12 @@ uint16_t f2h_census(float f) {
     if (a >= 65520.f) ++g_h_ovf;
     return f2h(f);
 }
-// Development switch of the low-toggle-weights experiment (tools/gpu_weight_toggle.py): DMAD_WEIGHT_MASK_BITS = k
-// rounds the f16 weight images of the 16-bit WaveNet path to 10 - k mantissa bits (round to nearest even on the f16 pattern, the
-// k low bits then zero: fewer toggling bits on the L2 -> LDS -> register path at a precision cost); DMAD_WEIGHT_MASK_WHICH selects
-// the images (bit 0 dilated conv, 1 res conv, 2 skip convs, 3 final_conv.0; default 3).  Unset / 0 = the product.
+// Development switch of the low-toggle-weights experiment (tools/gpu_weight_toggle.py), compiled in ONLY with
+// -DDMAD_DEV_WEIGHT_MASK (never in the product library: a leaked environment variable must not be able to void the exact-vote
+// bounds): DMAD_WEIGHT_MASK_BITS = k rounds the f16 weight images of the 16-bit WaveNet path to 10 - k mantissa bits (round to nearest
+// even on the f16 pattern, the k low bits then zero: fewer toggling bits on the L2 -> LDS -> register path at a precision cost);
+// DMAD_WEIGHT_MASK_WHICH selects the images (bit 0 dilated conv, 1 res conv, 2 skip convs, 3 final_conv.0; default 3).
+#ifdef DMAD_DEV_WEIGHT_MASK
 thread_local int g_mask_bits = 0;
 uint16_t f2h_census_masked(float f) {
     uint32_t h = f2h_census(f);
@@ -110,6 +112,7 @@ uint16_t f2h_census_masked(float f) {
     }
     return (uint16_t)h;
 }
+#endif
 void census_close_tensor() {
     ++g_h_tensors;
     const double share = g_h_sq > 0.0 ? g_h_sq_sub / g_h_sq : 0.0;
@@ -219,7 +222,7 @@ struct dmad_engine {
     long slab_floats = 0;
     // ResNeXt29 8x64d (models/resnext.py): 9 bottlenecks, every conv with its folded eval-BatchNorm scale/shift
     int cls_kind = 0;                      // 0 = VGG19_bn, 1 = ResNeXt29
-    struct RxConv { float *w = nullptr, *scale = nullptr, *shift = nullptr; h16_t* wh = nullptr; };   // wh: f16 image with the BN scale folded in (16-bit tier)
+    struct RxConv { float *w = nullptr, *scale = nullptr, *shift = nullptr; h16_t* wh = nullptr; float* wx = nullptr; };   // wh: f16 image with the BN scale folded in (16-bit tier); wx: split-f16 image (middle tier)
     struct RxBlock { RxConv reduce, conv, expand, shortc; bool has_short = false; int cin = 0, cout = 0, D = 0, stride = 1; };
     RxBlock rx[9];
     RxConv rxconv1;
@@ -229,6 +232,7 @@ struct dmad_engine {
     // shortcut add / ReLU in fp32), maps kept as f16 between the convs; tier 1 of the exact-vote loop uses it, the recheck tiers and
     // dmad_classify stay on the fp32 matrix cores
     bool rx_h16 = false;
+    bool rx_x3 = false;                    // exact-vote engines: ResNeXt29's split-f16 tier (every conv as three f16 MFMAs per product: fp32-grade), tier 1 of the exact-vote loop
     h16_t *rxX16 = nullptr, *rxY16 = nullptr, *rxT1h = nullptr, *rxT2h = nullptr, *rxS16 = nullptr;
     // Improved-Diffusion UNet purifier on 1x32x32 mel spectrograms (improved_diffusion/unet.py:278-477)
     struct UnOp {                          // one module of a TimestepEmbedSequential
@@ -365,14 +369,19 @@ int finalize_wavenet(dmad_engine* e) {
     if (e->bf16) {
         uint16_t (*cvt)(float) = e->f16 ? f2h_census : f2bf;
         g_h_sq = g_h_sq_sub = g_h_worst = 0.0; g_h_bad_tensors = g_h_ovf = g_h_tensors = 0;
-        int mask_bits = 0, mask_which = 3;              // development switch, see f2h_census_masked
+#ifdef DMAD_DEV_WEIGHT_MASK
+        int mask_bits = 0, mask_which = 3;              // development build only, see f2h_census_masked
         if (const char* mb = getenv("DMAD_WEIGHT_MASK_BITS")) mask_bits = atoi(mb);
         if (const char* mw = getenv("DMAD_WEIGHT_MASK_WHICH")) mask_which = atoi(mw);
         if (mask_bits < 0 || mask_bits > 9 || !e->f16) mask_bits = 0;
+        if (mask_bits) e->warn = "DEVELOPMENT BUILD: the f16 WaveNet weight images are rounded to fewer mantissa bits (DMAD_WEIGHT_MASK_BITS); the recheck bounds do not hold";
         auto cvt_for = [&](int which) -> uint16_t (*)(float) {
             g_mask_bits = mask_bits;
             return (mask_bits && (mask_which >> which & 1)) ? f2h_census_masked : cvt;
         };
+#else
+        auto cvt_for = [&](int) -> uint16_t (*)(float) { return cvt; };
+#endif
         int rmap[512];
         // tile row R = wm*128 + half*64 + mt*16 + i  <->  gate row half*256 + (mt*64 + wm*16 + i): channel ownership is
         // interleaved over the M-waves so that GEMM2 can start on channels [64 mt, 64 mt + 64) as soon as tiles mt are gated
@@ -546,6 +555,7 @@ int finalize_classifier(dmad_engine* e) {
 
 GemmF32Args plain_gemm(const float* A, const float* X, float* C, const float* scale, const float* shift, int M, int K, long N,
                        int ldc, long ldx, int relu);
+int upload_split(dmad_engine* e, const std::vector<float>& A, float** wx);
 
 // ResNeXt29 8x64d: names rx.conv1.*, rx.b<i>.{reduce,conv,expand,short}.{w,scale,shift} (i = 3 * stage + bottleneck),
 // rx.fc.{w,b}.  GEMM images: 1x1 convs [M][K]; the grouped 3x3 conv per group [tap][M/8][K/8] (models/resnext.py:23-62).
@@ -570,6 +580,7 @@ int finalize_resnext(dmad_engine* e) {
             }
             CHK(e->upload_bf(&c.wh, Hh));
         }
+        if (e->rx_x3 && row_len > 0) CHK(upload_split(e, Ah ? *Ah : A, &c.wx));      // the same image (grouped conv: the paired block-diagonal one), BN scale / shift stay in the epilogue
         return 0;
     };
     w = e->get("rx.conv1.w", {64, 1, 3, 3}); if (!w) return DMAD_ERR_STATE;
@@ -631,6 +642,51 @@ int finalize_resnext(dmad_engine* e) {
         CHK(e->alloc(&e->rxT1h, B * 1024 * 1024)); CHK(e->alloc(&e->rxT2h, B * 1024 * 512));
         if (int r = gemm_h16_configure()) return fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS, f16 conv GEMM) failed: %d", r);
     }
+    if (e->rx_x3) if (int r = gemm_x3_configure()) return fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS, split-f16 tier) failed: %d", r);
+    return 0;
+}
+
+// The same network on its SPLIT-F16 tier (exact-vote engines): the fp32 pipeline's structure with every conv on split-f16 operands (three f16
+// MFMAs per product, ~22 significant bits: gemm_x3_kernel's NHWC form, grouped for the 3x3), the eval-mode BatchNorm scale / shift, the
+// shortcut add and the ReLU in the fp32 epilogue; a map that only feeds GEMMs (and, as a block output, the next shortcut add) is written
+// in the split format directly.  Stage 1's 64-channel groups are paired into 128 x 128 block-diagonal groups (the kernel's tiles need
+// 128 rows), like on the 16-bit tier.  Average pool and head in fp32.
+int classify_resnext_x3(dmad_engine* e, const float* spec, int B, float* logits, hipStream_t s) {
+    float *X = e->rxX, *Y = e->rxY;
+    launch_vgg_conv1(spec, e->rxconv1.w, e->rxconv1.scale, e->rxconv1.shift, X, B, s);      // 1 -> 64, 3x3, BN, ReLU (direct kernel, fp32)
+    launch_scale(X, 1.f, X, (long)B * 1024 * 64, s, true);                                   // ... as a split-format operand, in place
+    int H = 32;
+    for (int i = 0; i < 9; ++i) {
+        const dmad_engine::RxBlock& b = e->rx[i];
+        const int Ho = (H - 1) / b.stride + 1;
+        const long Nin = (long)B * H * H, Nout = (long)B * Ho * Ho;
+        auto mk = [&](const dmad_engine::RxConv& c, const float* in, float* out, int M, int K, int taps, long N, int Hin, int ldx, int ldc, int stride, int relu,
+                      int out_split) {
+            GemmF32Args g{};
+            g.A = c.wx; g.X = in; g.C = out; g.scale = c.scale; g.shift = c.shift; g.M = M; g.K = K; g.taps = taps; g.ldc = ldc; g.relu = relu; g.N = N;
+            g.mode = 2; g.H = Hin; g.W = Hin; g.Cin = K; g.ldx = ldx; g.stride = stride; g.x3 = 1; g.out_split = out_split;
+            return g;
+        };
+        launch_gemm_f32(mk(b.reduce, X, e->rxT1, b.D, b.cin, 1, Nin, H, b.cin, b.D, 1, 1, 1), s);                 // conv_reduce + bn + ReLU
+        const int G = b.D / 8, pair = G < 128 ? 2 : 1;
+        GemmF32Args c = mk(b.conv, e->rxT1, e->rxT2, G * pair, G * pair, 9, Nout, H, b.D, b.D, b.stride, 1, 1);    // grouped 3x3 (stride) + bn + ReLU
+        c.groups = 8 / pair;
+        launch_gemm_f32(c, s);
+        GemmF32Args x = mk(b.expand, e->rxT2, Y, b.cout, b.D, 1, Nout, Ho, b.D, b.cout, 1, 1, i == 8 ? 0 : 1);    // conv_expand + bn + shortcut, ReLU
+        if (b.has_short) {
+            launch_gemm_f32(mk(b.shortc, X, e->rxS, b.cout, b.cin, 1, Nout, H, b.cin, b.cout, b.stride, 0, 0), s);  // shortcut conv + bn: fp32
+            x.res = e->rxS;
+        } else {
+            x.res = X; x.res_split = 1;                                                                              // the block input exists in the split format only
+        }
+        launch_gemm_f32(x, s);
+        float* t = X; X = Y; Y = t;
+        H = Ho;
+    }
+    launch_avgpool_nhwc(X, e->rxT2, B, H * H, 1024, s);
+    launch_gemm_f32(plain_gemm(e->rxfcw, e->rxT2, logits, nullptr, e->rxfcb, e->cfg.num_classes, 1024, B, e->cfg.num_classes, 1024, 0), s,
+                    e->slab, e->slab_floats, (long)e->maxB);
+    LASTCHK();
     return 0;
 }
 
@@ -1086,7 +1142,7 @@ int unet_eps(dmad_engine* e, const float* x, int t, int B, float* eps, hipStream
     if (h16 == 1) {
         int H = 32, rot = 0;
         UMap h{x, nullptr, nullptr};
-        std::vector<const float*> hs_st(e->un_hs.size(), nullptr);      // the statistics slab each saved map ended up with (none for conv_in's / the 4x4 maps)
+        std::vector<const float*> hs_st(e->un_hs.size(), nullptr);      // the statistics slab each saved map ended up with (16-pixel blocks on the 4x4 maps)
         for (size_t i = 0; i < e->un_in.size(); ++i)
             for (size_t j = 0; j < e->un_in[i].size(); ++j) {
                 const bool save = j + 1 == e->un_in[i].size();
@@ -1253,13 +1309,15 @@ int mel_db(dmad_engine* e, const float* x, int B, float* spec, hipStream_t s, in
     return 0;
 }
 
-// h16 = 1: the classifier's 16-bit tier where one is resident (ResNeXt29 on engines with a 16-bit side) — what tier 1 of the vote
-// loops runs; every other caller (dmad_classify, the recheck tiers) gets the fp32 matrix cores
+// h16 = 1: the classifier's 16-bit tier where one is resident (ResNeXt29 on engines with a 16-bit side) — the fast mode's; 2: its
+// split-f16 tier (exact-vote engines) — tier 1 of the exact-vote loops; every other caller (dmad_classify, the recheck tiers) gets the
+// fp32 matrix cores
 int classify(dmad_engine* e, const float* spec, int B, float* logits, hipStream_t s, int h16 = 0) {
     if (!e->cfg.with_classifier) return fail(DMAD_ERR_STATE, "engine was created with with_classifier = 0");
     if (!e->cls_final) return fail(DMAD_ERR_STATE, "classifier weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
     if (B < 1 || B > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d]", B, e->maxB);
-    if (e->cls_kind == 1) return (h16 && e->rx_h16) ? classify_resnext_h16(e, spec, B, logits, s) : classify_resnext(e, spec, B, logits, s);
+    if (e->cls_kind == 1) return (h16 == 1 && e->rx_h16) ? classify_resnext_h16(e, spec, B, logits, s)
+                                 : (h16 == 2 && e->rx_x3) ? classify_resnext_x3(e, spec, B, logits, s) : classify_resnext(e, spec, B, logits, s);
     float *cur = e->act0, *nxt = e->act1;
     launch_vgg_conv1(spec, e->vconv1w, e->vscale[0], e->vshift[0], cur, B, s);
     int H = 32, cin = 64, li = 1;
@@ -1302,7 +1360,11 @@ inline int wave_path(const dmad_engine* e) {
 // Round 5, measured on the calibrated stand-in (profiles/r05b_resnext29_error_attribution.json): the f16 classifier's leader-difference
 // error is 0.08-0.16 against 0.016-0.030 for the f16 WaveNet in front of the fp32 classifier — a bound that covered it would send a
 // quarter of the samples to the recheck tiers, so the exact-vote mode keeps the classifier on the fp32 matrix cores in every tier.
-inline int cls_tier(const dmad_engine* e) { return (e->rx_h16 && e->mode == DMAD_MODE_FAST) ? 1 : 0; }
+// It runs the classifier's SPLIT-F16 tier there (fp32-grade: its error, ~1e-4, disappears under the WaveNet's): a third of the fp32 tier's time.
+inline int cls_tier(const dmad_engine* e) {
+    if (e->mode == DMAD_MODE_FAST) return e->rx_h16 ? 1 : 0;
+    return (e->mode == DMAD_MODE_EXACT_VOTES && e->rx_x3 && e->cls_kind == 1) ? 2 : 0;
+}
 
 }  // namespace
 
@@ -1348,6 +1410,8 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     e->un_h16 = cfg->precision != DMAD_FP32;    // engines with a 16-bit side also get the UNet's f16 tier (once UNet weights are loaded)
     e->rx_h16 = cfg->precision != DMAD_FP32;    // ... and ResNeXt29's (once its weights are loaded)
     if (const char* v = getenv("DMAD_RX_H16")) if (v[0] == '0') e->rx_h16 = false;      // A/B switch: ResNeXt29 on the fp32 matrix cores in every tier
+    e->rx_x3 = cfg->precision == DMAD_EXACT;    // ... and its split-f16 tier
+    if (const char* v = getenv("DMAD_RX_X3")) if (v[0] == '0') e->rx_x3 = false;        // A/B switch
     e->tau_spec = 0.13f;                    // spec-domain vote loop: measured logit-difference error of the f16 UNet chain x headroom (see dmad.h)
     e->tau_spec2 = 5e-4f;                   // ... of the chain on the split-f16 tier (measured 2.3e-4)
     e->un_x3 = cfg->precision == DMAD_EXACT;    // exact-vote engines also hold the UNet's split-f16 middle tier
@@ -1359,6 +1423,7 @@ int dmad_create(const dmad_config* cfg, dmad_engine** out) {
     const size_t B = e->maxB, L = e->L, LP = e->LP, NL = e->NL, B32 = e->maxB32;
     int r = 0;
     do {
+        if ((r = gemm_f32_configure())) { r = fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS, fp32 narrow tile) failed: %d", r); break; }
         if ((r = e->alloc(&e->xt, B * L))) break;
         if ((r = e->alloc(&e->eps, B * L))) break;
         if ((r = e->alloc(&e->x0, B * L))) break;
@@ -1618,7 +1683,7 @@ int dmad_classify(dmad_engine* e, const float* spec, int32_t B, float* logits, d
 
 int dmad_classify_tier(dmad_engine* e, const float* spec, int32_t B, int32_t tier, float* logits, dmad_stream s) {
     if (!e || !spec || !logits) return fail(DMAD_ERR_INVALID, "null argument");
-    if (tier != 0 && tier != 1) return fail(DMAD_ERR_INVALID, "unknown classifier tier %d (0 fp32, 1 16-bit)", tier);
+    if (tier != 0 && tier != 1 && tier != 2) return fail(DMAD_ERR_INVALID, "unknown classifier tier %d (0 fp32, 1 16-bit, 2 split-f16)", tier);
     return classify(e, spec, B, logits, (hipStream_t)s, tier);
 }
 

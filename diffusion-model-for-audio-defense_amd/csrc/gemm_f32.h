@@ -42,9 +42,11 @@ struct GemmF32Args {
     // product is three v_mfma_f32_16x16x32_f16.  mode 0 (the WaveNet's GEMMs; M a multiple of 256): outputs that feed another GEMM
     // (epi 1: the gate, epi 2: hout) are written in that format, everything else (plain C, the skip sum) stays fp32.  mode 2 (NHWC convs:
     // 3x3 / 1x1, stride, two-part input; M a multiple of 128): plain epilogue with shift or scale / shift, fp32 residual, ReLU; fp32 out,
-    // or the split format with out_split.
+    // or the split format with out_split.  groups > 1 (mode 2, no two-part input): grouped conv, one group per grid.y; M, K and the A image are
+    // per group (M a multiple of 128), X / C / scale / shift / res advance by K resp. M per group.
     int x3;
     int out_split;        // x3, plain epilogue: C is written in the split format (the consumer is another GEMM of the tier)
+    int res_split;        // x3, plain epilogue: `res` is a map in the split format (a block output that only exists in that form)
     int diag;             // x3 only, error-attribution builds: bit 0 weights = f16(w), bit 1 the MFMA eats f16(x), bit 2 split-format outputs keep hi only
     int splits;           // > 1: split-K over grid.z; partial sums go to `slab` [splits][N][ldc] (fixed-order reduce)
     float* slab;
@@ -56,6 +58,7 @@ struct GemmF32Args {
 constexpr int kGemmBadShape = -1;
 int launch_gemm_f32(const GemmF32Args& a, hipStream_t s, float* slab = nullptr, long slab_floats = 0, long n_ref = 0);
 int gemm_take_bad_shapes();   // number of launches refused on this thread since the last call (reset to 0)
+int gemm_f32_configure();     // per device, from dmad_create: dynamic-LDS attribute of the 8-slot narrow-tile kernel (0 or a hipError_t)
 int gemm_x3_configure();      // per device, from dmad_create: dynamic-LDS attribute of the split-f16 kernel (0 or a hipError_t)
 
 }  // namespace dmad

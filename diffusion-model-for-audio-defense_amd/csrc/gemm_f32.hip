@@ -372,6 +372,17 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
     static_assert(WM == 4 || WM == 2, "wave layouts 4 x 2 and 2 x 4");
     const bool drop_alo = DIAG && (a.diag & 1), drop_blo = DIAG && (a.diag & 2), hi_only = DIAG && (a.diag & 4);
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (CONV) {
+        if (a.groups > 1) {                  // grouped conv: this workgroup's group = blockIdx.y
+            const int g = blockIdx.y;
+            a.A += (size_t)g * a.taps * a.M * a.K;
+            a.X += (size_t)g * a.K;
+            a.C += (size_t)g * a.M;
+            if (a.scale) a.scale += (size_t)g * a.M;
+            if (a.shift) a.shift += (size_t)g * a.M;
+            if (a.res) a.res += (size_t)g * a.M;
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv / WN, wn = wv % WN, q = lane >> 4, r16 = lane & 15;
@@ -686,6 +697,14 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_kernel(GemmF32Args a) {
         if (a.res) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) rr[j] = *(const float4*)(a.res + nrow[j] + m);
+            if (a.res_split) {               // the residual map is in the split format: back to fp32 values
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t4[4];
+                    join4(__builtin_bit_cast(u32x4_t, rr[j]), t4);
+                    rr[j] = float4{t4[0], t4[1], t4[2], t4[3]};
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -732,12 +751,11 @@ int gemm_x3_configure() {
     return (int)hipFuncSetAttribute((const void*)gemm_x3_kernel<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
 }
 
-namespace {
-bool narrow_ready() {                      // 128 KiB of dynamic LDS for the 8-slot instantiation, asked for once
-    static const bool ok = hipFuncSetAttribute((const void*)gemm_f32_kernel<64, false, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * SLOT) == hipSuccess;
-    return ok;
+// once per device a process uses (dmad_create, like gemm_x3_configure: the attribute is per device, so a function-local static set on the
+// first device would leave every later device without it): 128 KiB of dynamic LDS for the 8-slot narrow-tile instantiation
+int gemm_f32_configure() {
+    return (int)hipFuncSetAttribute((const void*)gemm_f32_kernel<64, false, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * SLOT);
 }
-}  // namespace
 
 int launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab_floats, long n_ref) {
     GemmF32Args a = a0;
@@ -745,9 +763,9 @@ int launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab
     if (a.epi == 2 && (a.N >= (1l << 31) || a.L < 1 || a.M != 256 || a.res_rows != a.M || !a.hin || !a.hout || !a.emb_next)) { ++g_bad_shapes; return kGemmBadShape; }
     if (a.x3) {                                   // split-f16 operands (shapes checked here, not in the kernel)
         a.splits = 1; a.slab = nullptr;
-        if ((a.K % 32) || a.groups > 1 || (a.ldc & 3) || a.K < 32) { ++g_bad_shapes; return kGemmBadShape; }
+        if ((a.K % 32) || (a.ldc & 3) || a.K < 32) { ++g_bad_shapes; return kGemmBadShape; }
         if (a.mode == 0) {                        // the WaveNet's row-gather GEMMs: tile 256 x 128
-            if ((a.M % X3_BM) || a.scale || a.res || a.out_split || a.X2) { ++g_bad_shapes; return kGemmBadShape; }
+            if ((a.M % X3_BM) || a.scale || a.res || a.out_split || a.X2 || a.groups > 1) { ++g_bad_shapes; return kGemmBadShape; }
             const long nx = (a.N + BN - 1) / BN;
             if (((nx + 7) / 8) * 8 * (a.M / X3_BM) > 0x7fffffffl) { ++g_bad_shapes; return kGemmBadShape; }
             const dim3 grid((unsigned)(((nx + 7) / 8) * 8 * (a.M / X3_BM)));
@@ -758,11 +776,12 @@ int launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab
         // NHWC convs (3x3 zero padding 1 / 1x1, stride 1 or 2, optional two-part input): rows of 16-byte chunks, no fused epilogue
         const long ldx = a.ldx ? a.ldx : a.Cin;
         if (a.mode != 2 || a.epi || a.diag || (a.M % 128) || (a.taps != 9 && a.taps != 1) || (ldx & 3) || a.H < 1 || a.W < 1 ||
-            (a.X2 && ((a.ksplit % 32) || a.ksplit <= 0 || a.ksplit >= a.K || (a.ldx2 & 3))) || (a.res && a.res == a.C)) { ++g_bad_shapes; return kGemmBadShape; }
+            (a.X2 && ((a.ksplit % 32) || a.ksplit <= 0 || a.ksplit >= a.K || (a.ldx2 & 3) || a.groups > 1)) || (a.res && a.res == a.C) ||
+            (a.groups > 1 && ((long)a.groups * a.K > ldx || (long)a.groups * a.M > a.ldc || a.groups > 65535))) { ++g_bad_shapes; return kGemmBadShape; }
         const bool big = a.M % 256 == 0;
         const long nx = (a.N + (big ? 127 : 255)) / (big ? 128 : 256), ny = a.M / (big ? 256 : 128);
         if (((nx + 7) / 8) * 8 * ny > 0x7fffffffl) { ++g_bad_shapes; return kGemmBadShape; }
-        const dim3 grid((unsigned)(((nx + 7) / 8) * 8 * ny));
+        const dim3 grid((unsigned)(((nx + 7) / 8) * 8 * ny), (unsigned)(a.groups > 1 ? a.groups : 1));
         if (big) hipLaunchKernelGGL((gemm_x3_kernel<false, 4, true>), grid, dim3(512), X3_LDS, s, a);
         else hipLaunchKernelGGL((gemm_x3_kernel<false, 2, true>), grid, dim3(512), X3_LDS, s, a);
         return 0;
@@ -780,7 +799,7 @@ int launch_gemm_f32(const GemmF32Args& a0, hipStream_t s, float* slab, long slab
     static const bool narrow_on = []() { const char* v = getenv("DMAD_F32_NARROW"); return !(v && v[0] == '0'); }();      // A/B switch
     auto launch = [&](dim3 grid) {
         if (a.X2) hipLaunchKernelGGL((gemm_f32_kernel<128, true>), grid, dim3(256), 3 * SLOT, s, a);
-        else if (BM == 64 && narrow_on && (long)grid.x * grid.y * grid.z < 256 && nks >= 8 && narrow_ready())       // fewer workgroups than CUs:
+        else if (BM == 64 && narrow_on && (long)grid.x * grid.y * grid.z < 256 && nks >= 8)       // fewer workgroups than CUs:
             hipLaunchKernelGGL((gemm_f32_kernel<64, false, 8, 1>), dim3((unsigned)((a.N + 31) / 32), grid.y, grid.z), dim3(256), 8 * SLOT, s, a);   // 64 x 32 tiles, 8-slot ring
         else if (BM == 64) hipLaunchKernelGGL((gemm_f32_kernel<64, false>), grid, dim3(256), 3 * SLOT, s, a);
         else hipLaunchKernelGGL((gemm_f32_kernel<128, false>), grid, dim3(256), 3 * SLOT, s, a);

@@ -24,6 +24,13 @@ namespace dmad {
 
 namespace {
 
+// WNF_VARIANT: development builds of tools/final_variants.sh (profiles/r05_final_kernel_bounds.md); the product is variant 0.  Both
+// ablations are numerically meaningless — only time, power and the in-kernel clock are read:
+//   1  every tile streams the FIRST tile's gate rows (L2-resident after the first pass): the kernel without its HBM stream
+//   2  no MFMAs in the skip GEMM's k loop (DMA, fragment reads and barriers stay): the kernel as a pure streamer
+#ifndef WNF_VARIANT
+#define WNF_VARIANT 0
+#endif
 constexpr int FT = 256;                       // positions per tile
 constexpr int F_SLOT = 32768, F_BOFF = 16384; // ring slot: weights then activations
 constexpr int F_W3 = 131072;                  // two final_conv.0 weight buffers
@@ -75,7 +82,11 @@ __global__ void __launch_bounds__(512, 2) wn_final_p(WnFinalArgs a, long npos, i
         const char* wb = (const char*)a.wsp;
         const char* w3b = (const char*)a.wf0p;
         asm volatile("" : "+s"(wb), "+s"(w3b));   // keep the DMA bases from being hoisted (SGPR spills)
+#if WNF_VARIANT == 1
+        const char* gb = (const char*)a.g;
+#else
         const char* gb = (const char*)a.g + (size_t)p0 * 64;
+#endif
         // rows beyond the end of the batch (last tile only) are clamped to the last valid position
         const long last = npos - 1 - p0;
         const unsigned voff0 = (unsigned)((brow < last ? brow : last) * 64 + (((tid & 3) ^ swz64(brow)) * 16));
@@ -132,7 +143,7 @@ __global__ void __launch_bounds__(512, 2) wn_final_p(WnFinalArgs a, long npos, i
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 5 * p; i < 5 * p + 5; ++i)
-                        acc[i >> 3][i & 7] = mfma16(af[cur][i >> 3], bf[cur][i & 7], acc[i >> 3][i & 7]);
+                        if (WNF_VARIANT != 2 || i == 0) acc[i >> 3][i & 7] = mfma16(af[cur][i >> 3], bf[cur][i & 7], acc[i >> 3][i & 7]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
@@ -143,7 +154,8 @@ __global__ void __launch_bounds__(512, 2) wn_final_p(WnFinalArgs a, long npos, i
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     const int i = 20 + p;
-                    acc[i >> 3][i & 7] = mfma16(af[cur][i >> 3], bf[cur][i & 7], acc[i >> 3][i & 7]);
+                    if (WNF_VARIANT != 2) acc[i >> 3][i & 7] = mfma16(af[cur][i >> 3], bf[cur][i & 7], acc[i >> 3][i & 7]);
+                    else asm volatile("" : "+v"(af[cur][i >> 3]), "+v"(bf[cur][i & 7]));        // keep the fragment reads alive
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }

@@ -617,7 +617,7 @@ class Engine:
         return out
 
     def classify_tier(self, spec: torch.Tensor, tier: int) -> torch.Tensor:
-        """dmad_classify_tier: the classifier on an explicit tier (0 fp32, 1 the 16-bit tier of ResNeXt29) — test / measurement hook."""
+        """dmad_classify_tier: the classifier on an explicit tier (0 fp32, 1 the 16-bit tier / 2 the split-f16 tier of ResNeXt29) — test / measurement hook."""
         if not spec.is_cuda:
             raise DmadError('input must live on the GPU (the dmad engine has no CPU path)')
         sp = spec.detach().reshape(spec.shape[0], 32 * 32).contiguous().float()

@@ -172,12 +172,14 @@ int dmad_classify(dmad_engine* e, const float* spec, int32_t B, float* logits, d
  * every conv (1x1 reduce / expand / shortcut, the grouped 3x3) on f16 operands with fp32 accumulation, the eval-mode BatchNorm
  * scale folded into the f16 weights, shift / shortcut add / ReLU in fp32, maps kept as f16 between the convs; average pool and
  * the linear head stay fp32.  It is the classifier of DMAD_MODE_FAST (the vote loops' pass and the mode-default path of
- * dmad_eval_samples there).  The exact-vote mode keeps the classifier on the fp32 matrix cores in EVERY tier since round 5: measured
- * on the calibrated synthetic stand-in, the f16 classifier's leader-difference error is 0.08-0.16 against 0.016-0.030 for the f16
- * WaveNet in front of the fp32 classifier (profiles/r05b_resnext29_error_attribution.json) — a recheck bound covering it would send
- * a quarter of the samples to the recheck tiers.  dmad_query_logits and dmad_classify always use the fp32 matrix cores.
- * dmad_classify_tier evaluates an explicit tier (0: fp32, 1: 16-bit; VGG19_bn has no 16-bit tier and is served on fp32 either way)
- * — test / measurement hook. */
+ * dmad_eval_samples there).  Measured on the calibrated synthetic stand-in, its leader-difference error is 0.08-0.16 against
+ * 0.016-0.030 for the f16 WaveNet in front of the fp32 classifier (profiles/r05b_resnext29_error_attribution.json) — a recheck bound
+ * covering it would send a quarter of the samples to the recheck tiers — so since round 5 the first pass of the exact-vote mode runs
+ * the classifier's SPLIT-F16 TIER instead (DMAD_EXACT engines): every conv on split-f16 operands (three f16 MFMAs per product, ~22
+ * significant bits; BatchNorm scale / shift, shortcut add and ReLU in the fp32 epilogue), fp32-grade at a third of the fp32 tier's
+ * time.  The recheck tiers, dmad_query_logits and dmad_classify always use the fp32 matrix cores, so a re-evaluated sample's logits
+ * are the fp32 path's.  dmad_classify_tier evaluates an explicit tier (0: fp32, 1: 16-bit, 2: split-f16; VGG19_bn has one tier and is
+ * served on fp32 either way) — test / measurement hook. */
 int dmad_classify_tier(dmad_engine* e, const float* spec, int32_t B, int32_t tier, float* logits, dmad_stream s);
 
 /* The Monte Carlo loop of RobustCertificate.smooth_predict (+ forward, compute_t_star's result),

@@ -706,9 +706,9 @@ def test_resnext29_16bit_tier_and_exact_votes(golden_dir, weights, sched):
     really another arithmetic than the fp32 tier; dmad_classify itself stays the fp32 tier.
     (2) the exact-vote loop: counts == the all-fp32 counts, bit for bit, on 3 clips x 3 sigmas x 512 = 4 608 samples, and NOT
     vacuously: every cell votes at least three classes, no class takes more than 70 %, samples ARE rechecked (on both recheck
-    tiers over the run), the rows that reached fp32 are the fp32 path's bit for bit.  Since round 5 the exact-vote mode keeps the
-    classifier on the fp32 matrix cores in every tier (the f16 classifier's leader-difference error, measured here too, is several
-    times the f16 WaveNet's and does NOT fit under the bound); the fast mode runs the f16 classifier."""
+    tiers over the run), the rows that reached fp32 are the fp32 path's bit for bit.  Since round 5 the first pass of the exact-vote
+    mode runs the classifier's SPLIT-F16 tier (fp32-grade) and the recheck tiers the fp32 one: the f16 classifier's leader-difference
+    error, measured here too, is several times the f16 WaveNet's and does NOT fit under the bound; the fast mode runs it."""
     from dmad_hip import engine as E
     z = G(golden_dir, 'resnext29.npz')
     sd = synth.resnext29_state_dict(int(z['seed']))
@@ -725,6 +725,13 @@ def test_resnext29_16bit_tier_and_exact_votes(golden_dir, weights, sched):
     assert torch.equal(eng.classify_tier(spec[1:2], 1), l16[1:2])                 # a sample's logits do not depend on its batch
     big = eng.classify_tier(spec.repeat(40, 1, 1, 1), 1)                          # 160 > max_batch: chunked; other tile shapes
     assert torch.equal(big[:4], l16) and torch.equal(big[156:], l16)
+    # (1b) its split-f16 tier (tier 1 of the exact-vote loop): every conv as three f16 MFMAs per product, grouped 3x3 included — fp32-grade
+    lx3 = eng.classify_tier(spec, 2)
+    ex3 = relmax(lx3.cpu().numpy(), z['logits'])
+    assert 0 < ex3 < 2e-4 and not torch.equal(lx3, l32), ex3                      # the fp32 tier's own tolerance
+    assert torch.equal(eng.classify_tier(spec[2:3], 2), lx3[2:3])
+    bigx = eng.classify_tier(spec.repeat(40, 1, 1, 1), 2)
+    assert torch.equal(bigx[:4], lx3) and torch.equal(bigx[156:], lx3)
     hp, coef = sched
     ab = hp['Alpha_bar']
     N, worst, worst_fast, rechecked, reached_fp32 = 512, 0.0, 0.0, 0, 0
@@ -744,7 +751,7 @@ def test_resnext29_16bit_tier_and_exact_votes(golden_dir, weights, sched):
             assert sum(1 for v in f32[0] if v > 0) >= 3 and max(f32[0]) <= 0.7 * N, f32[0]          # a non-degenerate stand-in
             assert ex[0] == f32[0], (ci, sigma, ex[0], f32[0])
             assert (ex[1].argmax(1) == f32[1].argmax(1)).all()
-            # tier 1 of the exact-vote mode = f16 WaveNet + fp32 classifier: its rows where nothing was rechecked
+            # tier 1 of the exact-vote mode = f16 WaveNet + split-f16 classifier: its rows where nothing was rechecked
             idx = torch.arange(N, dtype=torch.int64, device='cuda') + 9000
             eng.set_mode(E.MODE_EXACT_VOTES)
             t1 = eng.eval_samples(clip, sigma, sc, t, *coef(t), idx, path=0, seed=700 + ci).cpu().numpy().astype(np.float64)
@@ -762,7 +769,7 @@ def test_resnext29_16bit_tier_and_exact_votes(golden_dir, weights, sched):
             reached_fp32 += ex[2][2]
     assert rechecked >= 0.01 * 9 * N, rechecked                                   # the recheck hand-over is exercised ...
     assert reached_fp32 >= 1                                                      # ... down to the exact-fp32 tier
-    assert worst < eng.recheck_margin, (worst, eng.recheck_margin)                # the bound covers tier 1's error with the fp32 classifier
+    assert worst < eng.recheck_margin, (worst, eng.recheck_margin)                # the bound covers tier 1's error with the split-f16 classifier
     assert worst_fast > eng.recheck_margin, worst_fast                            # ... and would NOT cover the f16 classifier's (why it is FAST-only)
     eng.close()
 
@@ -1044,20 +1051,26 @@ def test_unet_purifier_vs_reference_fixture(golden_dir):
 @pytest.mark.gpu
 def test_unet_16bit_tier_large_batch_uses_the_256_tile_and_stays_batch_invariant():
     """At 256 spectrograms the 256-channel 16x16 convs and the M = 768 qkv convs fill the chip and run the persistent forms of
-    csrc/gemm_h16.hip (slice-resident / ping-pong); smaller batches run the 384-row kernel.  All accumulate every output in the same
-    order, so a sample's eps is the same bits in a batch of 256 and in a batch of 2 (batch invariance across the kernel switch),
+    csrc/gemm_h16.hip (slice-resident / ping-pong), at 1024 the 8x8 maps do too (and the 4 -> 8 Upsample conv reads through the
+    upsampling with tiles spanning four images); smaller batches run the 384-row kernel.  All accumulate every output in the same
+    order, so a sample's eps is the same bits in a batch of 1024, of 256 and of 2 (batch invariance across the kernel switches),
     and the tier stays within its f16 tolerance of the exact-fp32 tier at the large batch too.  The fp32 tier's own switch (narrow
     tiles for sub-chip launches) is checked the same way."""
     from dmad_hip import engine as E
     from diffusion_models.improved_diffusion_ddpm import create_improved_diffusion
-    eng = E.Engine(max_batch=256, precision=E.EXACT, with_classifier=False, with_wavenet=False)
+    eng = E.Engine(max_batch=1024, precision=E.EXACT, with_classifier=False, with_wavenet=False)
     create_improved_diffusion(None, reverse_timestep=3, state_dict=synth.unet_state_dict(31), engine=eng)
-    x = torch.randn(256, 32, 32, generator=torch.Generator().manual_seed(5)).cuda()
+    x = torch.randn(1024, 32, 32, generator=torch.Generator().manual_seed(5)).cuda()
     eng.set_mode(E.MODE_FAST)
-    big = eng.unet_eps(x, 7)
-    assert bool(torch.isfinite(big).all())
+    huge = eng.unet_eps(x, 7)           # 1024 spectrograms: also the 8x8 maps fill the chip (persistent forms, the 4 -> 8 upsample fused: a tile = 4 images)
+    big = eng.unet_eps(x[:256].contiguous(), 7)
+    assert bool(torch.isfinite(huge).all()) and torch.equal(huge[:256], big)
     for lo in (0, 77, 254):
         assert torch.equal(eng.unet_eps(x[lo:lo + 2].contiguous(), 7), big[lo:lo + 2]), lo
+    assert torch.equal(eng.unet_eps(x[1021:1024].contiguous(), 7), huge[1021:])
+    # the split-f16 middle tier has no kernel switch (no split-K, one tile shape per layer): batch-invariant by construction, checked anyway
+    mid = eng.unet_eps(x[:256].contiguous(), 7, tier=2)
+    assert torch.equal(eng.unet_eps(x[100:103].contiguous(), 7, tier=2), mid[100:103])
     eng.set_mode(E.MODE_FP32)
     ref = eng.unet_eps(x[:64].contiguous(), 7)
     assert 1e-5 < relmax(big[:64].cpu().numpy(), ref.cpu().numpy()) < UNET_F16_TOL

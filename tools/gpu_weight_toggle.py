@@ -8,6 +8,8 @@ power sampler: ms, W, J above idle per launch; (b) the leader-difference error o
 (unmasked fp32-grade weights) on N Philox samples of three clips at sigma = 0.5 — the statistic the recheck bound is set from;
 (c) the share of those samples whose 16-bit margin is below 1.4 x that error (what would leave tier 1).
 Writes gpurun_out/weight_toggle.json.     B=128 SECONDS=4 N=1024 KS=0,1,2,3 python tools/gpu_weight_toggle.py
+Since round 5 the mask path exists only in a library built with -DDMAD_DEV_WEIGHT_MASK (make CXXFLAGS+=-DDMAD_DEV_WEIGHT_MASK, pointed at with
+DMAD_LIB): the product library ignores the variables, so that a leaked environment cannot void the exact-vote bounds.
 """
 import json
 import os
