@@ -73,20 +73,20 @@ __device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
 
-// g = tanh(A) * sigmoid(B) for two values at a time, on accumulators that already hold the exp2 arguments: the host scales the tanh
-// rows of the dilated-conv weights by -2*log2(e) and the sigmoid rows by -log2(e), and the accumulators start from the equally
-// scaled bias, so
+// g = tanh(A) * sigmoid(B) for two values at a time with packed fp32 math, on accumulators that already hold the
+// exp2 arguments: the host scales the tanh rows of the dilated-conv weights by -2*log2(e) and the sigmoid rows by
+// -log2(e), and the accumulators start from the equally scaled bias, so
 //   u = 2^min(at, 30) = e^{-2A},  v = 2^as = e^{-B},  g = (1-u) / ((1+u)(1+v))
 // 2 v_exp + 1 v_rcp per value and no affine step.  Only the tanh side needs the clamp: v = inf gives
 // (1+u)(1+v) = inf -> rcp = 0 -> g = 0, the correct limit.
-// Round 5: the three FMA-class steps are SINGLE v_add_f32 / v_fma_f32 instructions (asm, so that neither the f32x2 type nor hipcc's
-// SLP vectoriser turns them into v_pk_*_f32).  The packed forms gave the same cycle count — the phase is bound by its transcendentals —
-// but on a board at its power cap they cost clock: 1.80 -> 2.07 GHz in-kernel at the same 1 400 W, 3.29 -> 2.85 ms per launch of 256
-// clips, with bit-identical results (profiles/r05_layer_gate_variants.md).
-// WNL_VARIANT: development builds of tools/layer_variants.sh; the product is variant 0.
+// WNL_VARIANT: development builds of tools/layer_variants.sh (round 5, profiles/r05_layer_gate_variants.md); the product is variant 0.
+//   1  the three FMA-class steps as single v_add_f32 / v_fma_f32 (scalar code; build the file with -fno-slp-vectorize): measured equal
+//      to the packed form (3.327 vs 3.321 ms per launch of 256 clips), so the product keeps the form its error statistics were taken on
 //   2  ABLATION (numerically meaningless): no transcendentals — what the gate's VALU work costs at all
-//   3  GEMM2's MFMAs interleaved with the gate's VALU by sched_group_barrier instead of 8-MFMA blocks
-//   5  the round-4 form: packed fp32 math (v_pk_add_f32 / v_pk_fma_f32)
+//   3  GEMM2's MFMAs interleaved with the gate's VALU by sched_group_barrier instead of 8-MFMA blocks: equal
+// (Never hand-write these steps as asm statements: a consumer of a v_exp / v_rcp result needs a wait state, and hipcc does not look
+// inside an asm statement — such a build produced NaNs, and because NaN operands do not toggle it ran 15 % FASTER on the power-capped
+// board, which looked like a win until the tests ran.)
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 #ifndef WNL_VARIANT
 #define WNL_VARIANT 0
@@ -94,7 +94,19 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ f32x2 gate2(f32x2 at, f32x2 as) {
 #if WNL_VARIANT == 2
     return at * as + at;
-#elif WNL_VARIANT == 5
+#elif WNL_VARIANT == 1
+    f32x2 g;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float a = __builtin_amdgcn_fmed3f(at[i], 30.f, -3.0e38f);
+        const float u = fast_exp2(a), v = fast_exp2(as[i]);
+        const float p = 1.f + u;
+        const float d = __builtin_fmaf(p, v, p);
+        const float r = fast_rcp(d);
+        g[i] = __builtin_fmaf(-u, r, r);
+    }
+    return g;
+#else
     at[0] = __builtin_amdgcn_fmed3f(at[0], 30.f, -3.0e38f);     // min(at, 30) as one v_med3 (fminf on an MFMA result costs
     at[1] = __builtin_amdgcn_fmed3f(at[1], 30.f, -3.0e38f);     // an extra canonicalising v_max)
     const f32x2 u = {fast_exp2(at[0]), fast_exp2(at[1])};
@@ -103,19 +115,6 @@ __device__ __forceinline__ f32x2 gate2(f32x2 at, f32x2 as) {
     const f32x2 d = p * v + p;
     const f32x2 r = {fast_rcp(d[0]), fast_rcp(d[1])};
     return r - u * r;                     // (1 - u) * r as one packed FMA
-#else
-    f32x2 g;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float a = __builtin_amdgcn_fmed3f(at[i], 30.f, -3.0e38f);     // min(at, 30) as one v_med3 (fminf on an MFMA result costs an extra canonicalising v_max)
-        const float u = fast_exp2(a), v = fast_exp2(as[i]);
-        float p, d;
-        asm("v_add_f32 %0, 1.0, %1" : "=v"(p) : "v"(u));                     // p = 1 + u
-        asm("v_fma_f32 %0, %1, %2, %1" : "=v"(d) : "v"(p), "v"(v));          // d = p v + p = (1 + u)(1 + v)
-        const float r = fast_rcp(d);
-        asm("v_fma_f32 %0, -%1, %2, %2" : "=v"(g[i]) : "v"(u), "v"(r));      // g = r - u r = (1 - u) / d
-    }
-    return g;
 #endif
 }
 

@@ -748,6 +748,7 @@ def test_resnext29_16bit_tier_and_exact_votes(golden_dir, weights, sched):
                 out[mode] = (c.cpu().tolist(), l.cpu().numpy().astype(np.float64), eng.recheck_stats(detail=True))
             fast, f32, ex = out[E.MODE_FAST], out[E.MODE_FP32], out[E.MODE_EXACT_VOTES]
             assert sum(fast[0]) == sum(f32[0]) == sum(ex[0]) == N
+            assert np.isfinite(fast[1]).all() and np.isfinite(f32[1]).all() and np.isfinite(ex[1]).all()      # (a NaN would slip through every max() below)
             assert sum(1 for v in f32[0] if v > 0) >= 3 and max(f32[0]) <= 0.7 * N, f32[0]          # a non-degenerate stand-in
             assert ex[0] == f32[0], (ci, sigma, ex[0], f32[0])
             assert (ex[1].argmax(1) == f32[1].argmax(1)).all()

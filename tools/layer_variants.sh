@@ -3,18 +3,18 @@
 #   tools/layer_variants.sh build     HERE (hipcc cross-compiles): libdmad_hip.so.v<N> next to the product library
 #   tools/layer_variants.sh run       ON the GPU box: per variant the per-phase cycle stamps (DMAD_LAYER_STAMPS=1), the un-stamped ms per
 #                                     launch and board power / in-kernel clock under back-to-back launches (tools/gpu_power_trace.py)
-# Variants: 0 product (gate FMA steps as single v_add / v_fma) · 2 ABLATION: no transcendentals (numerically meaningless) ·
-#           3 GEMM2's MFMAs interleaved by sched_group_barrier · 5 the round-4 form (packed fp32 gate math)
-#           EXTRA="-fno-slp-vectorize" adds compile flags to the variant builds            -> gpurun_out/layer_variants/summary.txt
+# Variants: 0 product (packed fp32 gate math) · 1 the gate's FMA steps as single v_add / v_fma (scalar code, -fno-slp-vectorize) ·
+#           2 ABLATION: no transcendentals (numerically meaningless) · 3 GEMM2's MFMAs interleaved by sched_group_barrier
+#           -> gpurun_out/layer_variants/summary.txt
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 PKG=$ROOT/diffusion-model-for-audio-defense_amd
-VARS="${VARS:-0 2 3 5}"
+VARS="${VARS:-0 1 2 3}"
 case "${1:-}" in
 build)
     make -C $PKG/csrc >/dev/null || exit 1
     for v in $VARS; do
-        /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function ${EXTRA:-} -DWNL_VARIANT=$v -c $PKG/csrc/wn_layer.hip -o /tmp/wn_layer_v$v.o || exit 1
+        /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $([ $v = 1 ] && echo -fno-slp-vectorize) ${EXTRA:-} -DWNL_VARIANT=$v -c $PKG/csrc/wn_layer.hip -o /tmp/wn_layer_v$v.o || exit 1
         objs=$(ls $PKG/csrc/*.o | grep -v wn_layer.o)
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $PKG/libdmad_hip.so.v$v $objs /tmp/wn_layer_v$v.o || exit 1
         echo "built libdmad_hip.so.v$v"
