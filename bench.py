@@ -65,12 +65,16 @@ UNET_FLOP_PER_SPEC = 16.76e9                                    # one Improved-D
 def layer_traffic_per_clip():
     """HBM-side bytes per clip per wn_layer launch from the newest rocprofv3 PMC passes committed under profiles/
     (2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE); (None, None) if no such file exists — or if the newest one was taken on
-    ANOTHER version of the layer kernel (the file carries the source hash of csrc/wn_layer.hip): a stale figure is dropped, not shown."""
+    ANOTHER version of the WaveNet kernels (the file carries one hash over csrc/wn_layer.hip, wn_final.hip, wn_bf16.h and dmad_common.h): a
+    stale figure is dropped, not shown."""
     import glob
     import hashlib
     try:
-        with open(os.path.join(ROOT, 'diffusion-model-for-audio-defense_amd', 'csrc', 'wn_layer.hip'), 'rb') as f:
-            now = hashlib.sha256(f.read()).hexdigest()[:16]
+        h = hashlib.sha256()
+        for name in ('wn_layer.hip', 'wn_final.hip', 'wn_bf16.h', 'dmad_common.h'):      # tools/make_profile_summary.py KERNEL_SOURCES
+            with open(os.path.join(ROOT, 'diffusion-model-for-audio-defense_amd', 'csrc', name), 'rb') as f:
+                h.update(f.read())
+        now = h.hexdigest()[:16]
     except Exception:
         now = None
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_layer_traffic.json')), reverse=True):

@@ -1129,15 +1129,21 @@ bool unet_apply_h16(dmad_engine* e, const dmad_engine::UnOp& o, UMap in, int B, 
 
 // eps = UNetModel.forward(x, t * ones)  (unet.py:453-477): x, eps [B][32][32]
 // h16 = 2: the split-f16 middle tier (fp32 pipeline, every conv on split-f16 operands: fp32-grade at several times the fp32 matrix rate).
-// h16 < 0: the tier of the map-returning entry points (dmad_unet_eps / dmad_unet_p_sample): the 16-bit tier in DMAD_MODE_FAST (and in
-// DMAD_MODE_EXACT_VOTES when dmad_set_waveform_tier chose the 16-bit tier), the exact-fp32 UNet otherwise — only the spec-domain vote
-// loop has a recheck, so it alone runs the 16-bit tier by default (it passes h16 = 1); 0 / 1: explicit
+// h16 < 0: the tier of the map-returning entry points (dmad_unet_eps / dmad_unet_p_sample / dmad_spec_query_logits): the 16-bit tier in
+// DMAD_MODE_FAST (and in DMAD_MODE_EXACT_VOTES when dmad_set_waveform_tier chose the 16-bit tier), in DMAD_MODE_EXACT_VOTES otherwise the
+// tier dmad_set_waveform_tier selects — the split-f16 tier by default (fp32-grade, 2.2 x the fp32 rate), the exact-fp32 UNet on request
+// and in DMAD_MODE_FP32 — only the spec-domain vote loop has a recheck, so it alone runs the 16-bit tier by default (it passes h16 = 1);
+// 0 / 1 / 2: explicit
 int unet_eps(dmad_engine* e, const float* x, int t, int B, float* eps, hipStream_t s, int h16 = -1) {
     if (!e->un_final) return fail(DMAD_ERR_STATE, "UNet weights are not finalised (dmad_load_weight + dmad_finalize_weights)");
     if (B < 1 || B > e->maxB) return fail(DMAD_ERR_STATE, "batch %d outside [1, max_batch=%d]", B, e->maxB);
     if (t < 0) return fail(DMAD_ERR_INVALID, "diffusion step %d < 0", t);
     CHK(unet_prepare_step(e, t, s));
-    if (h16 < 0) h16 = (e->un_h16 && (e->mode == DMAD_MODE_FAST || (e->mode == DMAD_MODE_EXACT_VOTES && e->wave_tier == PATH_DEFAULT))) ? 1 : 0;
+    if (h16 < 0) {      // the map-returning surfaces follow dmad_set_waveform_tier like the waveform-returning ones: split-f16 by default on exact-vote engines
+        if (e->un_h16 && (e->mode == DMAD_MODE_FAST || (e->mode == DMAD_MODE_EXACT_VOTES && e->wave_tier == PATH_DEFAULT))) h16 = 1;
+        else if (e->un_x3 && e->mode == DMAD_MODE_EXACT_VOTES && e->wave_tier == PATH_X3) h16 = 2;
+        else h16 = 0;
+    }
     if (h16 == 1 && !e->un_h16) return fail(DMAD_ERR_STATE, "this engine has no 16-bit UNet tier (DMAD_FP32 precision)");
     if (h16 == 1) {
         int H = 32, rot = 0;

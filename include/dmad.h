@@ -265,9 +265,10 @@ int dmad_spec_smooth_votes(dmad_engine* e, const float* clip, float sigma, int32
  * in fp32), softmax, bias and residual sums in fp32 (measured: 4e-3 of max|eps| per evaluation).  DMAD_EXACT engines also hold a
  * SPLIT-F16 MIDDLE TIER: the fp32 pipeline (fp32 maps, GroupNorm, softmax, residual sums) with every conv / 1x1 on split-f16 operands
  * (three f16 MFMAs per product, ~22 significant bits: fp32-grade at several times the fp32 matrix rate).
- * dmad_unet_eps / dmad_unet_p_sample — map-returning surfaces without a recheck — evaluate the exact-fp32 UNet unless the engine is in
- * DMAD_MODE_FAST (or dmad_set_waveform_tier chose the 16-bit tier): the 16-bit tier is opt-in there (DMAD_FP32 engines have only the
- * fp32 one).  In DMAD_MODE_EXACT_VOTES dmad_spec_smooth_votes runs every sample's chain on the 16-bit tier, queues the samples whose
+ * dmad_unet_eps / dmad_unet_p_sample / dmad_spec_query_logits — map- and logit-returning surfaces without a recheck — follow
+ * dmad_set_waveform_tier like the waveform-returning ones: on an exact-vote engine the split-f16 tier by default (within 1e-4 of the
+ * reference fixtures at 2.2 x the fp32 rate), the exact-fp32 UNet with tier 1 (fp32) or in DMAD_MODE_FP32, the 16-bit tier with tier 0
+ * or in DMAD_MODE_FAST (DMAD_FP32 engines have only the fp32 one).  In DMAD_MODE_EXACT_VOTES dmad_spec_smooth_votes runs every sample's chain on the 16-bit tier, queues the samples whose
  * top-2 logit margin is below tau_spec (dmad_set_spec_recheck_margin; default 0.13 = 1.5 x the largest leader-difference error (0.084;
  * Gaussian scale 0.020) of the 16-bit chain measured on 6 144 samples of the calibrated synthetic stand-in) and
  * re-runs their WHOLE chain from the same Philox keys on the split-f16 tier; a sample whose margin is still below tau_spec2
@@ -308,8 +309,8 @@ int dmad_query_logits(dmad_engine* e, const float* x, int32_t B, int32_t repeats
  * spectrogram): row i = r * B + b is clip x[b] through  mel dB -> standardise -> q_sample(t_star) -> t_star + 1 p_sample steps ->
  * un-standardise -> classifier  — the chain of dmad_spec_smooth_votes without the smoothing noise, every draw of row i Philox-keyed
  * (seed, sample0 + i) (q_sample: stream 0x5BEC, p_sample at t: stream 0x0E70 + t), so a row's logits do not depend on how the rows are
- * batched.  The UNet runs the tier of the map-returning surfaces (exact fp32 unless the engine is in DMAD_MODE_FAST), the classifier the
- * fp32 one: a query hands logits back and has no recheck.  Coefficients as for dmad_spec_smooth_votes (HOST arrays of t_star + 1
+ * batched.  The UNet runs the tier of the map-returning surfaces (dmad_set_waveform_tier: split-f16 by default on an exact-vote engine),
+ * the classifier the fp32 one: a query hands logits back and has no recheck.  Coefficients as for dmad_spec_smooth_votes (HOST arrays of t_star + 1
  * entries).  logits: [repeats * B][num_classes]; decisions: optional int32 [repeats * B]. */
 int dmad_spec_query_logits(dmad_engine* e, const float* x, int32_t B, int32_t repeats, int32_t t_star, float q_a, float q_b, const float* c_a,
                            const float* c_b, const float* c_1, const float* c_2, const float* c_sig, float mel_lo, float mel_hi, uint64_t seed,

@@ -1036,7 +1036,7 @@ def test_unet_purifier_vs_reference_fixture(golden_dir):
         ex3 = eng.unet_eps(xt, t, tier=2)
         err3 = relmax(ex3.cpu().numpy(), z['eps_t%d' % t][:, 0])
         assert 0 < err3 < UNET_X3_TOL, (t, err3)
-        assert torch.equal(eng.unet_eps(xt, t, tier=0), eng.unet_eps(xt, t)) and not torch.equal(ex3, eng.unet_eps(xt, t, tier=0))
+        assert torch.equal(ex3, eng.unet_eps(xt, t)) and not torch.equal(ex3, eng.unet_eps(xt, t, tier=0))      # the default of an exact-vote engine's map surfaces
         assert torch.equal(eng.unet_eps(xt[1:], t, tier=2), ex3[1:])                               # batch invariance (no split-K on this tier)
     with pytest.raises(E.DmadError):
         eng.load_wavenet(synth.wavenet_state_dict(1234))       # created with with_wavenet = 0
@@ -1759,7 +1759,7 @@ def test_spec_tier_calibration_and_audit(tmp_path):
     Engine.calibrate_spec_recheck measures the 16-bit chain's leader-difference error for the resident weights at this (sigma, t*) and
     only WIDENS tau_spec (never below the committed default, never below a wider bound the caller put in force);
     RobustCertificate(calibrate=n) runs it once per clip, certify(audit=k) re-runs k tier-1 voters on the exact-fp32 UNet and records
-    the outcome; the map-returning UNet surfaces of an exact-vote engine default to the fp32 tier."""
+    the outcome; the map-returning UNet surfaces of an exact-vote engine default to the split-f16 tier (fp32-grade)."""
     from audio_models.ConvNets_SpeechCommands.models.vgg import vgg19_bn
     from diffusion_models.improved_diffusion_ddpm import create_improved_diffusion, SpecDefense
     from dmad_hip import engine as E
@@ -1788,7 +1788,11 @@ def test_spec_tier_calibration_and_audit(tmp_path):
     eng.set_mode(E.MODE_FP32); e_32 = eng.unet_eps(x, 3)
     eng.set_mode(E.MODE_FAST); e_16 = eng.unet_eps(x, 3)
     eng.set_mode(E.MODE_EXACT_VOTES)
-    assert torch.equal(e_def, e_32) and not torch.equal(e_def, e_16)
+    # default on an exact-vote engine: the split-f16 tier (fp32-grade), like the waveform-returning surfaces; fp32 / 16-bit on request
+    assert torch.equal(e_def, eng.unet_eps(x, 3, tier=2)) and not torch.equal(e_def, e_16)
+    assert 0 < float((e_def - e_32).abs().max()) < 1e-4 * float(e_32.abs().max()) < float((e_16 - e_32).abs().max())
+    eng.set_waveform_tier(E.WAVE_FP32)
+    assert torch.equal(eng.unet_eps(x, 3), e_32)
     eng.set_waveform_tier(E.WAVE_16BIT)
     assert torch.equal(eng.unet_eps(x, 3), e_16)
     eng.set_waveform_tier(E.WAVE_SPLIT)

@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # alternative occur in it (either operand type)
 LAYER = (('wn_layer_p<', 'false, false>'), ('wn_layer_pI', 'Lb0ELb0E'))
 FINAL = (('wn_final_p<',), ('wn_final_pI',))
+KERNEL_SOURCES = ('wn_layer.hip', 'wn_final.hip', 'wn_bf16.h', 'dmad_common.h')      # what the committed counters belong to (bench.py hashes the same files)
 
 
 def one(pattern):
@@ -81,10 +82,14 @@ def main():
         ff, wf = mean_for(f, FINAL, 'FETCH_SIZE'), mean_for(w, FINAL, 'WRITE_SIZE')
         traffic = (2 * fl + wl) * 1024 / a.clips_per_launch
         # the kernel source these counters belong to: bench.py drops `roofline.traffic` when the layer kernel has changed since
-        src = os.path.join(ROOT, 'diffusion-model-for-audio-defense_amd', 'csrc', 'wn_layer.hip')
+        # (since round 5 the hash covers the tail kernel and the shared headers too: KERNEL_SOURCES, the same list bench.py hashes)
         import hashlib
+        h = hashlib.sha256()
+        for name in KERNEL_SOURCES:
+            h.update(open(os.path.join(ROOT, 'diffusion-model-for-audio-defense_amd', 'csrc', name), 'rb').read())
         json.dump({'layer_traffic_bytes_per_clip': traffic, 'fetch_kb': fl, 'write_kb': wl,
-                   'layer_kernel_sha16': hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16]},
+                   'final_traffic_bytes_per_clip': (2 * ff + wf) * 1024 / a.clips_per_launch if ff and wf else None,
+                   'kernel_sources': list(KERNEL_SOURCES), 'layer_kernel_sha16': h.hexdigest()[:16]},
                   open(os.path.join(prof, a.name + '_layer_traffic.json'), 'w'))
         md += ['', '## PMC (separate --pmc passes of the same program)', '',
                'Per launch of `%s` (%d clips), mean over the launches: FETCH_SIZE %.4g KB, WRITE_SIZE %.4g KB.' % ('wn_layer_p<T, false, false>', a.clips_per_launch, fl, wl),
