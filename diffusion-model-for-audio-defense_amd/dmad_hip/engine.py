@@ -365,7 +365,7 @@ class Engine:
             for ci, x in enumerate(clips):
                 args = (x, sigma, sqrt_abar_star, t, c_a, c_b)
                 idx = torch.arange(n, dtype=torch.int64, device=self.device)
-                self.set_mode(MODE_FAST)
+                self.set_mode(MODE_EXACT_VOTES)       # path 0 there = the loop's FIRST PASS: 16-bit WaveNet + the classifier tier it runs (ResNeXt29: split-f16)
                 fast = self.eval_samples(*args, idx, path=0, seed=seed + ci)
                 mid = self.eval_samples(*args, idx, path=2, seed=seed + ci)
                 ref = self.eval_samples(*args, idx[:n_fp32], path=1, seed=seed + ci)

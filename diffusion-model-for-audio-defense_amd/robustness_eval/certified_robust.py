@@ -312,7 +312,7 @@ class RobustCertificate():
         args = (x, sigma, coeffs[3], coeffs[0], coeffs[1], coeffs[2])
         mode = eng.mode
         try:
-            eng.set_mode(0)                         # path 0 = the 16-bit tier
+            eng.set_mode(1)                         # exact-vote mode: path 0 = the loop's first pass (16-bit WaveNet + the classifier tier it runs)
             fast = eng.eval_samples(*args, idx, path=0, seed=seed)
         finally:
             eng.set_mode(mode)
