@@ -1020,8 +1020,7 @@ const float* unet_apply(dmad_engine* e, const dmad_engine::UnOp& o, const float*
         const int C = o.cin, T = H * H;
         if (launch_groupnorm_nhwc(in, o.gn1w, o.gn1b, nullptr, 0, T1, B, T, C, s, nullptr, 0, nullptr, nullptr, nullptr, x3)) return gn_fail(T, C);
         gemm(x3 ? plain_conv1x1(o.w1, o.b1, T1, QKV, 3 * C, C, (long)B * T) : plain_gemm(o.w1, T1, QKV, nullptr, o.b1, 3 * C, C, (long)B * T, 3 * C, C, 0), o.w1x, nref);
-        if (int rc = launch_qkv_attention(QKV, ATT, B, T, kUnHeads, s)) { fail(rc > 0 ? DMAD_ERR_HIP : DMAD_ERR_STATE, "UNet attention (T = %d): %s", T, rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported map size"); return nullptr; }
-        if (x3) launch_scale(ATT, 1.f, ATT, (long)B * T * C, s, true);             // in place: a thread rewrites the 16 bytes it read
+        if (int rc = launch_qkv_attention(QKV, ATT, B, T, kUnHeads, s, nullptr, x3 ? 1 : 0)) { fail(rc > 0 ? DMAD_ERR_HIP : DMAD_ERR_STATE, "UNet attention (T = %d): %s", T, rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported map size"); return nullptr; }      // (x3: the output straight in the split format)
         GemmF32Args g = x3 ? plain_conv1x1(o.w2, o.b2, ATT, out, C, C, (long)B * T) : plain_gemm(o.w2, ATT, out, nullptr, o.b2, C, C, (long)B * T, C, C, 0);
         g.res = in;
         gemm(g, o.w2x, nref);
@@ -1371,6 +1370,11 @@ inline int cls_tier(const dmad_engine* e) {
     if (e->mode == DMAD_MODE_FAST) return e->rx_h16 ? 1 : 0;
     return (e->mode == DMAD_MODE_EXACT_VOTES && e->rx_x3 && e->cls_kind == 1) ? 2 : 0;
 }
+
+// ... and of a recheck tier: the split-f16 WaveNet tier is paired with the classifier's split-f16 tier (ResNeXt29; both fp32-grade, their
+// errors add up to ~3e-4 under tau2 = 1e-3 — the fp32 ResNeXt29 at recheck batch sizes cost 0.8 ms per sample, 45 % on top of the
+// WaveNet's), the exact-fp32 WaveNet tier with the fp32 classifier: what reaches tier 3 is the fp32 path bit for bit
+inline int cls_tier_of_path(const dmad_engine* e, int path) { return (path == PATH_X3 && e->rx_x3 && e->cls_kind == 1) ? 2 : 0; }
 
 }  // namespace
 
@@ -1732,14 +1736,16 @@ int dmad_split_f16(const float* x, int64_t n, float* y, dmad_stream s) {
 }
 
 int dmad_conv_x3(const float* x, const float* x2, int32_t ksplit, const float* w, const float* bias, const float* res, int32_t B, int32_t H,
-                 int32_t M, int32_t K, int32_t taps, int32_t stride, int32_t relu, int32_t out_split, float* out, dmad_stream s) {
+                 int32_t M, int32_t K, int32_t taps, int32_t stride, int32_t groups, int32_t relu, int32_t out_split, int32_t res_split, float* out,
+                 dmad_stream s) {
     if (!x || !w || !out) return fail(DMAD_ERR_INVALID, "null argument");
-    if (B < 1 || H < 1 || M < 1 || K < 1 || (stride != 1 && stride != 2)) return fail(DMAD_ERR_INVALID, "bad geometry");
+    if (B < 1 || H < 1 || M < 1 || K < 1 || groups < 1 || (stride != 1 && stride != 2) || (groups > 1 && x2)) return fail(DMAD_ERR_INVALID, "bad geometry");
     if (int r = gemm_x3_configure()) return fail(DMAD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS, split-f16 tier) failed: %d", r);
     const int Ho = (H - 1) / stride + 1;
     GemmF32Args g{};
-    g.A = w; g.X = x; g.C = out; g.shift = bias; g.res = res; g.M = M; g.K = K; g.taps = taps; g.ldc = M; g.relu = relu; g.N = (long)B * Ho * Ho;
-    g.mode = 2; g.H = H; g.W = H; g.Cin = K; g.ldx = x2 ? ksplit : K; g.stride = stride; g.x3 = 1; g.out_split = out_split;
+    g.A = w; g.X = x; g.C = out; g.shift = bias; g.res = res; g.M = M; g.K = K; g.taps = taps; g.ldc = groups * M; g.relu = relu; g.N = (long)B * Ho * Ho;
+    g.mode = 2; g.H = H; g.W = H; g.Cin = K; g.ldx = x2 ? ksplit : groups * K; g.stride = stride; g.x3 = 1; g.out_split = out_split; g.res_split = res_split;
+    g.groups = groups;
     if (x2) { g.X2 = x2; g.ksplit = ksplit; g.ldx2 = K - ksplit; }
     launch_gemm_f32(g, (hipStream_t)s);
     LASTCHK();
@@ -1860,7 +1866,7 @@ int dmad_eval_samples(dmad_engine* e, const float* clip, float sigma, float sqrt
         launch_lincomb(0, e->xt, e->eps, nullptr, c_a, c_b, 0.f, x0, (long)B * L, st);
         if (logits_out) {
             CHK(mel_db(e, x0, B, e->spec, st));
-            CHK(classify(e, e->spec, B, logits_out + done * C, st, path == PATH_DEFAULT ? cls_tier(e) : 0));
+            CHK(classify(e, e->spec, B, logits_out + done * C, st, path == PATH_DEFAULT ? cls_tier(e) : cls_tier_of_path(e, path)));
         }
     }
     LASTCHK();
@@ -1889,7 +1895,7 @@ int recheck_pass(dmad_engine* e, const RecheckJob& j, const long long* list, lon
         launch_lincomb(0, e->xt, e->eps, nullptr, j.c_a, j.c_b, 0.f, e->x0, (long)B * L, st);
         if (j.x0_out) launch_scatter_rows(e->x0, idx, (long long)j.sample0, j.x0_out, B, L, st);
         CHK(mel_db(e, e->x0, B, e->spec, st));
-        CHK(classify(e, e->spec, B, e->logits, st));
+        CHK(classify(e, e->spec, B, e->logits, st, cls_tier_of_path(e, path)));
         if (j.logits_out) launch_scatter_rows(e->logits, idx, (long long)j.sample0, j.logits_out, B, C, st);
         if (tau >= 0.f) launch_vote_margin(e->logits, B, C, (unsigned long long*)j.counts, tau, 0, idx, next, e->rc_n, e->rc_cap, nullptr, st);
         else launch_vote(e->logits, B, C, (unsigned long long*)j.counts, nullptr, st);

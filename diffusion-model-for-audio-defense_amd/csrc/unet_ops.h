@@ -38,7 +38,8 @@ void launch_upsample2x_nhwc_h16(const h16_t* in, h16_t* out, int B, int H, int W
 // head h: q = channels h*3*64 + [0,64), k = + 64, v = + 128;  out [B*T][C], channel h*64 + c.  Head width 64.
 // T = 256, 64 or 16 (the 16x16, 8x8 and 4x4 maps this network attends at); returns -1 for any other T, a hipError_t > 0
 // if the kernel could not be configured.
-int launch_qkv_attention(const float* qkv, float* out, int B, int T, int heads, hipStream_t s, h16_t* out16 = nullptr);   // out16: write f16 there instead of out
+int launch_qkv_attention(const float* qkv, float* out, int B, int T, int heads, hipStream_t s, h16_t* out16 = nullptr,   // out16: write f16 there instead of out
+                         int split = 0);      // split: `out` is written in the split-f16 storage format (operand of the middle tier's proj GEMM)
 // The same on the 16-bit tier: qkv and out in f16, both products on the f16 matrix cores (fp32 accumulate, fp32 softmax).
 int launch_qkv_attention_h16(const h16_t* qkv, h16_t* out, int B, int T, int heads, hipStream_t s);
 // GaussianDiffusion.p_sample (gaussian_diffusion.py:232-257,331-387: epsilon prediction, clip_denoised, fixed variance):

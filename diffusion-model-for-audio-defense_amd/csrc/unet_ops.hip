@@ -411,7 +411,7 @@ __global__ void upsample2x_nhwc_h16_kernel(const h16_t* __restrict__ in, h16_t* 
 // holds the whole S^T column block (T / 16 tiles) in registers and does the exact two-pass softmax torch does.
 constexpr int HD = 64, AROW = 68;
 template <int KT>                                       // T = 16 * KT keys / queries
-__global__ void __launch_bounds__(KT >= 8 ? 512 : 64 * KT) qkv_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int heads, h16_t* __restrict__ out16) {
+__global__ void __launch_bounds__(KT >= 8 ? 512 : 64 * KT) qkv_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int heads, h16_t* __restrict__ out16, int split) {
     extern __shared__ __attribute__((aligned(16))) float att_lds[];
     constexpr int T = 16 * KT, NW = KT >= 8 ? 8 : KT;
     float* Ks = att_lds;
@@ -474,6 +474,7 @@ __global__ void __launch_bounds__(KT >= 8 ? 512 : 64 * KT) qkv_attention_kernel(
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             if (out16) *(f16x4*)(out16 + ooff + dt * 16) = f16x4{(_Float16)(oacc[dt][0] * inv), (_Float16)(oacc[dt][1] * inv), (_Float16)(oacc[dt][2] * inv), (_Float16)(oacc[dt][3] * inv)};
+            else if (split) *(u32x4_t*)(out + ooff + dt * 16) = split4(oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);      // operand of a split-f16 GEMM
             else *(float4*)(out + ooff + dt * 16) = float4{oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv};
         }
     }
@@ -692,16 +693,16 @@ void launch_upsample2x_nhwc(const float* in, float* out, int B, int H, int W, in
     const long total4 = (long)B * 4 * H * W * (C / 4);
     hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3(nblk(total4, 256)), dim3(256), 0, s, in, out, H, W, C / 4, total4);
 }
-int launch_qkv_attention(const float* qkv, float* out, int B, int T, int heads, hipStream_t s, h16_t* out16) {
+int launch_qkv_attention(const float* qkv, float* out, int B, int T, int heads, hipStream_t s, h16_t* out16, int split) {
     const size_t lds = (size_t)2 * T * AROW * sizeof(float);
     if (T == 256) {
         static const hipError_t once = hipFuncSetAttribute((const void*)qkv_attention_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (once != hipSuccess) return (int)once;
-        hipLaunchKernelGGL(qkv_attention_kernel<16>, dim3((unsigned)heads, (unsigned)B), dim3(512), lds, s, qkv, out, heads, out16);
+        hipLaunchKernelGGL(qkv_attention_kernel<16>, dim3((unsigned)heads, (unsigned)B), dim3(512), lds, s, qkv, out, heads, out16, split);
     } else if (T == 64) {
-        hipLaunchKernelGGL(qkv_attention_kernel<4>, dim3((unsigned)heads, (unsigned)B), dim3(256), lds, s, qkv, out, heads, out16);
+        hipLaunchKernelGGL(qkv_attention_kernel<4>, dim3((unsigned)heads, (unsigned)B), dim3(256), lds, s, qkv, out, heads, out16, split);
     } else if (T == 16) {
-        hipLaunchKernelGGL(qkv_attention_kernel<1>, dim3((unsigned)heads, (unsigned)B), dim3(64), lds, s, qkv, out, heads, out16);
+        hipLaunchKernelGGL(qkv_attention_kernel<1>, dim3((unsigned)heads, (unsigned)B), dim3(64), lds, s, qkv, out, heads, out16, split);
     } else {
         return -1;                  // this network attends at 16x16, 8x8 (script_util.py attention_resolutions "16,8") and 4x4 (middle block)
     }

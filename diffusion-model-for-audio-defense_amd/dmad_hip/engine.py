@@ -798,30 +798,34 @@ def split_f16(x: torch.Tensor) -> torch.Tensor:
 
 
 def conv_x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, relu: bool = False,
-            res: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None, out_split: bool = False) -> torch.Tensor:
+            res: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None, out_split: bool = False, groups: int = 1,
+            res_split: bool = False) -> torch.Tensor:
     """dmad_conv_x3 — the split-f16 conv GEMM as a standalone op (test hook).  x: fp32 NHWC [B,H,H,Cx], x2: optional second map whose
-    channels follow x's; w: fp32 [taps, M, K]; bias fp32 [M]; res fp32 [B,Ho,Ho,M].  Operands are converted with split_f16 here."""
+    channels follow x's (dense only); w: fp32 [taps, M, K] (dense) or [groups, taps, M, K]; bias fp32 [groups*M]; res fp32
+    [B,Ho,Ho,groups*M] (res_split: handed to the kernel in the split format).  Operands are converted with split_f16 here."""
     lib = _lib.load()
-    assert x.is_cuda and x.dtype == torch.float32 and w.is_cuda and w.dtype == torch.float32 and x.dim() == 4 and w.dim() == 3
+    assert x.is_cuda and x.dtype == torch.float32 and w.is_cuda and w.dtype == torch.float32 and x.dim() == 4 and w.dim() in (3, 4)
+    if w.dim() == 3:
+        w = w[None]
     B, H, W_, cx = x.shape
-    assert H == W_
-    taps, M, K = w.shape
+    assert H == W_ and w.shape[0] == groups
+    _, taps, M, K = w.shape
     xs, ws = split_f16(x), split_f16(w)
     x2s, ksplit = None, 0
     if x2 is not None:
-        assert x2.shape[:3] == x.shape[:3] and cx + x2.shape[3] == K
+        assert groups == 1 and x2.shape[:3] == x.shape[:3] and cx + x2.shape[3] == K
         x2s, ksplit = split_f16(x2), cx
     else:
-        assert cx == K
+        assert cx == groups * K
     Ho = (H - 1) // stride + 1
-    out = torch.empty((B, Ho, Ho, M), device=x.device, dtype=torch.float32)
+    out = torch.empty((B, Ho, Ho, groups * M), device=x.device, dtype=torch.float32)
     if bias is not None:
         bias = bias.detach().contiguous().float()
     if res is not None:
-        assert tuple(res.shape) == (B, Ho, Ho, M) and res.dtype == torch.float32
-        res = res.contiguous()
-    check(lib.dmad_conv_x3(_ptr(xs), _ptr(x2s), int(ksplit), _ptr(ws), _ptr(bias), _ptr(res), B, H, M, K, taps, int(stride), 1 if relu else 0,
-                           1 if out_split else 0, _ptr(out), _stream()))
+        assert tuple(res.shape) == (B, Ho, Ho, groups * M) and res.dtype == torch.float32
+        res = split_f16(res) if res_split else res.contiguous()
+    check(lib.dmad_conv_x3(_ptr(xs), _ptr(x2s), int(ksplit), _ptr(ws), _ptr(bias), _ptr(res), B, H, M, K, taps, int(stride), int(groups),
+                           1 if relu else 0, 1 if out_split else 0, 1 if res_split else 0, _ptr(out), _stream()))
     return out
 
 

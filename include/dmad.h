@@ -177,8 +177,9 @@ int dmad_classify(dmad_engine* e, const float* spec, int32_t B, float* logits, d
  * covering it would send a quarter of the samples to the recheck tiers — so since round 5 the first pass of the exact-vote mode runs
  * the classifier's SPLIT-F16 TIER instead (DMAD_EXACT engines): every conv on split-f16 operands (three f16 MFMAs per product, ~22
  * significant bits; BatchNorm scale / shift, shortcut add and ReLU in the fp32 epilogue), fp32-grade at a third of the fp32 tier's
- * time.  The recheck tiers, dmad_query_logits and dmad_classify always use the fp32 matrix cores, so a re-evaluated sample's logits
- * are the fp32 path's.  dmad_classify_tier evaluates an explicit tier (0: fp32, 1: 16-bit, 2: split-f16; VGG19_bn has one tier and is
+ * time.  The split-f16 WaveNet recheck tier is paired with the same classifier tier (together 2.2e-4 from the all-fp32 logits, under
+ * tau2 = 1e-3); the exact-fp32 recheck tier, dmad_query_logits and dmad_classify use the fp32 matrix cores, so a sample that reaches the
+ * last tier carries the fp32 path's logits bit for bit.  dmad_classify_tier evaluates an explicit tier (0: fp32, 1: 16-bit, 2: split-f16; VGG19_bn has one tier and is
  * served on fp32 either way) — test / measurement hook. */
 int dmad_classify_tier(dmad_engine* e, const float* spec, int32_t B, int32_t tier, float* logits, dmad_stream s);
 
@@ -368,12 +369,14 @@ int dmad_groupnorm16_apply(const uint16_t* x, const float* st, const uint16_t* x
 /* Test hooks of the split-f16 conv GEMM (csrc/gemm_f32.hip, gemm_x3_kernel in its NHWC form: the kernel behind the UNet's middle tier),
  * standalone.  dmad_split_f16: y = the split-f16 storage form of the n fp32 values x (n % 4 == 0; hi = f16(v), lo = f16((v - hi) 2^11), four
  * values per 16-byte chunk: the bytes of four floats; x == y allowed).  dmad_conv_x3: NHWC convolution of split-format operands — x
- * [B][H][H][K] (or x | x2 with ksplit channels in x), w [taps][M][K] (taps 9 = 3x3 zero padding 1, or 1), fp32 bias [M], optional fp32
- * residual [N][M], stride 1 / 2, optional ReLU — every product as three f16 MFMAs; out [N][M] fp32, or in the split format (out_split).
+ * [B][H][H][groups * K] (or, dense only, x | x2 with ksplit channels in x), w [groups][taps][M][K] (taps 9 = 3x3 zero padding 1, or 1),
+ * fp32 bias [groups * M], optional residual [N][groups * M] (fp32, or a split-format map with res_split), stride 1 / 2, optional ReLU —
+ * every product as three f16 MFMAs; out [N][groups * M] fp32, or in the split format (out_split).  M and K are per group;
  * M % 128 == 0, K % 32 == 0 (ksplit % 32 == 0). */
 int dmad_split_f16(const float* x, int64_t n, float* y, dmad_stream s);
 int dmad_conv_x3(const float* x, const float* x2, int32_t ksplit, const float* w, const float* bias, const float* res, int32_t B, int32_t H,
-                 int32_t M, int32_t K, int32_t taps, int32_t stride, int32_t relu, int32_t out_split, float* out, dmad_stream s);
+                 int32_t M, int32_t K, int32_t taps, int32_t stride, int32_t groups, int32_t relu, int32_t out_split, int32_t res_split, float* out,
+                 dmad_stream s);
 
 /* Bytes of device memory held by the engine. */
 int64_t dmad_device_bytes(const dmad_engine* e);

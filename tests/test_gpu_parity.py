@@ -842,43 +842,49 @@ def test_gemm_h16_family_vs_torch_conv(case):
 
 
 
-X3_CASES = [   # B, H, cin, cout, taps, stride, c1 (two-part input), residual, relu
-    (2, 32, 128, 128, 9, 1, 0, True, False), (1, 32, 128, 128, 9, 1, 0, False, False),         # the 128 x 256 tile (M = 128), one image
-    (3, 16, 256, 256, 9, 1, 0, False, True), (2, 32, 256, 256, 9, 2, 0, False, False),         # the 256 x 128 tile; stride 2
-    (2, 16, 384, 128, 1, 1, 256, False, False), (5, 8, 512, 256, 9, 1, 256, True, False),      # two-part input: 1x1 skip conv, 3x3 with residual
-    (7, 4, 256, 768, 1, 1, 0, False, False), (65, 32, 384, 128, 9, 1, 256, True, False),       # qkv-like 1x1 on 4x4 maps; many tiles with an N tail
+X3_CASES = [   # B, H, cin, cout, taps, stride, c1 (two-part input), residual (2: handed over in the split format), relu, groups
+    (2, 32, 128, 128, 9, 1, 0, 1, False, 1), (1, 32, 128, 128, 9, 1, 0, 0, False, 1),         # the 128 x 256 tile (M = 128), one image
+    (3, 16, 256, 256, 9, 1, 0, 0, True, 1), (2, 32, 256, 256, 9, 2, 0, 0, False, 1),          # the 256 x 128 tile; stride 2
+    (2, 16, 384, 128, 1, 1, 256, 0, False, 1), (5, 8, 512, 256, 9, 1, 256, 1, False, 1),      # two-part input: 1x1 skip conv, 3x3 with residual
+    (7, 4, 256, 768, 1, 1, 0, 0, False, 1), (65, 32, 384, 128, 9, 1, 256, 1, False, 1),       # qkv-like 1x1 on 4x4 maps; many tiles with an N tail
+    # ResNeXt29's forms: grouped 3x3 (4 paired groups of 128 / 8 groups of 256, stride 2, ReLU), 1x1 with K = 64, a split-format residual
+    (3, 16, 512, 512, 9, 1, 0, 0, True, 4), (2, 16, 2048, 2048, 9, 2, 0, 0, True, 8), (2, 32, 64, 512, 1, 1, 0, 0, True, 1),
+    (3, 8, 1024, 512, 1, 1, 0, 2, True, 1),
 ]
 
 
-@pytest.mark.parametrize('case', X3_CASES, ids=lambda c: 'B%d_H%d_%dto%d_t%d_s%d_c1%d_r%d_relu%d' % tuple(int(v) for v in c))
+@pytest.mark.parametrize('case', X3_CASES, ids=lambda c: 'B%d_H%d_%dto%d_t%d_s%d_c1%d_r%d_relu%d_g%d' % tuple(int(v) for v in c))
 def test_gemm_x3_conv_vs_torch(case):
-    """The split-f16 conv GEMM (gemm_x3_kernel in its NHWC form, csrc/gemm_f32.hip: the UNet's middle tier — 3x3 / 1x1, stride 2,
-    two-part input, residual, both tile shapes) through dmad_conv_x3 against a float64 torch convolution of the same fp32 operands
-    (improved_diffusion/unet.py:107-252 are the callers' ops): every product is three f16 MFMAs on hi / lo pairs, ~22 significant
-    bits — the result must be fp32-grade (1e-5 of the output scale; the f16 family's is 2e-3), a sample's result must not depend on
-    its batch, and out_split writes the split form of the same values."""
+    """The split-f16 conv GEMM (gemm_x3_kernel in its NHWC form, csrc/gemm_f32.hip: the UNet's and ResNeXt29's middle tiers — 3x3 /
+    1x1, stride 2, two-part input, grouped, fp32 or split-format residual, both tile shapes) through dmad_conv_x3 against a float64
+    torch convolution of the same fp32 operands (improved_diffusion/unet.py:107-252, models/resnext.py:23-62 are the callers' ops):
+    every product is three f16 MFMAs on hi / lo pairs, ~22 significant bits — the result must be fp32-grade (1e-5 of the output
+    scale; the f16 family's is 2e-3), a sample's result must not depend on its batch, and out_split writes the split form of the
+    same values."""
     from dmad_hip import engine as E
-    B, H, cin, cout, taps, stride, c1, with_res, relu = case
+    B, H, cin, cout, taps, stride, c1, with_res, relu, groups = case
     g = torch.Generator().manual_seed(2000 + B + H + cin)
+    Kg, Mg = cin // groups, cout // groups
     x = (torch.rand(B, H, H, cin, generator=g) * 2 - 1).cuda()
-    w = ((torch.rand(taps, cout, cin, generator=g) * 2 - 1) * 0.1).cuda()
+    w = ((torch.rand(groups, taps, Mg, Kg, generator=g) * 2 - 1) * 0.1).cuda()
     bias = (torch.rand(cout, generator=g) * 2 - 1).cuda()
     Ho = (H - 1) // stride + 1
     res = (torch.rand(B, Ho, Ho, cout, generator=g) * 2 - 1).cuda() if with_res else None
     xa, xb = (x[..., :c1].contiguous(), x[..., c1:].contiguous()) if c1 else (x, None)
-    out = E.conv_x3(xa, w, bias, stride=stride, relu=bool(relu), res=res, x2=xb)
+    kw = dict(stride=stride, relu=bool(relu), groups=groups, res_split=with_res == 2)
+    out = E.conv_x3(xa, w, bias, res=res, x2=xb, **kw)
     k = 3 if taps == 9 else 1
-    wt = w.double().reshape(k, k, cout, cin).permute(2, 3, 0, 1)
-    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wt, bias=bias.double(), stride=stride, padding=k // 2).permute(0, 2, 3, 1)
+    wt = w.double().reshape(groups, k, k, Mg, Kg).permute(0, 3, 4, 1, 2).reshape(cout, Kg, k, k)
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wt, bias=bias.double(), stride=stride, padding=k // 2, groups=groups).permute(0, 2, 3, 1)
     if res is not None:
         ref = ref + res.double()
     if relu:
         ref = torch.relu(ref)
     err = float((out.double() - ref).abs().max()) / float(ref.abs().max())
     assert err < 1e-5, err
-    solo = E.conv_x3(xa[:1], w, bias, stride=stride, relu=bool(relu), res=None if res is None else res[:1], x2=None if xb is None else xb[:1])
+    solo = E.conv_x3(xa[:1], w, bias, res=None if res is None else res[:1], x2=None if xb is None else xb[:1], **kw)
     assert torch.equal(solo, out[:1])                                              # no split-K: batch-invariant bits
-    sp = E.conv_x3(xa, w, bias, stride=stride, relu=bool(relu), res=res, x2=xb, out_split=True)
+    sp = E.conv_x3(xa, w, bias, res=res, x2=xb, out_split=True, **kw)
     assert torch.equal(sp.view(torch.int32), E.split_f16(out).view(torch.int32))   # the split form of the same fp32 values
 
 

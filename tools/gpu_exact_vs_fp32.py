@@ -14,7 +14,11 @@ SIGMAS = [float(s) for s in os.environ.get('SIGMAS', '0.5,0.25').split(',')]
 HALF = os.environ.get('HALF', 'f16')           # operand format of tier 1 (bf16: bound 0.30 instead of 0.034, far more rechecks)
 eng = E.Engine(max_batch=256, precision=E.EXACT, recheck_batch=64, half_type=E.HALF_F16 if HALF == 'f16' else E.HALF_BF16)
 eng.load_wavenet(synth.wavenet_state_dict(1234))
-eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321))
+CLASSIFIER = os.environ.get('CLASSIFIER', 'vgg19_bn')     # resnext29: the reference script's default classifier (calibrated stand-in)
+if CLASSIFIER == 'resnext29':
+    eng.load_resnext29(synth.resnext29_state_dict(2929))
+else:
+    eng.load_vgg19_bn(synth.vgg19_bn_state_dict(4321))
 ab = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)['Alpha_bar']
 CLIP = int(os.environ.get('CLIP', 0))
 clip = torch.from_numpy(synth.synthetic_clip(CLIP)).cuda()
@@ -23,7 +27,7 @@ out = []
 for sigma in SIGMAS:
     t = int(torch.abs(ab - 1 / (1 + sigma ** 2)).min(0, keepdim=True)[1].item())
     args = (clip, sigma, float(torch.tensor((1 / (1 + sigma ** 2)) ** 0.5, dtype=torch.float32)), t, float((1 / ab).sqrt()[t]), float((1 / ab - 1).sqrt()[t]), N)
-    rec = {'clip': CLIP, 'half': HALF, 'sigma': sigma, 't_star': t + 1, 'n': N, 'margins': [eng.recheck_margin, eng.recheck_margin2]}
+    rec = {'clip': CLIP, 'half': HALF, 'classifier': CLASSIFIER, 'sigma': sigma, 't_star': t + 1, 'n': N, 'margins': [eng.recheck_margin, eng.recheck_margin2]}
     ref = next((r for r in (REF or []) if r.get('clip', 0) == CLIP and r['sigma'] == sigma and r['n'] == N), None)
     if REF is not None and ref is None:
         raise SystemExit('no record for clip %d sigma %g n %d in %s' % (CLIP, sigma, N, os.environ['REF']))
@@ -45,5 +49,5 @@ for sigma in SIGMAS:
     rec['fast_differs_by'] = sum(abs(a - b) for a, b in zip(rec['fast']['counts'], rec['fp32']['counts'])) // 2
     print(json.dumps(rec), flush=True)
     out.append(rec)
-    json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'exact_vs_fp32_clip%d.json' % CLIP), 'w'), indent=1)
+    json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'exact_vs_fp32_%sclip%d.json' % ('' if CLASSIFIER == 'vgg19_bn' else CLASSIFIER + '_', CLIP)), 'w'), indent=1)
 assert all(r['exact_equals_fp32'] for r in out)
