@@ -36,8 +36,13 @@ DEFAULT_RECHECK_MARGIN_RESNEXT29 = {1: 0.045, 0: 0.40}
 # only those whose margin is inside ITS error bound reach the exact-fp32 path.
 DEFAULT_RECHECK_MARGIN2 = 1e-3
 # Spec-domain vote loop (BASELINE C5): the UNet's 16-bit tier runs the whole 26-evaluation chain on f16 operands; a sample whose
-# top-2 logit margin is below this bound re-runs its chain on the exact-fp32 UNet.  Measured with tools/gpu_c5_flip_study.py
-# (profiles/r03_c5_flip_study.md): the same leader-difference statistic as DEFAULT_RECHECK_MARGIN, x headroom.
+# top-2 logit margin is below this bound re-runs its chain on a higher tier.  Measured with tools/gpu_c5_flip_study.py at the bench's
+# engine batch 2048 on the CALIBRATED synthetic VGG19_bn (profiles/r05c_c5_flip_study.json, 6 144 samples, sigma 0.5, t* 25): the same
+# leader-difference statistic as DEFAULT_RECHECK_MARGIN, 0.084 max, Gaussian scale 0.0198 -> 0.13 = 1.5 x max = 6.6 scales:
+# P(E >= 0.13) = 4.9e-10 per sample by the Gaussian tail (the pessimistic one here: the generalised-Pareto fit of the top 61 has a
+# negative shape and ends below 0.10; profiles/r05c_c5_recheck_tail_fit.txt), 1.5e-12 with the margin condition.  Like every bound of
+# this file it is a property of the WEIGHTS: calibrate (calibrate_spec_recheck / RobustCertificate(calibrate=...)) before certifying
+# with real checkpoints — round 4's 0.5 belonged to an uncalibrated stand-in whose logits were 50 x larger.
 DEFAULT_SPEC_RECHECK_MARGIN = 0.13
 # ... and the samples it queues first re-run their chain on the UNet's split-f16 tier (fp32 pipeline, three f16 MFMAs per product); only
 # those whose margin is inside THAT tier's error bound reach the exact-fp32 UNet (dmad_set_spec_recheck_margin2; < 0: no middle tier).

@@ -529,7 +529,7 @@ def test_certificate_calibration_and_audit_host_logic():
     assert rec['audited'] == 16 and rec['voted_on_tier1'] == len(voters) and rec['tau1'] == 0.040
     flips = [d for d in rec['disagreements']]
     assert flips == ([(7, 3, 5, pytest.approx(0.07, abs=1e-6))] if 7 in voters else [])
-    assert eng.modes[-2:] == [0, 1] and rc.audit_log[-1] is rec and 'audit:' in lines[-1]
+    assert eng.modes[-2:] == [1, 1] and rc.audit_log[-1] is rec and 'audit:' in lines[-1]      # the first pass is evaluated in the exact-vote mode (its classifier tier), the mode restored
     # certify(audit=k) audits every example
     y, r = rc.certify(x.reshape(1, 1, 16000), torch.tensor([3]), sigma=0.5, n_0=10, n=40, batch_size=8, audit=8)
     assert int(y[0]) == 3 and len(rc.audit_log) == 2 and rc.audit_log[-1]['audited'] == 8
