@@ -520,8 +520,9 @@ def main():
                "recheck_margin": engr.recheck_margin, "votes": rvotes, "voted_classes": sum(1 for v in rvotes if v > 0),
                "exact_equals_fp32": rx_ == rp_, "votes_exact_first_step": rx_,
                "votes_fp32_first_step": rp_, "check_samples": S * world,
-               "classifier_tiers": "exact-vote mode: fp32 matrix cores in every tier (the f16 classifier's error does not fit under the bound: "
-                                   "profiles/r05b_resnext29_error_attribution.json); fast mode: gemm_h16 (f16 operands, fp32 accumulate)"}
+               "classifier_tiers": "exact-vote mode: the classifier's split-f16 tier (three f16 MFMAs per product, fp32-grade) in the first pass and "
+                                   "the split-f16 recheck tier, fp32 matrix cores in the last tier (the f16 classifier's error does not fit under the "
+                                   "bound: profiles/r05b_resnext29_error_attribution.json); fast mode: gemm_h16 (f16 operands, fp32 accumulate)"}
         engr.close()
         cur['eng'] = eng
 

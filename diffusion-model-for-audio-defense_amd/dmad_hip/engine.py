@@ -31,6 +31,7 @@ DEFAULT_RECHECK_MARGIN = {1: 0.034, 0: 0.30}          # by dmad_half_type: HALF_
 # The error a given eps error turns into is a property of the classifier.  With the calibrated synthetic ResNeXt29 (fp32 classifier in
 # every tier of the exact-vote mode; tools/gpu_flip_study.py with CLASSIFIER=resnext29, profiles/r05b_flip_study_resnext29_fp32cls.json,
 # 18 432 samples): E = 0.0300, Gaussian scale 0.0065 -> 1.5 x E = 0.045 >= 5.4 scales.  load_resnext29 widens the bound to this floor.
+# (the bf16 entry is the f16 one scaled by the VGG table's ratio 0.30 / 0.034, NOT measured: calibrate before using bf16 operands with it)
 DEFAULT_RECHECK_MARGIN_RESNEXT29 = {1: 0.045, 0: 0.40}
 # The queued samples first go through the split-f16 tier (fp32 pipeline, three f16 MFMAs per product, ~22 significant bits);
 # only those whose margin is inside ITS error bound reach the exact-fp32 path.
