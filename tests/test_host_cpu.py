@@ -167,6 +167,70 @@ def test_acoustic_system_semantics():
     assert torch.allclose(spec(x), (x + 1) * 2)
 
 
+def test_spec_defense_query_routing_host_logic():
+    """AcousticSystem(defense_type='spec').query routes to ONE engine call (spec_query_logits) exactly when the classifier, the mel
+    transform and a SpecPurifier sit on one engine: argument block = the purifier's coefficient table + the mel-dB bounds, rows
+    keyed from the purifier's draw counter, the counter advanced by repeats * B; everything else loops over forward()
+    (acoustic_system.py:40-49; host logic only: the engine is a stub)."""
+    from acoustic_system import AcousticSystem
+    from diffusion_models.improved_diffusion_ddpm import ImprovedDiffusion, SpecPurifier
+    from dmad_hip.transforms import MelSpectrogramDB
+
+    class Eng:
+        has_classifier, has_wavenet, num_classes = True, False, 10
+
+        def __init__(self):
+            self.calls = []
+
+        def spec_query_logits(self, x, repeats, *args, seed=0, sample0=0):
+            self.calls.append(('spec', tuple(x.shape), repeats, args, seed, sample0))
+            n = repeats * x.shape[0]
+            return torch.arange(n * 10, dtype=torch.float32).reshape(n, 10), torch.full((n,), 9, dtype=torch.int32)
+
+        def query_logits(self, x, repeats, sampler, *a, **k):
+            self.calls.append(('wave', sampler, repeats))
+            n = repeats * x.shape[0]
+            return torch.zeros(n, 10), torch.zeros(n, dtype=torch.int32)
+
+    class Model(torch.nn.Module):           # stands for the HIP UNet: only `.engine` is read on this path
+        pass
+
+    class Diff:
+        def _f32(self, arr, t):
+            return float(arr[t])
+        sqrt_alphas_cumprod = sqrt_one_minus_alphas_cumprod = sqrt_recip_alphas_cumprod = sqrt_recipm1_alphas_cumprod = [0.9, 0.8, 0.7, 0.6]
+        posterior_mean_coef1 = posterior_mean_coef2 = [0.1, 0.2, 0.3, 0.4]
+        model_log_variance = [-9.0, -8.0, -7.0, -6.0]
+    eng = Eng()
+    model = Model(); model.engine = eng
+    pur = ImprovedDiffusion(model=model, diffusion=Diff(), reverse_timestep=2)
+    den = SpecPurifier(pur, seed=77)
+    clf = torch.nn.Identity(); clf.engine = eng
+    mel = MelSpectrogramDB(eng)
+    sys_ = AcousticSystem(classifier=clf, transform=mel, defender=den, defense_type='spec')
+    assert sys_._engine_chain(True) == (eng, 3) and sys_._engine_chain(False) == (eng, 0)
+    x = torch.zeros(3, 1, 16000)
+
+    class FakeCuda(torch.Tensor):           # query() takes the engine route for CUDA tensors only
+        @property
+        def is_cuda(self):
+            return True
+    xc = x.as_subclass(FakeCuda)
+    den._draws = 50
+    logits, dec = sys_.query(xc, repeats=4)
+    assert logits.shape == (4, 3, 10) and dec.shape == (4, 3) and dec.dtype == torch.int64 and den._draws == 62
+    kind, shape, rep, args, seed, s0 = eng.calls[-1]
+    assert (kind, shape, rep, seed, s0) == ('spec', (3, 1, 16000), 4, 77, 50)
+    ts, q_a, q_b, c_a, c_b, c_1, c_2, c_sig, lo, hi = args
+    assert ts == 2 and len(c_a) == len(c_sig) == 3 and c_sig[0] == 0.0 and (lo, hi) == (-100.0, 38.22) and abs(q_a - 0.7) < 1e-6
+    sys_.query(xc, repeats=2, defend=False)
+    assert eng.calls[-1] == ('wave', 0, 2) and den._draws == 62                    # no defender: the plain query, no draws consumed
+    other = AcousticSystem(classifier=clf, transform=mel, defender=torch.nn.Identity(), defense_type='spec')
+    assert other._engine_chain(True) == (None, 0)                                   # an unknown spec defender: the forward loop
+    den2 = SpecPurifier(ImprovedDiffusion(model=Model(), diffusion=Diff(), reverse_timestep=2))
+    assert AcousticSystem(classifier=clf, transform=mel, defender=den2, defense_type='spec')._engine_chain(True) == (None, 0)   # a purifier on no / another engine
+
+
 def test_create_model_checkpoint_layouts(tmp_path, golden_dir):
     """whole-module pickles: bare M5 and DataParallel(VGG) under a 'ConvNets_SpeechCommands' path."""
     from audio_models.ConvNets_SpeechCommands.create_model import create_model
