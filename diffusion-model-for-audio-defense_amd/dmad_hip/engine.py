@@ -28,9 +28,10 @@ WAVE_16BIT, WAVE_FP32, WAVE_SPLIT = 0, 1, 2       # dmad_set_waveform_tier: Wave
 # profiles/r02_flip_study.md): f16 operands E = 0.0244 (0.0287 over all pairs i, j; 35 flips, the largest at margin 0.011),
 # bf16 operands 0.207 (0.221; 261 flips) -> bounds with ~1.4x headroom.  Overridable: DMAD_RECHECK_MARGIN / recheck_margin=.
 DEFAULT_RECHECK_MARGIN = {1: 0.034, 0: 0.30}          # by dmad_half_type: HALF_F16, HALF_BF16
-# The error a given eps error turns into is a property of the classifier.  With the calibrated synthetic ResNeXt29 (fp32 classifier in
-# every tier of the exact-vote mode; tools/gpu_flip_study.py with CLASSIFIER=resnext29, profiles/r05b_flip_study_resnext29_fp32cls.json,
-# 18 432 samples): E = 0.0300, Gaussian scale 0.0065 -> 1.5 x E = 0.045 >= 5.4 scales.  load_resnext29 widens the bound to this floor.
+# The error a given eps error turns into is a property of the classifier.  With the calibrated synthetic ResNeXt29 (first pass of the
+# exact-vote mode = f16 WaveNet + the classifier's split-f16 tier; tools/gpu_flip_study.py with CLASSIFIER=resnext29 FIRSTPASS=1,
+# profiles/r05h_flip_study_resnext29_first_pass.json, 36 864 samples): E = 0.0303, Gaussian scale 0.0065 -> 1.5 x E = 0.045 = 7 scales,
+# P(E >= 0.045) = 4.5e-11 per sample.  load_resnext29 widens the bound to this floor.
 # (the bf16 entry is the f16 one scaled by the VGG table's ratio 0.30 / 0.034, NOT measured: calibrate before using bf16 operands with it)
 DEFAULT_RECHECK_MARGIN_RESNEXT29 = {1: 0.045, 0: 0.40}
 # The queued samples first go through the split-f16 tier (fp32 pipeline, three f16 MFMAs per product, ~22 significant bits);

@@ -26,6 +26,7 @@ N = int(os.environ.get('N', 4096))
 CLIPS = [int(c) for c in os.environ.get('CLIPS', '0,1,2').split(',')]
 SIGMAS = [float(s) for s in os.environ.get('SIGMAS', '0.25,0.5,1.0').split(',')]
 CLASSIFIER = os.environ.get('CLASSIFIER', 'vgg19_bn')
+FIRSTPASS = os.environ.get('FIRSTPASS', '0') == '1'      # '16-bit' leg = the exact-vote mode's first pass instead of the fast mode (differs for ResNeXt29: split-f16 vs f16 classifier)
 TAUS = (0.01, 0.02, 0.03, 0.034, 0.04, 0.05, 0.075, 0.1, 0.15, 0.2, 0.3, 0.5)
 OUT = os.path.join(ROOT, 'gpurun_out')
 os.makedirs(OUT, exist_ok=True)
@@ -61,7 +62,13 @@ for ci in CLIPS:
                 e.set_mode(mode); e.set_recheck_margin(TAU1); e.set_recheck_margin2(TAU2)
             torch.cuda.synchronize()
             t0 = time.time()
-            c, l, _ = e.smooth_votes(clip, sigma, sc, t, c_a, c_b, N, seed=1000 + ci, sample0=0, want_logits=True)
+            if name == 'bf16' and FIRSTPASS:      # the exact-vote loop's FIRST PASS (16-bit WaveNet + the classifier tier it runs there), nothing rechecked
+                e.set_mode(E.MODE_EXACT_VOTES)
+                l = torch.cat([e.eval_samples(clip, sigma, sc, t, c_a, c_b, torch.arange(i, min(N, i + 8192), device='cuda'), path=0, seed=1000 + ci)
+                               for i in range(0, N, 8192)])
+                c = torch.bincount(l.argmax(1), minlength=l.shape[1])
+            else:
+                c, l, _ = e.smooth_votes(clip, sigma, sc, t, c_a, c_b, N, seed=1000 + ci, sample0=0, want_logits=True)
             torch.cuda.synchronize()
             secs[name] = time.time() - t0
             lg[name], cnt[name] = l.cpu().numpy().astype(np.float64), c.cpu().tolist()
@@ -77,7 +84,7 @@ for ci in CLIPS:
         pair_err = np.abs((b[:, :, None] - b[:, None, :]) - (f[:, :, None] - f[:, None, :])).max((1, 2))
         e_ = b - f                       # what the recheck bound has to cover: the error of a difference AGAINST THE fp32 LEADER
         lead_err = np.abs(e_ - e_[rows, f.argmax(1)][:, None]).max(1)
-        rec = {'half': HALF, 'clip': ci, 'sigma': sigma, 't_star': t + 1, 'n': N, 'counts_bf16': cnt['bf16'], 'counts_fp32': cnt['fp32'],
+        rec = {'half': HALF, 'classifier': CLASSIFIER, 'first_pass_of_exact_mode': FIRSTPASS, 'clip': ci, 'sigma': sigma, 't_star': t + 1, 'n': N, 'counts_bf16': cnt['bf16'], 'counts_fp32': cnt['fp32'],
                'flips': int(flips.sum()), 'logit_err_max': float(err.max()), 'logit_err_rms': float(np.sqrt((err ** 2).mean())),
                'top2_diff_err_max': float(np.abs(dd).max()), 'top2_diff_err_rms': float(np.sqrt((dd ** 2).mean())),
                'pair_diff_err_max': float(pair_err.max()), 'leader_diff_err_max': float(lead_err.max()),
