@@ -772,6 +772,13 @@ def test_resnext29_16bit_tier_and_exact_votes(golden_dir, weights, sched):
     assert reached_fp32 >= 1                                                      # ... down to the exact-fp32 tier
     assert worst < eng.recheck_margin, (worst, eng.recheck_margin)                # the bound covers tier 1's error with the split-f16 classifier
     assert worst_fast > eng.recheck_margin, worst_fast                            # ... and would NOT cover the f16 classifier's (why it is FAST-only)
+    # calibration measures the loop's FIRST PASS (f16 WaveNet + split-f16 classifier), not the fast mode's f16 classifier: the observed
+    # error stays below the committed bound of this classifier kind, which therefore stands (a calibration only widens)
+    t = int(torch.abs(ab - 1 / 1.25).min(0, keepdim=True)[1].item())
+    tau1, tau2, e1, e2 = eng.calibrate_recheck(clip, 0.5, float(torch.tensor((1 / 1.25) ** 0.5, dtype=torch.float32)), t, *coef(t), n=128, n_fp32=64)
+    floor = E.DEFAULT_RECHECK_MARGIN_RESNEXT29[E.HALF_F16]
+    assert 0 < e1 < floor and floor <= tau1 < 0.07, (tau1, e1)                    # (with the f16 classifier in the measured pass e1 would be ~0.1)
+    assert 0 < e2 < tau2 and tau2 >= E.DEFAULT_RECHECK_MARGIN2 and eng.mode == E.MODE_EXACT_VOTES
     eng.close()
 
 
