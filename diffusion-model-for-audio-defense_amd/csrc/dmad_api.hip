@@ -1381,7 +1381,7 @@ inline int cls_tier_of_path(const dmad_engine* e, int path) { return (path == PA
 extern "C" {
 
 const char* dmad_last_error(void) { return g_err.c_str(); }
-const char* dmad_version(void) { return "dmad-hip 0.3 (gfx950)"; }
+const char* dmad_version(void) { return "dmad-hip 0.5 (gfx950)"; }
 const char* dmad_last_warning(void) { return g_warn.c_str(); }
 
 int dmad_create(const dmad_config* cfg, dmad_engine** out) {

@@ -55,7 +55,7 @@ def test_c_abi_fails_loudly_without_gpu(built_lib):
     old = _lib.DmadConfig(256, 256, 36, 12, 128, 512, 512, 16000, 1, 10, 0, 1, 0, 0)
     old.struct_size = 12 * 4                               # the round-1 layout: no struct_size, recheck_batch, half_type
     assert lib.dmad_create(ctypes.byref(old), ctypes.byref(h)) == -1 and b'struct_size' in lib.dmad_last_error()
-    assert b'dmad-hip 0.3' in lib.dmad_version() and lib.dmad_last_warning() == b''
+    assert b'dmad-hip 0.5' in lib.dmad_version() and lib.dmad_last_warning() == b''
 
 
 def test_lds_layouts_are_bank_conflict_free():
