@@ -58,6 +58,20 @@ def test_c_abi_fails_loudly_without_gpu(built_lib):
     assert b'dmad-hip 0.5' in lib.dmad_version() and lib.dmad_last_warning() == b''
 
 
+def test_c_abi_from_a_plain_c_caller(built_lib, tmp_path):
+    """The boundary is a C ABI: include/dmad.h compiles as strict C99, and a plain-C host (tests/c_abi_caller.c: dlopen + the exports
+    a minimal host needs) sees the revision handshake, the refusal of unsupported geometry and — without a GPU — a loud DMAD_ERR_HIP
+    (on a GPU box: an engine created and destroyed)."""
+    exe = str(tmp_path / 'c_abi_caller')
+    cc = subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', os.path.join(ROOT, 'include'),
+                         os.path.join(ROOT, 'tests', 'c_abi_caller.c'), '-ldl', '-o', exe], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([exe, LIB], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    assert 'library: dmad-hip' in run.stdout
+    assert ('engine destroyed' in run.stdout) if torch.cuda.is_available() else ('DMAD_ERR_HIP' in run.stdout)
+
+
 def test_lds_layouts_are_bank_conflict_free():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'lds_bank_check.py')], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
