@@ -4,7 +4,8 @@
 #   tools/layer_variants.sh run       ON the GPU box: per variant the per-phase cycle stamps (DMAD_LAYER_STAMPS=1), the un-stamped ms per
 #                                     launch and board power / in-kernel clock under back-to-back launches (tools/gpu_power_trace.py)
 # Variants: 0 product (packed fp32 gate math) · 1 the gate's FMA steps as single v_add / v_fma (scalar code, -fno-slp-vectorize) ·
-#           2 ABLATION: no transcendentals (numerically meaningless) · 3 GEMM2's MFMAs interleaved by sched_group_barrier
+#           2 ABLATION: no transcendentals (numerically meaningless) · 3 GEMM2's MFMAs interleaved by sched_group_barrier ·
+#           4 ABLATION: no epilogue (no residual add, no h' stores; tools/patches/wnl_variant4_no_epilogue.patch; VARS="0 4")
 #           -> gpurun_out/layer_variants/summary.txt
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -14,7 +15,13 @@ case "${1:-}" in
 build)
     make -C $PKG/csrc >/dev/null || exit 1
     for v in $VARS; do
-        /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $([ $v = 1 ] && echo -fno-slp-vectorize) ${EXTRA:-} -DWNL_VARIANT=$v -c $PKG/csrc/wn_layer.hip -o /tmp/wn_layer_v$v.o || exit 1
+        src=$PKG/csrc/wn_layer.hip
+        if [ $v = 4 ]; then            # the epilogue ablation lives in a patch (the product source stays under bench.py's hash guard)
+            rm -rf /tmp/wnl_v4 && mkdir -p /tmp/wnl_v4 && cp $PKG/csrc/*.h $PKG/csrc/wn_layer.hip /tmp/wnl_v4/ || exit 1
+            (cd /tmp/wnl_v4 && patch -s -p3 < $ROOT/tools/patches/wnl_variant4_no_epilogue.patch) || exit 1
+            src=/tmp/wnl_v4/wn_layer.hip
+        fi
+        /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $([ $v = 1 ] && echo -fno-slp-vectorize) ${EXTRA:-} -DWNL_VARIANT=$v -c $src -o /tmp/wn_layer_v$v.o || exit 1
         objs=$(ls $PKG/csrc/*.o | grep -v wn_layer.o)
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $PKG/libdmad_hip.so.v$v $objs /tmp/wn_layer_v$v.o || exit 1
         echo "built libdmad_hip.so.v$v"
