@@ -16,10 +16,11 @@ build)
     make -C $PKG/csrc >/dev/null || exit 1
     for v in $VARS; do
         src=$PKG/csrc/wn_layer.hip
-        if [ $v = 4 ]; then            # the epilogue ablation lives in a patch (the product source stays under bench.py's hash guard)
-            rm -rf /tmp/wnl_v4 && mkdir -p /tmp/wnl_v4 && cp $PKG/csrc/*.h $PKG/csrc/wn_layer.hip /tmp/wnl_v4/ || exit 1
-            (cd /tmp/wnl_v4 && patch -s -p3 < $ROOT/tools/patches/wnl_variant4_no_epilogue.patch) || exit 1
-            src=/tmp/wnl_v4/wn_layer.hip
+        if [ $v -ge 4 ]; then          # variants 4-6 live in patches (the product source stays under bench.py's hash guard)
+            pf=$ROOT/tools/patches/wnl_variant4_no_epilogue.patch; [ $v -ge 5 ] && pf=$ROOT/tools/patches/wnl_variant56_idle_cycles.patch
+            rm -rf /tmp/wnl_v$v && mkdir -p /tmp/wnl_v$v && cp $PKG/csrc/*.h $PKG/csrc/wn_layer.hip /tmp/wnl_v$v/ || exit 1
+            (cd /tmp/wnl_v$v && patch -s -p3 < $pf) || exit 1
+            src=/tmp/wnl_v$v/wn_layer.hip
         fi
         /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $([ $v = 1 ] && echo -fno-slp-vectorize) ${EXTRA:-} -DWNL_VARIANT=$v -c $src -o /tmp/wn_layer_v$v.o || exit 1
         objs=$(ls $PKG/csrc/*.o | grep -v wn_layer.o)
