@@ -16,8 +16,8 @@ build)
     make -C $PKG/csrc >/dev/null || exit 1
     for v in $VARS; do
         src=$PKG/csrc/wn_layer.hip
-        if [ $v -ge 4 ]; then          # variants 4-6 live in patches (the product source stays under bench.py's hash guard)
-            pf=$ROOT/tools/patches/wnl_variant4_no_epilogue.patch; [ $v -ge 5 ] && pf=$ROOT/tools/patches/wnl_variant56_idle_cycles.patch
+        if [ $v -ge 4 ]; then          # variants 4-8 live in patches (the product source stays under bench.py's hash guard)
+            pf=$ROOT/tools/patches/wnl_variant4_no_epilogue.patch; [ $v -ge 5 ] && pf=$ROOT/tools/patches/wnl_variant56_idle_cycles.patch; [ $v -ge 7 ] && pf=$ROOT/tools/patches/wnl_variant78_cu_skew.patch
             rm -rf /tmp/wnl_v$v && mkdir -p /tmp/wnl_v$v && cp $PKG/csrc/*.h $PKG/csrc/wn_layer.hip /tmp/wnl_v$v/ || exit 1
             (cd /tmp/wnl_v$v && patch -s -p3 < $pf) || exit 1
             src=/tmp/wnl_v$v/wn_layer.hip
