@@ -72,6 +72,24 @@ def test_c_abi_from_a_plain_c_caller(built_lib, tmp_path):
     assert ('engine destroyed' in run.stdout) if torch.cuda.is_available() else ('DMAD_ERR_HIP' in run.stdout)
 
 
+def test_development_patches_still_apply_to_the_layer_kernel(tmp_path):
+    """tools/patches/*.patch hold the layer kernel's ablation / experiment variants (profiles/r05_layer_gate_variants.md) outside the
+    product source, which is under bench.py's hash guard; tools/layer_variants.sh applies them to a temporary copy.  They must not rot."""
+    import glob
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which('patch') is None:
+        pytest.skip('no patch(1) here')
+    patches = sorted(glob.glob(os.path.join(root, 'tools', 'patches', 'wnl_*.patch')))
+    assert len(patches) >= 3
+    for pf in patches:
+        shutil.copy(os.path.join(root, 'diffusion-model-for-audio-defense_amd', 'csrc', 'wn_layer.hip'), tmp_path / 'wn_layer.hip')
+        with open(pf) as f:
+            run = subprocess.run(['patch', '-s', '-p3'], stdin=f, cwd=tmp_path, capture_output=True, text=True)
+        assert run.returncode == 0, (pf, run.stdout, run.stderr)
+        assert 'WNL_VARIANT ==' in (tmp_path / 'wn_layer.hip').read_text()
+
+
 def test_lds_layouts_are_bank_conflict_free():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'lds_bank_check.py')], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
